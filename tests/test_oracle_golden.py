@@ -1,0 +1,140 @@
+"""CPU: the NumPy oracle reproduces the reference bit-for-bit on every golden vector.
+
+The fixtures were captured from the imported reference by oracle/capture_golden.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import mjhmc_oracle as orc
+from tests.helpers import load, oracle_energy, bits_equal
+
+np.seterr(all='ignore')
+
+
+def test_g1_min_idx():
+    g = load('g1_min_idx')                                    # mjhmc/tests/test_utils.py:15-52
+    (i0, i1), _ = orc.first_minimum([g['a'].reshape(1, -1), g['b'].reshape(1, -1)])
+    assert np.array_equal(i0, g['two_0']) and np.array_equal(i1, g['two_1'])
+    assert np.array_equal(i0, np.arange(100)[g['a'] < g['b']])
+    (j0, j1, j2), _ = orc.first_minimum([g[k].reshape(1, -1) for k in 'cde'])
+    assert np.array_equal(j0, g['three_0']) and np.array_equal(j1, g['three_1']) and np.array_equal(j2, g['three_2'])
+    (t0, t1, t2), _ = orc.first_minimum([g['t'], g['u'], g['v']])
+    assert np.array_equal(t0, g['ties_0']) and np.array_equal(t1, g['ties_1']) and np.array_equal(t2, g['ties_2'])
+
+
+@pytest.mark.parametrize('tag,kind,par', [
+    ('iso_2x100', 'iso', dict(sigma=1.3)), ('iso_512x64', 'iso', dict(sigma=1.3)),
+    ('diag_10x33', 'diag', dict(ndims=10, log_conditioning=6)), ('rough_5x40', 'rough', dict(scale1=100, scale2=4)),
+    ('mm_3x20', 'mm', dict(ndims=3, separation=3))])
+def test_g2_energy_evaluations(tag, kind, par):
+    g = load('g2_energies')
+    cls = {'iso': orc.IsoGaussian, 'diag': orc.DiagGaussian, 'rough': orc.RoughWell, 'mm': orc.MultimodalGaussian}[kind]
+    e = cls(**par)
+    X = g[tag + '_X']
+    assert bits_equal(np.asarray(e.E_val(X)).reshape(-1), g[tag + '_E'])
+    assert bits_equal(e.dEdX_val(X), g[tag + '_g'])
+    idx = np.arange(0, X.shape[1], 2)
+    assert bits_equal(np.asarray(e.E_val(X[:, idx])).reshape(-1), g[tag + '_Eg'])
+    assert bits_equal(e.dEdX_val(X[:, idx]), g[tag + '_gg'])
+
+
+@pytest.mark.parametrize('tag,kind', [('iso_2x100', 'iso'), ('iso_512x32', 'iso'), ('diag_16x24', 'diag'), ('rough_4x16', 'rough')])
+def test_g3_trajectories(tag, kind):
+    g = load('g3_trajectories')
+    X0, V0 = g[tag + '_X0'], g[tag + '_V0']
+    eps, L = g[tag + '_hp']
+    if kind == 'iso':
+        en = orc.IsoGaussian(sigma=1.3)
+    elif kind == 'diag':
+        en = orc.DiagGaussian(ndims=X0.shape[0], log_conditioning=2)
+    else:
+        en = orc.RoughWell(100, 4)
+    s = orc.MarkovJumpHMC(en, X0, epsilon=float(eps), beta=0.3, num_leapfrog_steps=int(L), V0=V0, rng=orc.ReplayRNG())
+    assert bits_equal(s.state.EX[0], g[tag + '_EX0']) and bits_equal(s.state.EV[0], g[tag + '_EV0'])
+    assert bits_equal(s.state.dEdX, g[tag + '_g0'])
+    for nm, z in (('L', s.state.clone().L()), ('FLF', s.state.clone().FLF())):
+        for f, arr in (('X', z.X), ('V', z.V), ('EX', z.EX[0]), ('EV', z.EV[0]), ('g', z.dEdX)):
+            assert bits_equal(arr, g['%s_%s_%s' % (tag, nm, f)]), (tag, nm, f)
+
+
+G4 = ['g4_iso_2x100_a', 'g4_iso_2x100_b', 'g4_diag_16x64', 'g4_iso_512x32', 'g4_rough_4x48', 'g4_mm_3x40',
+      'g4_iso_33x17', 'g6_retry_a_iso_4x32', 'g6_retry_b_iso_4x32']
+
+
+@pytest.mark.parametrize('name', G4)
+def test_g4_g6_sampling_iteration_replay(name):
+    g = load(name)
+    en = oracle_energy(g)
+    rng = orc.ReplayRNG(normals=list(g['normals'][1:]), exps=list(g['exps']))
+    s = orc.MarkovJumpHMC(en, g['Xinit'], epsilon=float(g['eps']), beta=float(g['beta']),
+                          num_leapfrog_steps=int(g['L']), V0=g['normals'][0], rng=rng, resample=False)
+    assert s.p_r == float(g['p_r'])
+    T = int(g['T'])
+    for t in range(T + 1):
+        if t:
+            s.sampling_iteration()
+            assert np.array_equal(s.last_transition, g['trans'][t - 1]), (name, t)
+            assert bits_equal(s.dwelling_times, g['dwell'][t]), (name, t)
+        st = s.state
+        for f, arr in (('X', st.X), ('V', st.V), ('EX', st.EX[0]), ('EV', st.EV[0])):
+            assert bits_equal(arr, g[f][t]), (name, t, f)
+        if 'dEdX' in g.files:
+            assert bits_equal(st.dEdX, g['dEdX'][t])
+        assert np.array_equal(st.shadow_ok, g['cache'][t])
+        assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t])
+        assert [en.E_count, en.dEdX_count] == list(g['evals'][t])
+        assert rng.attempt == int(g['attempts_done'][t])
+        assert (s.epsilon, s.num_leapfrog_steps) == (g['hp'][t][0], int(g['hp'][t][1]))
+    if name.startswith('g6'):
+        assert rng.attempt > T                                  # the retry path really ran
+
+
+def test_g5_sample_with_resampling():
+    g = load('g5_sample_2x100')
+    en = orc.IsoGaussian(sigma=1.0)
+    rng = orc.ReplayRNG(normals=list(g['normals'][1:]), exps=list(g['exps']), uniforms=[g['resample_u']])
+    s = orc.MarkovJumpHMC(en, g['Xinit'], epsilon=float(g['eps']), beta=float(g['beta']),
+                          num_leapfrog_steps=int(g['L']), V0=g['normals'][0], rng=rng)
+    out = s.sample(int(g['n_samples']))
+    assert out.shape == (2, 1000)
+    assert bits_equal(out, g['samples'])
+    assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'])
+    assert [en.E_count, en.dEdX_count] == list(g['evals'])
+
+
+@pytest.mark.parametrize('name', ['g7_control_iso_2x100', 'g7_hmc_diag_8x32', 'g7_base_iso_3x50'])
+def test_g7_control_samplers(name):
+    g = load(name)
+    en = oracle_energy(g)
+    uni = []
+    for t in range(int(g['T'])):
+        uni += [g['u_acc'][t], g['u_flip'][t], g['u_r'][t]]
+    rng = orc.ReplayRNG(normals=list(g['normals'][1:]), uniforms=uni)
+    cls = getattr(orc, str(g['cls']))
+    s = cls(en, g['Xinit'], epsilon=float(g['eps']), beta=float(g['beta_in']), num_leapfrog_steps=int(g['L']),
+            V0=g['normals'][0], rng=rng)
+    assert (s.beta, s.p_r, s.p_flip) == (float(g['beta']), float(g['p_r']), float(g['p_flip']))
+    for t in range(int(g['T']) + 1):
+        if t:
+            s.sampling_iteration()
+        st = s.state
+        for f, arr in (('X', st.X), ('V', st.V), ('EX', st.EX[0]), ('EV', st.EV[0]), ('dEdX', st.dEdX)):
+            assert bits_equal(arr, g[f][t]), (name, t, f)
+        assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t])
+        assert [en.E_count, en.dEdX_count] == list(g['evals'][t])
+        assert rng.n_normals_used == int(g['normals_done'][t]) - 1
+
+
+def test_global_rng_mode_equals_replay():
+    """Seeding np.random and letting the oracle draw in the reference's order gives the same chain
+    as replaying what the reference drew (pins the draw ORDER, utils.py:37-42 / hmc_state.py:125)."""
+    g = load('g4_diag_16x64')
+    en = oracle_energy(g)
+    np.random.seed(103)
+    X0 = np.random.randn(16, 64)
+    assert bits_equal(X0, g['Xinit'])
+    s = orc.MarkovJumpHMC(en, X0, epsilon=float(g['eps']), beta=float(g['beta']), num_leapfrog_steps=int(g['L']),
+                          resample=False)
+    for t in range(1, int(g['T']) + 1):
+        s.sampling_iteration()
+        assert bits_equal(s.state.X, g['X'][t]) and bits_equal(s.state.V, g['V'][t])
