@@ -1,0 +1,186 @@
+/*
+ * mjhmc_hip.h -- C ABI of libmjhmc_hip.so, the MI355X (gfx950) engine for the particle-parallel
+ * Markov-Jump-HMC hot path of rueberger/MJHMC.
+ *
+ * The reference has no FFI: its hot path is NumPy called from Python classes.  Each entry point
+ * below replaces the reference interface cited next to it (paths relative to the reference
+ * root); a reference maintainer binds them with ctypes.
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes.  Return 0 on success, a negative mjhmc_status
+ *     otherwise; the message is available from mjhmc_last_error().  Nothing throws across the ABI.
+ *   - Every pointer argument is caller-owned HOST memory, valid for the duration of the call.
+ *     Matrices are C-ordered (ndims, nparticles) float64 exactly like the reference's arrays
+ *     (mjhmc/samplers/markov_jump_hmc.py:29); the engine re-tiles them on the device.
+ *   - Device memory is owned by the handles.  One HIP stream per sampler.  A handle is not
+ *     thread-safe; distinct handles are independent.  No process-global mutable state except
+ *     the last-error string of failed *_create calls (thread-local).
+ */
+#ifndef MJHMC_HIP_H
+#define MJHMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJHMC_ABI_VERSION 1
+
+typedef struct mjhmc_ctx mjhmc_ctx;         /* one per process x device                          */
+typedef struct mjhmc_energy mjhmc_energy;   /* an energy model, parameters resident in HBM       */
+typedef struct mjhmc_sampler mjhmc_sampler; /* particle state (HMCState) + jump-process machinery */
+
+typedef enum {
+  MJHMC_OK = 0,
+  MJHMC_ERR_INVALID = -1,      /* bad argument                                                   */
+  MJHMC_ERR_HIP = -2,          /* a HIP runtime call failed                                      */
+  MJHMC_ERR_UNSUPPORTED = -3,  /* e.g. ndims too large for the fused register kernel             */
+  MJHMC_ERR_NO_DEVICE = -4,
+  MJHMC_ERR_NONFINITE = -5     /* informational: see mjhmc_iterate                               */
+} mjhmc_status;
+
+/* Energy models.  params are float64; layout per kind:
+ *   ISO_GAUSS   {sigma}                         TestGaussian  mjhmc/misc/distributions.py:348-362, README.md:18-24
+ *   DIAG_GAUSS  {j_0..j_{D-1}} diagonal of J    Gaussian      mjhmc/misc/distributions.py:256-273
+ *   ROUGH_WELL  {scale1, scale2}                RoughWell     mjhmc/misc/distributions.py:283-304
+ *   MM_GAUSS    {separation}                    MultimodalGaussian mjhmc/misc/distributions.py:314-335
+ *   FUNNEL_NEAL {scale}                         Funnel as documented, mjhmc/misc/tf_distributions.py:142-147
+ *   FUNNEL_REF  {scale}                         Funnel as coded,      mjhmc/misc/tf_distributions.py:157-165
+ *   PRODUCT_OF_T {nbasis, W[D*nbasis] row-major (D,nbasis), nu[nbasis], b[nbasis]}
+ *                                               ProductOfT    mjhmc/misc/distributions.py:373-433
+ *   SPARSE_CODE {n_patches, img, n_coeffs, lambda, cauchy, B[img*n_coeffs], Y[n_patches*img]}
+ *                                               SparseImageCode mjhmc/misc/tf_distributions.py:204-272
+ */
+typedef enum {
+  MJHMC_E_ISO_GAUSS = 0,
+  MJHMC_E_DIAG_GAUSS = 1,
+  MJHMC_E_ROUGH_WELL = 2,
+  MJHMC_E_MM_GAUSS = 3,
+  MJHMC_E_FUNNEL_NEAL = 4,
+  MJHMC_E_FUNNEL_REF = 5,
+  MJHMC_E_PRODUCT_OF_T = 6,
+  MJHMC_E_SPARSE_CODE = 7
+} mjhmc_energy_kind;
+
+typedef enum { MJHMC_F64 = 0, MJHMC_F32 = 1 } mjhmc_dtype;  /* arithmetic type of state and force */
+
+/* Sampler families (mjhmc/samplers/markov_jump_hmc.py). */
+typedef enum {
+  MJHMC_MODE_MJHMC = 0,   /* MarkovJumpHMC.sampling_iteration      :355-415 */
+  MJHMC_MODE_CONTROL = 1, /* HMCBase / HMC / ControlHMC            :116-148 */
+  MJHMC_MODE_CTHMC = 2    /* ContinuousTimeHMC.sampling_iteration  :251-290 */
+} mjhmc_mode;
+
+/* State fields (mjhmc/samplers/hmc_state.py:13-44) readable / writable through mjhmc_read/write.
+ * Matrix fields are (ndims, nparticles) float64 C-order on the host side. */
+typedef enum {
+  MJHMC_F_X = 0,      /* HMCState.X                                  float64 (D,N)  rw */
+  MJHMC_F_V = 1,      /* HMCState.V                                  float64 (D,N)  rw */
+  MJHMC_F_EX = 2,     /* HMCState.EX                                 float64 (N)    r  */
+  MJHMC_F_EV = 3,     /* HMCState.EV                                 float64 (N)    r  */
+  MJHMC_F_DEDX = 4,   /* HMCState.dEdX (recomputed from X on demand) float64 (D,N)  r  */
+  MJHMC_F_HFLF = 5,   /* H() of HMCState.cached_flf_state            float64 (N)    r  */
+  MJHMC_F_CACHE = 6,  /* HMCState.cache_active                       uint8   (N)    rw */
+  MJHMC_F_DWELL = 7,  /* ContinuousTimeHMC.dwelling_times            float64 (N)    r  */
+  MJHMC_F_TRANS = 8   /* argmin row of min_idx (0=L,1=F,2=R; CONTROL: bit0=FL accepted, bit1=flipped) uint8 (N) r */
+} mjhmc_field;
+
+/* Integer bookkeeping of one sampling_iteration attempt (bit-exact with the reference):
+ * l/f/r/fl follow the sampler's l_count/f_count/r_count/fl_count increments
+ * (markov_jump_hmc.py:143-148,288-290,413-415); E_evals/dEdX_evals are the increments of
+ * Distribution.E_count / dEdX_count (mjhmc/misc/distributions.py:62-75). */
+typedef struct {
+  int64_t l, f, r, fl;
+  int64_t n_cold;      /* particles whose inverse-L proposal had to be integrated (cold FLF cache) */
+  int64_t E_evals;
+  int64_t dEdX_evals;
+  int32_t nonfinite;   /* 1: some particle produced a non-finite rate (utils.py:41-48); the attempt
+                          was NOT committed, state is as before the attempt                        */
+  int32_t L_used;
+  double eps_used;
+} mjhmc_iter_stats;
+
+const char* mjhmc_last_error(void);
+int mjhmc_abi_version(void);
+
+int mjhmc_ctx_create(int device, mjhmc_ctx** out);
+int mjhmc_ctx_destroy(mjhmc_ctx* ctx);
+/* name, CU count, HBM bytes of the bound device */
+int mjhmc_ctx_info(mjhmc_ctx* ctx, char* name, size_t name_cap, int* n_cu, uint64_t* hbm_bytes);
+
+/* Replaces constructing a Distribution subclass (mjhmc/misc/distributions.py:20-59). */
+int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* params, size_t nparams,
+                        mjhmc_energy** out);
+int mjhmc_energy_destroy(mjhmc_energy* e);
+
+/* One evaluation of E_val / dEdX_val (mjhmc/misc/distributions.py:66-81) on n columns.
+ * E_out (n) and dEdX_out (D,n) may each be NULL. */
+int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E_out, double* dEdX_out);
+
+/* Replaces HMCState.__init__ (mjhmc/samplers/hmc_state.py:13-44) as called from
+ * ContinuousTimeHMC.__init__ / HMCBase.__init__ (markov_jump_hmc.py:46-65,225-234).
+ *   Xinit (D,N) float64.  Vinit (D,N) float64 or NULL -> standard normals from the counter RNG
+ *   (tick 0).  first_particle_id: global id of column 0 (shard offset); the RNG is keyed by
+ *   global id so results do not depend on how columns are sharded over GPUs. */
+int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, int64_t first_particle_id,
+                         int dtype, const double* Xinit, const double* Vinit, uint64_t seed, int mode,
+                         mjhmc_sampler** out);
+int mjhmc_sampler_destroy(mjhmc_sampler* s);
+
+/* epsilon, num_leapfrog_steps, p_r, beta as used by HMCState.R, p_flip
+ * (markov_jump_hmc.py:67-80,189,197-200,221-223). */
+int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, double p_r, double beta,
+                      double p_flip);
+
+/* Runs up to n_iter sampling_iteration()s back to back on the sampler's stream with no host
+ * round trip in between.  Stops early when an attempt hits a non-finite rate: that attempt is
+ * rolled back (nothing committed), *n_done is the number of committed iterations, and the
+ * caller performs the reference's halve-epsilon / double-L / reset_flf_cache / retry / restore
+ * sequence (markov_jump_hmc.py:376-389) through mjhmc_set_hparams + mjhmc_reset_flf_cache +
+ * mjhmc_iterate(1).  Return value stays 0 in that case.
+ *
+ * Replay inputs (all nullable; NULL -> counter RNG):
+ *   replay_normal (n_iter, D, N) the randn blocks of HMCState.R (hmc_state.py:125)
+ *   replay_exp    (n_iter, 3, N) unit exponentials behind draw_from (utils.py:42), rows L,F,R
+ *                 (MJHMC) or FL,F,R (CTHMC)
+ *   replay_unif   (n_iter, 2N+1) CONTROL mode: rand(N) accept, rand(N) flip, random() R gate
+ * per_iter: n_iter entries (nullable); entry i describes attempt i (valid for i <= *n_done).
+ * ring_slot0 >= 0: iteration i additionally records its post-jump X in ring slot ring_slot0+i
+ * and its dwelling times in dwell slot ring_slot0+i (see mjhmc_ring_alloc). */
+int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
+                  const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
+
+/* HMCState.reset_flf_cache (hmc_state.py:145-148). */
+int mjhmc_reset_flf_cache(mjhmc_sampler* s);
+
+/* Field access for sampler.state.X / .V / .EX / ... and HMCState assignment (figures/poe_fig.py:59).
+ * Writing X or V re-derives EX/EV on the device and clears the FLF cache. */
+int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes);
+int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes);
+
+/* Sample ring for ContinuousTimeHMC.sample / HMCBase.sample (markov_jump_hmc.py:150-173,293-338):
+ * n_slots snapshots of X (device resident) and of dwelling_times. */
+int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots);
+/* dwell of slots [slot0, slot0+n) -> (n, N) float64 */
+int mjhmc_ring_read_dwell(mjhmc_sampler* s, int slot0, int n, double* host_dst);
+/* out[:, k] = X_slot[idx[k] / N][:, idx[k] % N] for k < n, i.e. the column gather of
+ * `samples[:, sample_idx]` (markov_jump_hmc.py:322-328) with idx into the time-major pool.
+ * out is (D, n) float64. */
+int mjhmc_ring_gather(mjhmc_sampler* s, const int64_t* idx, int64_t n, double* host_out);
+/* whole slots [slot0, slot0+n): (D, n*N) time-major if stacked==0 (np.concatenate(axis=1)),
+ * (D, N, n) if stacked==1 (np.stack(axis=-1)). */
+int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* host_out);
+
+/* Device-time of the last mjhmc_iterate call in milliseconds (HIP events on the sampler's
+ * stream): total, and the sum over its jump-kernel launches. */
+int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms, int* n_jump_launches);
+
+/* Stream synchronisation (bench harness). */
+int mjhmc_sync(mjhmc_sampler* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJHMC_HIP_H */

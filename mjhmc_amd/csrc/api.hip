@@ -1,0 +1,955 @@
+// C ABI of libmjhmc_hip.so (include/mjhmc_hip.h): handle management, host<->device re-tiling,
+// launch sequencing of the fused jump kernels, integer bookkeeping, the sample ring.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mjhmc_hip.h"
+#include "elementwise.hpp"
+
+using namespace mjhmc;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                    \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(MJHMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ +  \
+                                     ":" + std::to_string(__LINE__) + ")");                             \
+  } while (0)
+
+#define TRY(expr)             \
+  do {                        \
+    int r_ = (expr);          \
+    if (r_ != 0) return r_;   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct mjhmc_ctx {
+  int device;
+  hipDeviceProp_t prop;
+};
+
+struct mjhmc_energy {
+  mjhmc_ctx* ctx;
+  EnergyParams ep;
+  std::vector<double> params;
+  void* dev64 = nullptr;
+  void* dev32 = nullptr;
+};
+
+struct Shape {
+  int E, logG, pitch, CH, esize;
+};
+
+static const int kMaxTimed = 256;
+
+struct mjhmc_sampler {
+  mjhmc_ctx* ctx;
+  mjhmc_energy* en;
+  int64_t N, first_pid;
+  int D, dtype, mode;
+  Shape sh;
+  hipStream_t stream = nullptr;
+  void* Xbuf[2] = {nullptr, nullptr};
+  void* Vbuf[2] = {nullptr, nullptr};
+  void* Xcur = nullptr;
+  int vcur = 0, scur = 0;
+  void* EX[2] = {nullptr, nullptr};
+  void* EV[2] = {nullptr, nullptr};
+  void* Hflf[2] = {nullptr, nullptr};
+  uint8_t* cache[2] = {nullptr, nullptr};
+  double* dwell = nullptr;
+  uint8_t* trans = nullptr;
+  Control* ctl = nullptr;
+  long long* stats = nullptr;  // [stats_cap][4]
+  int stats_cap = 0;
+  void* ring = nullptr;
+  double* dwell_ring = nullptr;
+  int ring_slots = 0;
+  double* stage = nullptr;  // device staging, float64 host layout
+  size_t stage_elems = 0;
+  void* noise = nullptr;    // replay normals, particle-major
+  double* rexp = nullptr;   // [3][N]
+  double* runif = nullptr;  // [2N+1]
+  void* scratch = nullptr;  // [N][pitch] scratch (dEdX reads)
+  double eps = 1e-4, p_r = 0, beta = 1, p_flip = 0.5;
+  int L = 5;
+  uint64_t seed = 0, tick = 1;
+  hipEvent_t ev_total[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_k;
+  double last_total_ms = 0, last_jump_ms = 0;
+  int last_jump_launches = 0;
+};
+
+static size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s->sh.esize; }
+static size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->N * row_bytes(s); }
+
+static int pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// lanes-per-particle / elements-per-lane selection (see elementwise.hpp header comment)
+static int pick_shape(int D, int dtype, Shape* out) {
+  const int esize = dtype == MJHMC_F64 ? 8 : 4;
+  const int VEC = 16 / esize;
+  Shape s;
+  s.esize = esize;
+  s.pitch = (D + VEC - 1) / VEC * VEC;
+  s.CH = s.pitch / VEC;
+  int C, G;
+  if (s.CH <= 1) {
+    C = 1;
+    G = 1;
+  } else {
+    C = 4;
+    G = pow2ceil((s.CH + 3) / 4);
+    if (G > 64) {
+      C = 8;
+      G = pow2ceil((s.CH + 7) / 8);
+    }
+    if (G > 64) return fail(MJHMC_ERR_UNSUPPORTED, "ndims too large for the register-resident jump kernel");
+  }
+  s.E = C * VEC;
+  s.logG = ilog2(G);
+  *out = s;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small kernels: re-tiling between the reference's (ndims, nparticles) float64 host layout and
+// the particle-major device layout; integer bookkeeping
+// ---------------------------------------------------------------------------------------------
+
+// src (D, N) float64 row-major  ->  dst [N][pitch] T ; only d < D is written
+template <typename T>
+__global__ void to_particle_major(const double* __restrict__ src, T* __restrict__ dst, int D, int64_t N, int pitch) {
+  __shared__ double tile[32][33];
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int d0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int dd = threadIdx.y + 8 * i;
+    const int d = d0 + dd;
+    const int64_t p = p0 + threadIdx.x;
+    if (d < D && p < N) tile[dd][threadIdx.x] = src[(size_t)d * N + p];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pp = threadIdx.y + 8 * i;
+    const int64_t p = p0 + pp;
+    const int d = d0 + threadIdx.x;
+    if (d < D && p < N) dst[(size_t)p * pitch + d] = (T)tile[threadIdx.x][pp];
+  }
+}
+
+// dst[d*rs + k*cs + off] = src[row(k)][d],  row(k) = idx ? idx[k] : k
+template <typename T>
+__global__ void to_dim_major(const T* __restrict__ src, const int64_t* __restrict__ idx, double* __restrict__ dst,
+                             int D, int64_t ncols, int pitch, int64_t rs, int64_t cs, int64_t off) {
+  __shared__ double tile[32][33];
+  const int64_t k0 = (int64_t)blockIdx.x * 32;
+  const int d0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kk = threadIdx.y + 8 * i;
+    const int64_t k = k0 + kk;
+    const int d = d0 + threadIdx.x;
+    if (d < D && k < ncols) {
+      const int64_t row = idx ? idx[k] : k;
+      tile[kk][threadIdx.x] = (double)src[(size_t)row * pitch + d];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int dd = threadIdx.y + 8 * i;
+    const int d = d0 + dd;
+    const int64_t k = k0 + threadIdx.x;
+    if (d < D && k < ncols) dst[(size_t)d * rs + (size_t)k * cs + off] = tile[threadIdx.x][dd];
+  }
+}
+
+template <typename T>
+__global__ void widen_vec(const T* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i];
+}
+
+// stats[0..3] += (#trans==0, #trans==1, #trans==2, #cold) for one attempt.
+// Control mode: trans bit0 = FL accepted, bit1 = flipped -> (both, flip only, -, accept only)
+__global__ void count_kernel(const uint8_t* __restrict__ trans, const uint8_t* __restrict__ cache_in, int64_t N,
+                             const Control* ctl, int iter, int control_mode, unsigned long long* stats) {
+  const bool failed = ctl->failed != 0;
+  if (failed && ctl->failed_iter < iter) return;
+  const bool failed_now = failed && ctl->failed_iter == iter;
+  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = trans[i];
+    if (control_mode) {
+      c0 += (t == 3);
+      c1 += (t == 2);
+      c3 += (t == 1);
+    } else {
+      if (!failed_now) {
+        c0 += (t == 0);
+        c1 += (t == 1);
+        c2 += (t == 2);
+      }
+      c3 += (cache_in[i] == 0);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    c0 += __shfl_xor(c0, o);
+    c1 += __shfl_xor(c1, o);
+    c2 += __shfl_xor(c2, o);
+    c3 += __shfl_xor(c3, o);
+  }
+  __shared__ unsigned long long sm[4][4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[w][0] = c0;
+    sm[w][1] = c1;
+    sm[w][2] = c2;
+    sm[w][3] = c3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sm[k][threadIdx.x];
+    if (t) atomicAdd(&stats[threadIdx.x], t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch over energies / dtypes
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int dispatch_jump(int kind, const JumpArgs<T>& a, const EnergyParams& ep, int E, hipStream_t st);
+
+template <>
+int dispatch_jump<double>(int kind, const JumpArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_jump_f64(a, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_jump_f64(a, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_jump_f64(a, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_jump_f64(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_jump_f64(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_jump_f64(a, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no fused jump kernel yet");
+  }
+  return 0;
+}
+template <>
+int dispatch_jump<float>(int kind, const JumpArgs<float>& a, const EnergyParams& ep, int E, hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_jump_f32(a, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_jump_f32(a, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_jump_f32(a, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_jump_f32(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_jump_f32(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_jump_f32(a, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no fused jump kernel yet");
+  }
+  return 0;
+}
+
+template <typename T>
+static int dispatch_eval(int kind, const EvalArgs<T>& a, const EnergyParams& ep, int E, hipStream_t st);
+template <>
+int dispatch_eval<double>(int kind, const EvalArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_eval_f64(a, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_eval_f64(a, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_eval_f64(a, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_eval_f64(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_eval_f64(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_eval_f64(a, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no evaluation kernel yet");
+  }
+  return 0;
+}
+template <>
+int dispatch_eval<float>(int kind, const EvalArgs<float>& a, const EnergyParams& ep, int E, hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_eval_f32(a, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_eval_f32(a, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_eval_f32(a, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_eval_f32(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_eval_f32(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_eval_f32(a, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no evaluation kernel yet");
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers on a sampler
+// ---------------------------------------------------------------------------------------------
+static int ensure_stage(mjhmc_sampler* s, size_t elems) {
+  if (s->stage_elems >= elems) return 0;
+  if (s->stage) HIPCHK(hipFree(s->stage));
+  s->stage = nullptr;
+  s->stage_elems = 0;
+  HIPCHK(hipMalloc(&s->stage, elems * sizeof(double)));
+  s->stage_elems = elems;
+  return 0;
+}
+
+// host (D, N) float64 -> device particle-major matrix `dst` (stream ordered)
+static int upload_matrix(mjhmc_sampler* s, const double* host, void* dst) {
+  TRY(ensure_stage(s, (size_t)s->D * s->N));
+  HIPCHK(hipMemcpyAsync(s->stage, host, (size_t)s->D * s->N * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  dim3 grid((unsigned)((s->N + 31) / 32), (unsigned)((s->D + 31) / 32)), block(32, 8);
+  if (s->dtype == MJHMC_F64)
+    hipLaunchKernelGGL(to_particle_major<double>, grid, block, 0, s->stream, s->stage, (double*)dst, s->D, s->N,
+                       s->sh.pitch);
+  else
+    hipLaunchKernelGGL(to_particle_major<float>, grid, block, 0, s->stream, s->stage, (float*)dst, s->D, s->N,
+                       s->sh.pitch);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// device particle-major rows -> host float64 with strides (see to_dim_major)
+static int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_idx, int64_t ncols, double* host,
+                         size_t host_elems, int64_t rs, int64_t cs, int64_t off, bool copy_out) {
+  dim3 grid((unsigned)((ncols + 31) / 32), (unsigned)((s->D + 31) / 32)), block(32, 8);
+  if (s->dtype == MJHMC_F64)
+    hipLaunchKernelGGL(to_dim_major<double>, grid, block, 0, s->stream, (const double*)src, dev_idx, s->stage, s->D,
+                       ncols, s->sh.pitch, rs, cs, off);
+  else
+    hipLaunchKernelGGL(to_dim_major<float>, grid, block, 0, s->stream, (const float*)src, dev_idx, s->stage, s->D,
+                       ncols, s->sh.pitch, rs, cs, off);
+  HIPCHK(hipGetLastError());
+  if (copy_out) {
+    HIPCHK(hipMemcpyAsync(host, s->stage, host_elems * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+  }
+  return 0;
+}
+
+template <typename T>
+static int run_eval_t(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
+  EvalArgs<T> a;
+  a.X = (const T*)X;
+  a.G = (T*)Gout;
+  a.E = (T*)Eout;
+  a.EV = (T*)EVout;
+  a.V = (const T*)V;
+  a.V_out = (T*)Vgen;
+  a.N = s->N;
+  a.first_pid = s->first_pid;
+  a.D = s->D;
+  a.pitch = s->sh.pitch;
+  a.CH = s->sh.CH;
+  a.logG = s->sh.logG;
+  a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), 0u, 0u};
+  TRY(dispatch_eval<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
+  return s->dtype == MJHMC_F64 ? run_eval_t<double>(s, X, Gout, Eout, V, Vgen, EVout)
+                               : run_eval_t<float>(s, X, Gout, Eout, V, Vgen, EVout);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mjhmc_last_error(void) { return g_err.c_str(); }
+int mjhmc_abi_version(void) { return MJHMC_ABI_VERSION; }
+
+int mjhmc_ctx_create(int device, mjhmc_ctx** out) {
+  if (!out) return fail(MJHMC_ERR_INVALID, "out is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(MJHMC_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(MJHMC_ERR_INVALID, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  mjhmc_ctx* c = new mjhmc_ctx();
+  c->device = device;
+  HIPCHK(hipGetDeviceProperties(&c->prop, device));
+  *out = c;
+  return 0;
+}
+
+int mjhmc_ctx_destroy(mjhmc_ctx* ctx) {
+  delete ctx;
+  return 0;
+}
+
+int mjhmc_ctx_info(mjhmc_ctx* ctx, char* name, size_t name_cap, int* n_cu, uint64_t* hbm_bytes) {
+  if (!ctx) return fail(MJHMC_ERR_INVALID, "ctx is NULL");
+  if (name && name_cap) {
+    std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;
+  return 0;
+}
+
+int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* params, size_t nparams,
+                        mjhmc_energy** out) {
+  if (!ctx || !out) return fail(MJHMC_ERR_INVALID, "ctx/out is NULL");
+  if (ndims < 1) return fail(MJHMC_ERR_INVALID, "ndims must be >= 1");
+  if (nparams && !params) return fail(MJHMC_ERR_INVALID, "params is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  mjhmc_energy* e = new mjhmc_energy();
+  e->ctx = ctx;
+  e->params.assign(params, params + nparams);
+  std::memset(&e->ep, 0, sizeof(e->ep));
+  e->ep.kind = kind;
+  e->ep.ndims = ndims;
+  auto need = [&](size_t n) { return nparams == n; };
+  int rc = 0;
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS:
+      if (!need(1) || !(params[0] > 0)) rc = fail(MJHMC_ERR_INVALID, "ISO_GAUSS expects {sigma > 0}");
+      else e->ep.p[0] = params[0];
+      break;
+    case MJHMC_E_ROUGH_WELL:
+      if (!need(2)) rc = fail(MJHMC_ERR_INVALID, "ROUGH_WELL expects {scale1, scale2}");
+      else {
+        e->ep.p[0] = params[0];
+        e->ep.p[1] = params[1];
+      }
+      break;
+    case MJHMC_E_MM_GAUSS:
+    case MJHMC_E_FUNNEL_NEAL:
+    case MJHMC_E_FUNNEL_REF:
+      if (!need(1)) rc = fail(MJHMC_ERR_INVALID, "expects one scalar parameter");
+      else e->ep.p[0] = params[0];
+      break;
+    case MJHMC_E_DIAG_GAUSS: {
+      if (!need((size_t)ndims)) {
+        rc = fail(MJHMC_ERR_INVALID, "DIAG_GAUSS expects ndims diagonal entries");
+        break;
+      }
+      if (ndims > kParamPad) {
+        rc = fail(MJHMC_ERR_UNSUPPORTED, "ndims too large");
+        break;
+      }
+      std::vector<double> h64(kParamPad, 0.0);
+      std::vector<float> h32(kParamPad, 0.f);
+      for (int i = 0; i < ndims; ++i) {
+        h64[i] = params[i];
+        h32[i] = (float)params[i];
+      }
+      if (hipMalloc(&e->dev64, kParamPad * sizeof(double)) != hipSuccess ||
+          hipMalloc(&e->dev32, kParamPad * sizeof(float)) != hipSuccess ||
+          hipMemcpy(e->dev64, h64.data(), kParamPad * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(e->dev32, h32.data(), kParamPad * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(MJHMC_ERR_HIP, "allocating DIAG_GAUSS parameters failed");
+      e->ep.dev_f64 = e->dev64;
+      e->ep.dev_f32 = e->dev32;
+      break;
+    }
+    default:
+      rc = fail(MJHMC_ERR_UNSUPPORTED, "energy kind not implemented in this build");
+  }
+  if (rc) {
+    mjhmc_energy_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+int mjhmc_energy_destroy(mjhmc_energy* e) {
+  if (!e) return 0;
+  if (e->dev64) (void)hipFree(e->dev64);
+  if (e->dev32) (void)hipFree(e->dev32);
+  delete e;
+  return 0;
+}
+
+int mjhmc_sampler_destroy(mjhmc_sampler* s) {
+  if (!s) return 0;
+  (void)hipSetDevice(s->ctx->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  void* ptrs[] = {s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
+                  s->EV[1],   s->Hflf[0], s->Hflf[1],  s->cache[0], s->cache[1], s->dwell,  s->trans,
+                  s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
+                  s->runif,   s->scratch};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& e : s->ev_total)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : s->ev_k) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return 0;
+}
+
+int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, int64_t first_particle_id, int dtype,
+                         const double* Xinit, const double* Vinit, uint64_t seed, int mode, mjhmc_sampler** out) {
+  if (!ctx || !e || !out || !Xinit) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (nparticles < 1) return fail(MJHMC_ERR_INVALID, "nparticles must be >= 1");
+  if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
+  if (mode != MJHMC_MODE_MJHMC) return fail(MJHMC_ERR_UNSUPPORTED, "only MJHMC mode is built so far");
+  if (first_particle_id < 0 || first_particle_id + nparticles > 0xFFFFFFFFLL)
+    return fail(MJHMC_ERR_INVALID, "global particle ids must fit 32 bits");
+  HIPCHK(hipSetDevice(ctx->device));
+  mjhmc_sampler* s = new mjhmc_sampler();
+  s->ctx = ctx;
+  s->en = e;
+  s->N = nparticles;
+  s->first_pid = first_particle_id;
+  s->D = e->ep.ndims;
+  s->dtype = dtype;
+  s->mode = mode;
+  s->seed = seed;
+  int rc = pick_shape(s->D, dtype, &s->sh);
+  if (rc) {
+    delete s;
+    return rc;
+  }
+  auto build = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t mb = mat_bytes(s);
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipMalloc(&s->Xbuf[i], mb));
+      HIPCHK(hipMalloc(&s->Vbuf[i], mb));
+      HIPCHK(hipMemsetAsync(s->Xbuf[i], 0, mb, s->stream));
+      HIPCHK(hipMemsetAsync(s->Vbuf[i], 0, mb, s->stream));
+      HIPCHK(hipMalloc(&s->EX[i], s->N * s->sh.esize));
+      HIPCHK(hipMalloc(&s->EV[i], s->N * s->sh.esize));
+      HIPCHK(hipMalloc(&s->Hflf[i], s->N * s->sh.esize));
+      HIPCHK(hipMalloc((void**)&s->cache[i], s->N));
+      HIPCHK(hipMemsetAsync(s->Hflf[i], 0, s->N * s->sh.esize, s->stream));
+      HIPCHK(hipMemsetAsync(s->cache[i], 0, s->N, s->stream));
+    }
+    HIPCHK(hipMalloc((void**)&s->dwell, s->N * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->dwell, 0, s->N * sizeof(double), s->stream));
+    HIPCHK(hipMalloc((void**)&s->trans, s->N));
+    HIPCHK(hipMemsetAsync(s->trans, 0, s->N, s->stream));
+    HIPCHK(hipMalloc((void**)&s->ctl, sizeof(Control)));
+    HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
+    HIPCHK(hipEventCreate(&s->ev_total[0]));
+    HIPCHK(hipEventCreate(&s->ev_total[1]));
+    s->Xcur = s->Xbuf[0];
+    TRY(upload_matrix(s, Xinit, s->Xcur));
+    if (Vinit) {
+      TRY(upload_matrix(s, Vinit, s->Vbuf[0]));
+      TRY(run_eval(s, s->Xcur, nullptr, s->EX[0], s->Vbuf[0], nullptr, s->EV[0]));
+    } else {
+      TRY(run_eval(s, s->Xcur, nullptr, s->EX[0], nullptr, s->Vbuf[0], s->EV[0]));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+  };
+  rc = build();
+  if (rc) {
+    std::string keep = g_err;
+    mjhmc_sampler_destroy(s);
+    g_err = keep;
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, double p_r, double beta,
+                      double p_flip) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  if (num_leapfrog_steps < 0) return fail(MJHMC_ERR_INVALID, "num_leapfrog_steps must be >= 0");
+  s->eps = epsilon;
+  s->L = num_leapfrog_steps;
+  s->p_r = p_r;
+  s->beta = beta;
+  s->p_flip = p_flip;
+  return 0;
+}
+
+int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipMemsetAsync(s->cache[s->scur], 0, s->N, s->stream));
+  return 0;
+}
+
+}  // extern "C"
+
+template <typename T>
+static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
+                     const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
+  const size_t mb = mat_bytes(s);
+  if (s->stats_cap < n_iter) {
+    if (s->stats) HIPCHK(hipFree(s->stats));
+    s->stats = nullptr;
+    HIPCHK(hipMalloc((void**)&s->stats, (size_t)n_iter * 4 * sizeof(long long)));
+    s->stats_cap = n_iter;
+  }
+  if (replay_normal && !s->noise) {
+    HIPCHK(hipMalloc(&s->noise, mb));
+    HIPCHK(hipMemsetAsync(s->noise, 0, mb, s->stream));
+  }
+  if (replay_exp && !s->rexp) HIPCHK(hipMalloc((void**)&s->rexp, 3 * s->N * sizeof(double)));
+  const int n_timed = std::min(n_iter, kMaxTimed);
+  while ((int)s->ev_k.size() < 2 * n_timed) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    s->ev_k.push_back(e);
+  }
+  HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
+  HIPCHK(hipMemsetAsync(s->stats, 0, (size_t)n_iter * 4 * sizeof(long long), s->stream));
+
+  std::vector<void*> xout(n_iter);
+  void* xin = s->Xcur;
+  HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
+  for (int i = 0; i < n_iter; ++i) {
+    void* xo;
+    double* dring = nullptr;
+    if (ring_slot0 >= 0) {
+      xo = (char*)s->ring + (size_t)(ring_slot0 + i) * mb;
+      dring = s->dwell_ring + (size_t)(ring_slot0 + i) * s->N;
+      if (xo == xin) {  // the live state sits in the slot about to be overwritten: move it out first
+        void* spare = s->Xbuf[0];
+        HIPCHK(hipMemcpyAsync(spare, xin, mb, hipMemcpyDeviceToDevice, s->stream));
+        xin = spare;
+        if (i == 0) s->Xcur = spare;
+      }
+    } else {
+      xo = (xin != s->Xbuf[0]) ? s->Xbuf[0] : s->Xbuf[1];
+    }
+    xout[i] = xo;
+    const int vi = (s->vcur + i) & 1, si = (s->scur + i) & 1;
+    if (replay_normal) TRY(upload_matrix(s, replay_normal + (size_t)i * s->D * s->N, s->noise));
+    if (replay_exp)
+      HIPCHK(hipMemcpyAsync(s->rexp, replay_exp + (size_t)i * 3 * s->N, 3 * s->N * sizeof(double),
+                            hipMemcpyHostToDevice, s->stream));
+    JumpArgs<T> a;
+    a.X_in = (const T*)xin;
+    a.V_in = (const T*)s->Vbuf[vi];
+    a.X_out = (T*)xo;
+    a.V_out = (T*)s->Vbuf[vi ^ 1];
+    a.EX_in = (const T*)s->EX[si];
+    a.EV_in = (const T*)s->EV[si];
+    a.EX_out = (T*)s->EX[si ^ 1];
+    a.EV_out = (T*)s->EV[si ^ 1];
+    a.Hflf_in = (const T*)s->Hflf[si];
+    a.Hflf_out = (T*)s->Hflf[si ^ 1];
+    a.cache_in = s->cache[si];
+    a.cache_out = s->cache[si ^ 1];
+    a.dwell = s->dwell;
+    a.dwell_ring = dring;
+    a.trans = s->trans;
+    a.noise = replay_normal ? (const T*)s->noise : nullptr;
+    a.rexp = replay_exp ? s->rexp : nullptr;
+    a.runif = nullptr;
+    a.ctl = s->ctl;
+    a.N = s->N;
+    a.first_pid = s->first_pid;
+    a.D = s->D;
+    a.pitch = s->sh.pitch;
+    a.CH = s->sh.CH;
+    a.logG = s->sh.logG;
+    a.L = s->L;
+    a.iter = i;
+    a.eps = (T)s->eps;
+    a.chalf = (T)(-s->eps / 2.);
+    a.r_keep = (T)std::sqrt(1. - s->beta);
+    a.r_mix = (T)std::sqrt(s->beta);
+    a.p_r = s->p_r;
+    a.p_flip = s->p_flip;
+    const uint64_t tick = s->tick + (uint64_t)i;
+    a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), (uint32_t)(tick & 0xFFFFFFFFu),
+                   (uint32_t)(tick >> 32)};
+    if (i < n_timed) HIPCHK(hipEventRecord(s->ev_k[2 * i], s->stream));
+    TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+    if (i < n_timed) HIPCHK(hipEventRecord(s->ev_k[2 * i + 1], s->stream));
+    const unsigned cgrid = (unsigned)std::min<int64_t>(64, (s->N + 4095) / 4096);
+    hipLaunchKernelGGL(count_kernel, dim3(cgrid), dim3(256), 0, s->stream, (const uint8_t*)s->trans,
+                       (const uint8_t*)s->cache[si], s->N, (const Control*)s->ctl, i, 0,
+                       (unsigned long long*)(s->stats + 4 * i));
+    HIPCHK(hipGetLastError());
+    xin = xo;
+  }
+  HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  Control hc;
+  std::vector<long long> hs((size_t)n_iter * 4);
+  HIPCHK(hipMemcpyAsync(&hc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(hs.data(), s->stats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+
+  const int done = hc.failed ? hc.failed_iter : n_iter;
+  const int attempts = hc.failed ? done + 1 : n_iter;
+  if (per_iter) {
+    for (int i = 0; i < attempts; ++i) {
+      mjhmc_iter_stats& st = per_iter[i];
+      std::memset(&st, 0, sizeof(st));
+      st.l = hs[4 * i + 0];
+      st.f = hs[4 * i + 1];
+      st.r = hs[4 * i + 2];
+      st.n_cold = hs[4 * i + 3];
+      st.E_evals = s->N + st.n_cold;                          // L on all + FLF on the cold ones
+      st.dEdX_evals = (int64_t)s->L * (s->N + st.n_cold);
+      st.nonfinite = (hc.failed && i == done) ? 1 : 0;
+      st.L_used = s->L;
+      st.eps_used = s->eps;
+    }
+  }
+  // commit the finished iterations
+  if (done > 0) s->Xcur = xout[done - 1];
+  s->vcur = (s->vcur + done) & 1;
+  s->scur = (s->scur + done) & 1;
+  s->tick += (uint64_t)attempts;
+  if (n_done) *n_done = done;
+
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, s->ev_total[0], s->ev_total[1]));
+  s->last_total_ms = ms;
+  s->last_jump_ms = 0;
+  s->last_jump_launches = 0;
+  for (int i = 0; i < std::min(n_timed, attempts); ++i) {
+    HIPCHK(hipEventElapsedTime(&ms, s->ev_k[2 * i], s->ev_k[2 * i + 1]));
+    s->last_jump_ms += ms;
+    s->last_jump_launches += 1;
+  }
+  return 0;
+}
+
+extern "C" {
+
+int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
+                  const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  if (n_iter < 1) return fail(MJHMC_ERR_INVALID, "n_iter must be >= 1");
+  if (ring_slot0 >= 0 && (!s->ring || ring_slot0 + n_iter > s->ring_slots))
+    return fail(MJHMC_ERR_INVALID, "ring slots out of range (call mjhmc_ring_alloc)");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  return s->dtype == MJHMC_F64
+             ? iterate_t<double>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done)
+             : iterate_t<float>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
+}
+
+static int read_vec(mjhmc_sampler* s, const void* dev, void* host, size_t nbytes) {
+  // state scalars are stored in the state dtype; the ABI hands out float64
+  if (nbytes != (size_t)s->N * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected N float64");
+  if (s->dtype == MJHMC_F64) {
+    HIPCHK(hipMemcpyAsync(host, dev, nbytes, hipMemcpyDeviceToHost, s->stream));
+  } else {
+    TRY(ensure_stage(s, (size_t)s->N));
+    hipLaunchKernelGGL(widen_vec<float>, dim3((unsigned)((s->N + 255) / 256)), dim3(256), 0, s->stream,
+                       (const float*)dev, s->stage, s->N);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host, s->stage, nbytes, hipMemcpyDeviceToHost, s->stream));
+  }
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
+  if (!s || !host_dst) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t mat = (size_t)s->D * s->N;
+  switch (field) {
+    case MJHMC_F_X:
+    case MJHMC_F_V:
+    case MJHMC_F_DEDX: {
+      if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
+      TRY(ensure_stage(s, mat));
+      const void* src = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
+      if (field == MJHMC_F_DEDX) {
+        if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, mat_bytes(s)));
+        TRY(run_eval(s, s->Xcur, s->scratch, nullptr, nullptr, nullptr, nullptr));
+        src = s->scratch;
+      }
+      return download_cols(s, src, nullptr, s->N, (double*)host_dst, mat, s->N, 1, 0, true);
+    }
+    case MJHMC_F_EX: return read_vec(s, s->EX[s->scur], host_dst, nbytes);
+    case MJHMC_F_EV: return read_vec(s, s->EV[s->scur], host_dst, nbytes);
+    case MJHMC_F_HFLF: return read_vec(s, s->Hflf[s->scur], host_dst, nbytes);
+    case MJHMC_F_DWELL:
+      if (nbytes != (size_t)s->N * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected N float64");
+      HIPCHK(hipMemcpyAsync(host_dst, s->dwell, nbytes, hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      return 0;
+    case MJHMC_F_CACHE:
+    case MJHMC_F_TRANS:
+      if (nbytes != (size_t)s->N) return fail(MJHMC_ERR_INVALID, "expected N uint8");
+      HIPCHK(hipMemcpyAsync(host_dst, field == MJHMC_F_CACHE ? s->cache[s->scur] : s->trans, nbytes,
+                            hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      return 0;
+    default: return fail(MJHMC_ERR_INVALID, "unknown field");
+  }
+}
+
+int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes) {
+  if (!s || !host_src) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t mat = (size_t)s->D * s->N;
+  switch (field) {
+    case MJHMC_F_X:
+    case MJHMC_F_V: {
+      if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
+      void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
+      TRY(upload_matrix(s, (const double*)host_src, dst));
+      TRY(run_eval(s, s->Xcur, nullptr, s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
+      HIPCHK(hipMemsetAsync(s->cache[s->scur], 0, s->N, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      return 0;
+    }
+    case MJHMC_F_CACHE:
+      if (nbytes != (size_t)s->N) return fail(MJHMC_ERR_INVALID, "expected N uint8");
+      HIPCHK(hipMemcpyAsync(s->cache[s->scur], host_src, nbytes, hipMemcpyHostToDevice, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      return 0;
+    default: return fail(MJHMC_ERR_INVALID, "field is not writable");
+  }
+}
+
+int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots) {
+  if (!s || n_slots < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  if (n_slots <= s->ring_slots) return 0;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  const size_t mb = mat_bytes(s);
+  // the live X may sit in the old ring: park it in a ping-pong buffer before freeing
+  if (s->ring && (char*)s->Xcur >= (char*)s->ring && (char*)s->Xcur < (char*)s->ring + (size_t)s->ring_slots * mb) {
+    HIPCHK(hipMemcpy(s->Xbuf[0], s->Xcur, mb, hipMemcpyDeviceToDevice));
+    s->Xcur = s->Xbuf[0];
+  }
+  if (s->ring) HIPCHK(hipFree(s->ring));
+  if (s->dwell_ring) HIPCHK(hipFree(s->dwell_ring));
+  s->ring = nullptr;
+  s->dwell_ring = nullptr;
+  s->ring_slots = 0;
+  HIPCHK(hipMalloc(&s->ring, (size_t)n_slots * mb));
+  HIPCHK(hipMemset(s->ring, 0, (size_t)n_slots * mb));
+  HIPCHK(hipMalloc((void**)&s->dwell_ring, (size_t)n_slots * s->N * sizeof(double)));
+  s->ring_slots = n_slots;
+  return 0;
+}
+
+int mjhmc_ring_read_dwell(mjhmc_sampler* s, int slot0, int n, double* host_dst) {
+  if (!s || !host_dst) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return fail(MJHMC_ERR_INVALID, "slots out of range");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipMemcpyAsync(host_dst, s->dwell_ring + (size_t)slot0 * s->N, (size_t)n * s->N * sizeof(double),
+                        hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int mjhmc_ring_gather(mjhmc_sampler* s, const int64_t* idx, int64_t n, double* host_out) {
+  if (!s || !idx || !host_out || n < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const int64_t pool = (int64_t)s->ring_slots * s->N;
+  for (int64_t k = 0; k < n; ++k)
+    if (idx[k] < 0 || idx[k] >= pool) return fail(MJHMC_ERR_INVALID, "gather index outside the sample ring");
+  int64_t* didx = nullptr;
+  HIPCHK(hipMalloc((void**)&didx, n * sizeof(int64_t)));
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(didx, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream) != hipSuccess) {
+      rc = fail(MJHMC_ERR_HIP, "index upload failed");
+      break;
+    }
+    rc = ensure_stage(s, (size_t)s->D * n);
+    if (rc) break;
+    rc = download_cols(s, s->ring, didx, n, host_out, (size_t)s->D * n, n, 1, 0, true);
+  } while (0);
+  (void)hipFree(didx);
+  return rc;
+}
+
+int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* host_out) {
+  if (!s || !host_out) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return fail(MJHMC_ERR_INVALID, "slots out of range");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t total = (size_t)s->D * s->N * n;
+  TRY(ensure_stage(s, total));
+  const size_t mb = mat_bytes(s);
+  const char* base = (const char*)s->ring + (size_t)slot0 * mb;
+  if (!stacked) {
+    TRY(download_cols(s, base, nullptr, (int64_t)n * s->N, host_out, total, (int64_t)n * s->N, 1, 0, true));
+  } else {
+    for (int k = 0; k < n; ++k)
+      TRY(download_cols(s, base + (size_t)k * mb, nullptr, s->N, host_out, total, (int64_t)s->N * n, n, k, k == n - 1));
+  }
+  return 0;
+}
+
+int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms, int* n_jump_launches) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  if (total_ms) *total_ms = s->last_total_ms;
+  if (jump_kernel_ms) *jump_kernel_ms = s->last_jump_ms;
+  if (n_jump_launches) *n_jump_launches = s->last_jump_launches;
+  return 0;
+}
+
+int mjhmc_sync(mjhmc_sampler* s) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E_out, double* dEdX_out) {
+  if (!e || !X || n < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
+  if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  // a throw-away sampler-shaped workspace keeps one code path for re-tiling and evaluation
+  mjhmc_sampler w;
+  w.ctx = e->ctx;
+  w.en = e;
+  w.N = n;
+  w.first_pid = 0;
+  w.D = e->ep.ndims;
+  w.dtype = dtype;
+  TRY(pick_shape(w.D, dtype, &w.sh));
+  void *Xd = nullptr, *Gd = nullptr, *Ed = nullptr;
+  auto body = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    const size_t mb = mat_bytes(&w);
+    HIPCHK(hipMalloc(&Xd, mb));
+    HIPCHK(hipMemsetAsync(Xd, 0, mb, w.stream));
+    if (dEdX_out) HIPCHK(hipMalloc(&Gd, mb));
+    if (E_out) HIPCHK(hipMalloc(&Ed, n * w.sh.esize));
+    TRY(upload_matrix(&w, X, Xd));
+    TRY(run_eval(&w, Xd, Gd, Ed, nullptr, nullptr, nullptr));
+    if (E_out) TRY(read_vec(&w, Ed, E_out, (size_t)n * sizeof(double)));
+    if (dEdX_out) TRY(download_cols(&w, Gd, nullptr, n, dEdX_out, (size_t)w.D * n, n, 1, 0, true));
+    HIPCHK(hipStreamSynchronize(w.stream));
+    return 0;
+  };
+  const int rc = body();
+  if (Xd) (void)hipFree(Xd);
+  if (Gd) (void)hipFree(Gd);
+  if (Ed) (void)hipFree(Ed);
+  if (w.stage) (void)hipFree(w.stage);
+  if (w.stream) (void)hipStreamDestroy(w.stream);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,737 @@
+// Fused Markov-jump kernel for energies whose gradient is elementwise (optionally coupled through
+// a few per-particle scalars).  One launch = one MarkovJumpHMC.sampling_iteration attempt
+// (mjhmc/samplers/markov_jump_hmc.py:355-415) for every particle:
+//
+//   load (X, V) once -> inverse-L proposal (only if the FLF cache is cold; only its H is kept,
+//   because the reference reads the FLF state only through H(), :367) -> forward L proposal
+//   (mjhmc/samplers/hmc_state.py:86-100) -> transition rates (:341-347) -> waiting-time draws
+//   (mjhmc/misc/utils.py:31-49) -> first-minimum (utils.py:15-28) -> write the chosen
+//   successor state once.
+//
+// Data layout in HBM: particle-major.  Particle p owns `pitch` consecutive elements, so the 64/G
+// particles a wavefront works on are ONE contiguous span and every global access is a full
+// 16 B/lane, 1 KiB/wave-instruction transaction.  G (power of two, <= 64) lanes share a particle;
+// lane j holds chunks j, j+G, j+2G, ... (16-byte chunks) of X and V in registers for the whole
+// iteration -- both trajectories run out of registers, reductions are xor-butterflies inside the
+// G-lane group, and for G == 64 (ndims >= 256) all per-particle control flow is wave-uniform.
+//
+// Floating-point contraction is OFF for this translation unit (see Makefile): the leapfrog
+// update is evaluated as the reference writes it (mul, then add), which makes X and V
+// bit-identical to the NumPy path for linear forces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace mjhmc {
+
+struct Control {
+  int failed;       // some attempt hit a non-finite rate
+  int failed_iter;  // index (within the current mjhmc_iterate call) of that attempt
+};
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+  using type = double2;
+  static constexpr int n = 2;
+};
+template <>
+struct VecOf<float> {
+  using type = float4;
+  static constexpr int n = 4;
+};
+
+// which dims a lane owns
+struct LaneMap {
+  int j;      // lane within the particle group
+  int G;      // lanes per particle
+  int D;      // true ndims
+  int CH;     // 16-byte chunks per particle row (pitch / VEC)
+  int lane0;  // wave lane index of the group's lane 0
+};
+
+template <typename T, int E>
+__device__ __forceinline__ int dim_of(const LaneMap& m, int e) {
+  constexpr int VEC = VecOf<T>::n;
+  return ((e / VEC) * m.G + m.j) * VEC + (e % VEC);
+}
+
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int G) {
+  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T group_bcast0(T v, const LaneMap& m) {
+  return __shfl(v, m.lane0);
+}
+
+// ------------------------------------------------------------------------------------------
+// energy functors.  Protocol (E = elements per lane):
+//   Local<E> local<E>(m)              per-lane constants, loaded once per kernel
+//   Ctx      prep(x, m)               per-evaluation context (may reduce over the group)
+//   T        grad(xe, e, d, ctx, lc)  dE/dx_d for the lane's element e (dim d)
+//   T        energy(x, m, lc)         E(x), reduced over the group, valid in every lane
+// Padded elements (d >= D) hold x = 0 and must produce grad = 0; energy() masks them.
+// ------------------------------------------------------------------------------------------
+
+struct NoCtx {};
+template <int E>
+struct NoLocal {};
+
+// TestGaussian: E = sum(x^2) / (2 sigma^2), dE/dx = x / sigma^2 (distributions.py:356-362)
+template <typename T>
+struct IsoGaussF {
+  T inv_s2;   // 1 / sigma^2
+  T two_s2;   // 2 sigma^2
+  using Ctx = NoCtx;
+  template <int E>
+  using Local = NoLocal<E>;
+  template <int E>
+  __device__ __forceinline__ Local<E> local(const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ Ctx prep(const T (&)[E], const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ T grad(T xe, int, int, const Ctx&, const Local<E>&) const {
+    return xe * inv_s2;
+  }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += x[e] * x[e];  // padded x are 0
+    return group_sum(s, m.G) / two_s2;
+  }
+};
+
+// Gaussian with diagonal J: E = sum x (J x) / 2, dE/dx = Jx/2 + J^T x/2 == j_d x_d exactly
+// (distributions.py:268-273)
+template <typename T>
+struct DiagGaussF {
+  const T* jdiag;  // zero padded to kParamPad elements
+  using Ctx = NoCtx;
+  template <int E>
+  struct Local {
+    T j[E];
+  };
+  template <int E>
+  __device__ __forceinline__ Local<E> local(const LaneMap& m) const {
+    Local<E> lc;
+#pragma unroll
+    for (int e = 0; e < E; ++e) lc.j[e] = jdiag[dim_of<T, E>(m, e)];
+    return lc;
+  }
+  template <int E>
+  __device__ __forceinline__ Ctx prep(const T (&)[E], const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ T grad(T xe, int e, int, const Ctx&, const Local<E>& lc) const {
+    return lc.j[e] * xe;
+  }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>& lc) const {
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += x[e] * (lc.j[e] * x[e]);
+    return group_sum(s, m.G) / T(2);
+  }
+};
+
+// RoughWell: E = sum x^2/(2 s1^2) + cos(2 pi x / s2); dE/dx = x/s1^2 - sin(2 pi x/s2) 2 pi/s2
+// (distributions.py:295-304), operation order as written there.
+template <typename T>
+struct RoughWellF {
+  T s1sq;       // scale1^2
+  T two_s1sq;   // 2 scale1^2
+  T s2;
+  using Ctx = NoCtx;
+  template <int E>
+  using Local = NoLocal<E>;
+  template <int E>
+  __device__ __forceinline__ Local<E> local(const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ Ctx prep(const T (&)[E], const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ T grad(T xe, int, int, const Ctx&, const Local<E>&) const {
+    const T pi = T(3.141592653589793);
+    const T sn = sin(xe * T(2) * pi / s2);
+    return xe / s1sq + -sn * T(2) * pi / s2;
+  }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
+    const T pi = T(3.141592653589793);
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const T t = (x[e] * x[e]) / two_s1sq + cos(x[e] * T(2) * pi / s2);
+      s += (dim_of<T, E>(m, e) < m.D) ? t : T(0);
+    }
+    return group_sum(s, m.G);
+  }
+};
+
+// MultimodalGaussian as coded (distributions.py:323-335): separation vector = (2*sep, 0, ..., 0).
+template <typename T>
+struct MMGaussF {
+  T sep0;  // 2 * separation
+  struct Ctx {
+    T common;  // exp(sum 4 S X) = exp(4 sep0 x_0)
+  };
+  template <int E>
+  using Local = NoLocal<E>;
+  template <int E>
+  __device__ __forceinline__ Local<E> local(const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
+    const T x0 = group_bcast0(x[0], m);
+    return Ctx{(T)exp(T(4) * sep0 * x0)};
+  }
+  template <int E>
+  __device__ __forceinline__ T grad(T xe, int, int d, const Ctx& c, const Local<E>&) const {
+    const T s = (d == 0) ? sep0 : T(0);
+    return (T(2) * ((xe - s) * c.common + s + xe)) / (c.common + T(1));
+  }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
+    T a = 0, b = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const T s = (dim_of<T, E>(m, e) == 0) ? sep0 : T(0);
+      a += (x[e] + s) * (x[e] + s);
+      b += (x[e] - s) * (x[e] - s);
+    }
+    a = group_sum(a, m.G);
+    b = group_sum(b, m.G);
+    return -(T)log(exp(-a) + exp(-b));
+  }
+};
+
+// Neal's funnel, x0 ~ N(0, s^2), x_k ~ N(0, e^{x0}) (tf_distributions.py:143-147):
+// E = x0^2/(2 s^2) + e^{-x0} sum_k x_k^2 / 2 + (D-1) x0 / 2
+template <typename T>
+struct FunnelNealF {
+  T inv_s2;      // 1/scale^2
+  T half_dm1;    // (D-1)/2
+  struct Ctx {
+    T x0, ex, S;  // x_0, exp(-x_0), sum_{k>=1} x_k^2
+  };
+  template <int E>
+  using Local = NoLocal<E>;
+  template <int E>
+  __device__ __forceinline__ Local<E> local(const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += (dim_of<T, E>(m, e) == 0) ? T(0) : x[e] * x[e];
+    Ctx c;
+    c.S = group_sum(s, m.G);
+    c.x0 = group_bcast0(x[0], m);
+    c.ex = (T)exp(-c.x0);
+    return c;
+  }
+  template <int E>
+  __device__ __forceinline__ T grad(T xe, int, int d, const Ctx& c, const Local<E>&) const {
+    return (d == 0) ? (c.x0 * inv_s2 - T(0.5) * c.ex * c.S + half_dm1) : xe * c.ex;
+  }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
+    const Ctx c = prep(x, m);
+    return c.x0 * c.x0 * (T(0.5) * inv_s2) + T(0.5) * c.ex * c.S + half_dm1 * c.x0;
+  }
+};
+
+// Funnel exactly as coded (tf_distributions.py:157-165): E = -(D-1) x0^2/s^2 - e^{-x0} sum_k x_k^2
+template <typename T>
+struct FunnelRefF {
+  T inv_s2;
+  T dm1;  // D-1
+  struct Ctx {
+    T x0, ex, S;
+  };
+  template <int E>
+  using Local = NoLocal<E>;
+  template <int E>
+  __device__ __forceinline__ Local<E> local(const LaneMap&) const {
+    return {};
+  }
+  template <int E>
+  __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += (dim_of<T, E>(m, e) == 0) ? T(0) : x[e] * x[e];
+    Ctx c;
+    c.S = group_sum(s, m.G);
+    c.x0 = group_bcast0(x[0], m);
+    c.ex = (T)exp(-c.x0);
+    return c;
+  }
+  template <int E>
+  __device__ __forceinline__ T grad(T xe, int, int d, const Ctx& c, const Local<E>&) const {
+    return (d == 0) ? (T(-2) * dm1 * c.x0 * inv_s2 + c.ex * c.S) : T(-2) * xe * c.ex;
+  }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
+    const Ctx c = prep(x, m);
+    return -(dm1 * c.x0 * c.x0 * inv_s2) - c.ex * c.S;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// kernel arguments
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+struct JumpArgs {
+  const T* X_in;
+  const T* V_in;
+  T* X_out;
+  T* V_out;
+  const T* EX_in;
+  const T* EV_in;
+  T* EX_out;
+  T* EV_out;
+  const T* Hflf_in;
+  T* Hflf_out;
+  const uint8_t* cache_in;
+  uint8_t* cache_out;
+  double* dwell;        // [N]
+  double* dwell_ring;   // [N] slot or nullptr
+  uint8_t* trans;       // [N]
+  const T* noise;       // replay normals, particle-major [N][pitch], or nullptr
+  const double* rexp;   // replay unit exponentials [3][N], or nullptr
+  const double* runif;  // replay uniforms (control mode) [2N+1], or nullptr
+  Control* ctl;
+  int64_t N;
+  int64_t first_pid;
+  int D, pitch, CH, logG;
+  int L;
+  int iter;             // index of this attempt inside the current mjhmc_iterate call
+  T eps, chalf;         // epsilon and -epsilon/2 (hmc_state.py:88-91)
+  T r_keep, r_mix;      // sqrt(1-beta), sqrt(beta) of HMCState.R (hmc_state.py:125-126)
+  double p_r, p_flip;
+  RngKey key;
+};
+
+template <typename T>
+struct EvalArgs {
+  const T* X;     // [n][pitch]
+  T* G;           // [n][pitch] or nullptr
+  T* E;           // [n] or nullptr
+  T* EV;          // [n] or nullptr (kinetic energy of V when V != nullptr)
+  const T* V;     // optional
+  T* V_out;       // when non-null: V is GENERATED (tick-0 normals) and written here
+  int64_t N;
+  int64_t first_pid;
+  int D, pitch, CH, logG;
+  RngKey key;
+};
+
+// ------------------------------------------------------------------------------------------
+// building blocks
+// ------------------------------------------------------------------------------------------
+
+template <typename T, int E>
+__device__ __forceinline__ void load_row(const T* row, const LaneMap& m, T (&r)[E]) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    const int chunk = c * m.G + m.j;
+    V v;
+    if (chunk < m.CH) {
+      v = *reinterpret_cast<const V*>(row + (size_t)chunk * VEC);
+    } else {
+      if constexpr (VEC == 2) v = V{0, 0};
+      else v = V{0, 0, 0, 0};
+    }
+    if constexpr (VEC == 2) {
+      r[c * 2] = v.x;
+      r[c * 2 + 1] = v.y;
+    } else {
+      r[c * 4] = v.x;
+      r[c * 4 + 1] = v.y;
+      r[c * 4 + 2] = v.z;
+      r[c * 4 + 3] = v.w;
+    }
+  }
+}
+
+template <typename T, int E>
+__device__ __forceinline__ void store_row(T* row, const LaneMap& m, const T (&r)[E]) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    const int chunk = c * m.G + m.j;
+    if (chunk < m.CH) {
+      V v;
+      if constexpr (VEC == 2) v = V{r[c * 2], r[c * 2 + 1]};
+      else v = V{r[c * 4], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
+      *reinterpret_cast<V*>(row + (size_t)chunk * VEC) = v;
+    }
+  }
+}
+
+// M leapfrog steps, in place (hmc_state.py:86-100).  The half kicks are NOT merged, as in the
+// reference; c*g of the closing kick is reused by the next opening kick (same product).
+template <class En, typename T, int E>
+__device__ __forceinline__ void trajectory(const En& en, const typename En::template Local<E>& lc, const LaneMap& m,
+                                           T (&x)[E], T (&v)[E], int L, T eps, T chalf) {
+  T cg[E];
+  {
+    const auto ctx = en.prep(x, m);
+#pragma unroll
+    for (int e = 0; e < E; ++e) cg[e] = chalf * en.template grad<E>(x[e], e, dim_of<T, E>(m, e), ctx, lc);
+  }
+  for (int s = 0; s < L; ++s) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      v[e] = v[e] + cg[e];
+      x[e] = x[e] + eps * v[e];
+    }
+    const auto ctx = en.prep(x, m);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      cg[e] = chalf * en.template grad<E>(x[e], e, dim_of<T, E>(m, e), ctx, lc);
+      v[e] = v[e] + cg[e];
+    }
+  }
+}
+
+template <typename T, int E>
+__device__ __forceinline__ T kinetic(const T (&v)[E], const LaneMap& m) {
+  T s = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) s += v[e] * v[e];
+  return group_sum(s, m.G) / T(2);  // hmc_state.py:50
+}
+
+// momentum-refresh noise for this lane's dims (hmc_state.py:125): replayed or counter RNG
+template <typename T, int E>
+__device__ __forceinline__ void refresh_noise(const T* noise_row, const RngKey& key, uint32_t pid, const LaneMap& m,
+                                              T (&z)[E]) {
+  constexpr int VEC = VecOf<T>::n;
+  if (noise_row) {
+    load_row<T, E>(noise_row, m, z);
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    const int chunk = c * m.G + m.j;
+#pragma unroll
+    for (int h = 0; h < VEC / 2; ++h) {
+      const int d = chunk * VEC + 2 * h;
+      double z0 = 0.0, z1 = 0.0;
+      if (chunk < m.CH && d < m.D) normal_pair(key, pid, (uint32_t)(d >> 1), z0, z1);
+      z[c * VEC + 2 * h] = (T)z0;
+      z[c * VEC + 2 * h + 1] = (d + 1 < m.D) ? (T)z1 : T(0);
+    }
+  }
+}
+
+__device__ __forceinline__ double wait_time(double rate, double e, bool& bad) {
+  // utils.py:37-48: rate == 0 -> inf; finite -> exponential(scale=1/rate) == (1/rate)*std_exp; else error
+  if (rate == 0.0) return __builtin_huge_val();
+  if (!isfinite(rate)) {
+    bad = true;
+    return __builtin_nan("");
+  }
+  return (1.0 / rate) * e;
+}
+
+// np.argmin over rows (first occurrence; a NaN wins as soon as it is met)
+__device__ __forceinline__ int first_min3(double a, double b, double c) {
+  int k = 0;
+  double best = a;
+  if (!(best != best)) {
+    if (b < best || b != b) {
+      k = 1;
+      best = b;
+    }
+  }
+  if (!(best != best)) {
+    if (c < best || c != c) {
+      k = 2;
+      best = c;
+    }
+  }
+  return k;
+}
+
+// ------------------------------------------------------------------------------------------
+// the jump kernel (MJHMC mode)
+// ------------------------------------------------------------------------------------------
+
+template <class En, typename T, int E>
+__global__ __launch_bounds__(256) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
+  if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int G = 1 << a.logG;
+  const int64_t p_raw = tid >> a.logG;
+  const bool alive = p_raw < a.N;
+  const int64_t p = alive ? p_raw : a.N - 1;
+  LaneMap m;
+  m.j = (int)(tid & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
+
+  T x0[E], v0[E];
+  load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, x0);
+  load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v0);
+  const T EX0 = a.EX_in[p];
+  const T EV0 = a.EV_in[p];
+  const T H0 = EX0 + EV0;  // HMCState.H (hmc_state.py:80-84)
+  const bool warm = a.cache_in[p] != 0;
+  const auto lc = en.template local<E>(m);
+
+  // inverse-L proposal F L F; only H() of it is ever read (markov_jump_hmc.py:360,367)
+  T Hflf;
+  if (warm) {
+    Hflf = a.Hflf_in[p];
+  } else {
+    T x[E], v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      x[e] = x0[e];
+      v[e] = -v0[e];
+    }
+    trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+    const T ev = kinetic<T, E>(v, m);
+    const T ex = en.energy(x, m, lc);
+    Hflf = ex + ev;
+  }
+
+  // forward proposal L
+  T x[E], v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    x[e] = x0[e];
+    v[e] = v0[e];
+  }
+  trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+  const T EVL = kinetic<T, E>(v, m);
+  const T EXL = en.energy(x, m, lc);
+  const T HL = EXL + EVL;
+
+  // rates: exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347, 366-369)
+  const double l_rate = sqrt(exp((double)(H0 - HL)));
+  const double flf_rate = sqrt(exp((double)(H0 - Hflf)));
+  const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
+  const double f_rate = flf_rate - mn;
+  const double r_rate = a.p_r;
+
+  // unit exponentials
+  double eL, eF, eR;
+  const uint32_t pid = (uint32_t)(a.first_pid + p);
+  if (a.rexp) {
+    eL = a.rexp[p];
+    eF = a.rexp[a.N + p];
+    eR = a.rexp[2 * a.N + p];
+  } else {
+    const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+    const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+    eL = -log(u53(w.w0, w.w1));
+    eF = -log(u53(w.w2, w.w3));
+    eR = -log(u53(q.w0, q.w1));
+  }
+  bool bad = false;
+  const double dL = wait_time(l_rate, eL, bad);
+  const double dF = wait_time(f_rate, eF, bad);
+  const double dR = wait_time(r_rate, eR, bad);
+  if (bad && alive) {
+    a.ctl->failed = 1;
+    a.ctl->failed_iter = a.iter;
+  }
+  const int k = first_min3(dL, dF, dR);
+  const double dwell = (k == 0) ? dL : (k == 1 ? dF : dR);
+
+  // successor state (markov_jump_hmc.py:399-410)
+  T EXn, EVn, Hc;
+  uint8_t cn;
+  if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
+    EXn = EXL;
+    EVn = EVL;
+    Hc = H0;
+    cn = 1;
+  } else if (k == 1) {  // F: flip the momentum
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      x[e] = x0[e];
+      v[e] = -v0[e];
+    }
+    EXn = EX0;
+    EVn = EV0;
+    Hc = Hflf;
+    cn = 0;
+  } else {  // R: refresh the momentum (hmc_state.py:121-129)
+    T z[E];
+    refresh_noise<T, E>(a.noise ? a.noise + (size_t)p * a.pitch : nullptr, a.key, pid, m, z);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      x[e] = x0[e];
+      v[e] = v0[e] * a.r_keep + z[e] * a.r_mix;
+    }
+    EXn = EX0;
+    EVn = kinetic<T, E>(v, m);
+    Hc = Hflf;
+    cn = 0;
+  }
+  if (!alive) return;
+  store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
+  store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+  if (m.j == 0) {
+    a.EX_out[p] = EXn;
+    a.EV_out[p] = EVn;
+    a.Hflf_out[p] = Hc;
+    a.cache_out[p] = cn;
+    a.dwell[p] = dwell;
+    if (a.dwell_ring) a.dwell_ring[p] = dwell;
+    a.trans[p] = (uint8_t)k;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// evaluation kernel: E(X), dEdX(X), optionally kinetic energy / generated initial momentum
+// (HMCState.__init__, hmc_state.py:24-39; Distribution.E/dEdX, distributions.py:62-81)
+// ------------------------------------------------------------------------------------------
+
+template <class En, typename T, int E>
+__global__ __launch_bounds__(256) void mjhmc_eval_kernel(const EvalArgs<T> a, const En en) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int G = 1 << a.logG;
+  const int64_t p_raw = tid >> a.logG;
+  const bool alive = p_raw < a.N;
+  const int64_t p = alive ? p_raw : a.N - 1;
+  LaneMap m;
+  m.j = (int)(tid & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
+  T x[E];
+  load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
+  const auto lc = en.template local<E>(m);
+  if (a.G) {
+    T g[E];
+    const auto ctx = en.prep(x, m);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int d = dim_of<T, E>(m, e);
+      g[e] = (d < a.D) ? en.template grad<E>(x[e], e, d, ctx, lc) : T(0);
+    }
+    if (alive) store_row<T, E>(a.G + (size_t)p * a.pitch, m, g);
+  }
+  if (a.E) {
+    const T ex = en.energy(x, m, lc);
+    if (alive && m.j == 0) a.E[p] = ex;
+  }
+  if (a.EV) {
+    T v[E];
+    if (a.V_out) {
+      refresh_noise<T, E>(nullptr, a.key, (uint32_t)(a.first_pid + p), m, v);
+      if (alive) store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+    } else {
+      load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
+    }
+    const T ev = kinetic<T, E>(v, m);
+    if (alive && m.j == 0) a.EV[p] = ev;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch plumbing shared by the per-energy translation units
+// ------------------------------------------------------------------------------------------
+
+struct LaunchShape {
+  int E;      // elements per lane (template arg)
+  int logG;
+  int pitch;
+  int CH;
+};
+
+// host-visible parameter block; each energy TU turns it into its functor
+constexpr int kParamPad = 4096;  // device parameter vectors are zero padded to this many elements
+
+struct EnergyParams {
+  int kind;
+  int ndims;
+  double p[8];           // scalar params
+  const void* dev_f64;   // device arrays (already in the state dtype), zero padded to pitch
+  const void* dev_f32;
+};
+
+template <class En, typename T, int E>
+inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
+  const int64_t threads = a.N << a.logG;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E>), dim3(grid), dim3(256), 0, st, a, en);
+}
+
+template <class En, typename T, int E>
+inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
+  const int64_t threads = a.N << a.logG;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  hipLaunchKernelGGL((mjhmc_eval_kernel<En, T, E>), dim3(grid), dim3(256), 0, st, a, en);
+}
+
+// E choices: f64 {2, 8, 16}, f32 {4, 16, 32}  (1, 4, 8 chunks per lane)
+#define MJHMC_DEFINE_ENERGY_LAUNCHERS(NAME, MAKE64, MAKE32)                                               \
+  void NAME##_jump_f64(const JumpArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {        \
+    const auto en = MAKE64(ep);                                                                           \
+    if (E == 2) launch_jump_t<decltype(en), double, 2>(a, en, st);                                        \
+    else if (E == 8) launch_jump_t<decltype(en), double, 8>(a, en, st);                                   \
+    else launch_jump_t<decltype(en), double, 16>(a, en, st);                                              \
+  }                                                                                                       \
+  void NAME##_jump_f32(const JumpArgs<float>& a, const EnergyParams& ep, int E, hipStream_t st) {         \
+    const auto en = MAKE32(ep);                                                                           \
+    if (E == 4) launch_jump_t<decltype(en), float, 4>(a, en, st);                                         \
+    else if (E == 16) launch_jump_t<decltype(en), float, 16>(a, en, st);                                  \
+    else launch_jump_t<decltype(en), float, 32>(a, en, st);                                               \
+  }                                                                                                       \
+  void NAME##_eval_f64(const EvalArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {        \
+    const auto en = MAKE64(ep);                                                                           \
+    if (E == 2) launch_eval_t<decltype(en), double, 2>(a, en, st);                                        \
+    else if (E == 8) launch_eval_t<decltype(en), double, 8>(a, en, st);                                   \
+    else launch_eval_t<decltype(en), double, 16>(a, en, st);                                              \
+  }                                                                                                       \
+  void NAME##_eval_f32(const EvalArgs<float>& a, const EnergyParams& ep, int E, hipStream_t st) {         \
+    const auto en = MAKE32(ep);                                                                           \
+    if (E == 4) launch_eval_t<decltype(en), float, 4>(a, en, st);                                         \
+    else if (E == 16) launch_eval_t<decltype(en), float, 16>(a, en, st);                                  \
+    else launch_eval_t<decltype(en), float, 32>(a, en, st);                                               \
+  }
+
+#define MJHMC_DECLARE_ENERGY_LAUNCHERS(NAME)                                                       \
+  void NAME##_jump_f64(const JumpArgs<double>&, const EnergyParams&, int, hipStream_t);           \
+  void NAME##_jump_f32(const JumpArgs<float>&, const EnergyParams&, int, hipStream_t);            \
+  void NAME##_eval_f64(const EvalArgs<double>&, const EnergyParams&, int, hipStream_t);           \
+  void NAME##_eval_f32(const EvalArgs<float>&, const EnergyParams&, int, hipStream_t);
+
+MJHMC_DECLARE_ENERGY_LAUNCHERS(iso)
+MJHMC_DECLARE_ENERGY_LAUNCHERS(diag)
+MJHMC_DECLARE_ENERGY_LAUNCHERS(rough)
+MJHMC_DECLARE_ENERGY_LAUNCHERS(mm)
+MJHMC_DECLARE_ENERGY_LAUNCHERS(funnel_neal)
+MJHMC_DECLARE_ENERGY_LAUNCHERS(funnel_ref)
+
+}  // namespace mjhmc

@@ -1,0 +1,179 @@
+"""Object wrappers over the C ABI: Context (device), DeviceEnergy, DeviceSampler.
+
+These are plumbing; the reference-shaped API lives in mjhmc_amd.samplers / mjhmc_amd.misc.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr, as_f64
+
+_DTYPES = {'float64': _lib.F64, 'f64': _lib.F64, np.float64: _lib.F64, 'float32': _lib.F32, 'f32': _lib.F32,
+           np.float32: _lib.F32}
+
+_contexts = {}
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise ValueError('dtype must be float64 or float32, got %r' % (dtype,))
+
+
+class Context(object):
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.mjhmc_ctx_create(int(device), ctypes.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def info(self):
+        name = ctypes.create_string_buffer(256)
+        ncu = ctypes.c_int()
+        hbm = ctypes.c_uint64()
+        check(self.lib.mjhmc_ctx_info(self.handle, name, 256, ctypes.byref(ncu), ctypes.byref(hbm)))
+        return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+
+def context(device=0):
+    """Process-wide context per device index."""
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+class DeviceEnergy(object):
+    """(kind, ndims, float64 params) resident on one device."""
+
+    def __init__(self, ctx, kind, ndims, params):
+        self.ctx = ctx
+        self.kind = int(kind)
+        self.ndims = int(ndims)
+        self.params = np.ascontiguousarray(np.atleast_1d(params), dtype=np.float64)
+        h = ctypes.c_void_p()
+        check(ctx.lib.mjhmc_energy_create(ctx.handle, self.kind, self.ndims, ptr(self.params), self.params.size,
+                                          ctypes.byref(h)))
+        self.handle = h
+
+    def eval(self, X, want_E=True, want_grad=True, dtype='float64'):
+        X = as_f64(X)
+        if X.ndim != 2 or X.shape[0] != self.ndims:
+            raise ValueError('X must be (ndims, n)')
+        n = X.shape[1]
+        E = np.empty(n) if want_E else None
+        G = np.empty((self.ndims, n)) if want_grad else None
+        if n:
+            check(self.ctx.lib.mjhmc_eval(self.handle, dtype_code(dtype), ptr(X), n, ptr(E), ptr(G)))
+        return E, G
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.ctx.lib.mjhmc_energy_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceSampler(object):
+    """One shard of particle columns on one GPU."""
+
+    def __init__(self, energy, Xinit, Vinit=None, seed=0, first_particle_id=0, dtype='float64',
+                 mode=_lib.MODE_MJHMC):
+        self.energy = energy
+        self.ctx = energy.ctx
+        self.lib = self.ctx.lib
+        X = as_f64(Xinit)
+        if X.ndim != 2 or X.shape[0] != energy.ndims:
+            raise ValueError('Xinit must be (ndims, nparticles)')
+        self.ndims, self.nparticles = X.shape
+        V = None if Vinit is None else as_f64(Vinit, X.shape)
+        h = ctypes.c_void_p()
+        check(self.lib.mjhmc_sampler_create(self.ctx.handle, energy.handle, self.nparticles, int(first_particle_id),
+                                            dtype_code(dtype), ptr(X), ptr(V), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                            int(mode), ctypes.byref(h)))
+        self.handle = h
+        self.ring_slots = 0
+
+    def set_hparams(self, epsilon, num_leapfrog_steps, p_r, beta=1.0, p_flip=0.5):
+        check(self.lib.mjhmc_set_hparams(self.handle, float(epsilon), int(num_leapfrog_steps), float(p_r), float(beta),
+                                         float(p_flip)))
+
+    def iterate(self, n_iter=1, replay_normal=None, replay_exp=None, replay_unif=None, ring_slot0=-1):
+        """Returns (list of IterStats for the attempts made, n_done)."""
+        D, N = self.ndims, self.nparticles
+        rn = None if replay_normal is None else as_f64(replay_normal).reshape(n_iter, D, N)
+        re = None if replay_exp is None else as_f64(replay_exp).reshape(n_iter, 3, N)
+        ru = None if replay_unif is None else as_f64(replay_unif).reshape(n_iter, 2 * N + 1)
+        stats = (_lib.IterStats * n_iter)()
+        done = ctypes.c_int()
+        check(self.lib.mjhmc_iterate(self.handle, int(n_iter), ptr(rn), ptr(re), ptr(ru), int(ring_slot0), stats,
+                                     ctypes.byref(done)))
+        n_done = done.value
+        attempts = n_done + 1 if n_done < n_iter else n_iter
+        return [stats[i] for i in range(attempts)], n_done
+
+    def reset_flf_cache(self):
+        check(self.lib.mjhmc_reset_flf_cache(self.handle))
+
+    def read(self, field):
+        D, N = self.ndims, self.nparticles
+        if field in (_lib.F_X, _lib.F_V, _lib.F_DEDX):
+            out = np.empty((D, N))
+        elif field in (_lib.F_CACHE, _lib.F_TRANS):
+            out = np.empty(N, dtype=np.uint8)
+        else:
+            out = np.empty(N)
+        check(self.lib.mjhmc_read(self.handle, int(field), ptr(out), out.nbytes))
+        return out
+
+    def write(self, field, arr):
+        if field == _lib.F_CACHE:
+            a = np.ascontiguousarray(arr, dtype=np.uint8)
+        else:
+            a = as_f64(arr, (self.ndims, self.nparticles))
+        check(self.lib.mjhmc_write(self.handle, int(field), ptr(a), a.nbytes))
+
+    def ring_alloc(self, n_slots):
+        check(self.lib.mjhmc_ring_alloc(self.handle, int(n_slots)))
+        self.ring_slots = max(self.ring_slots, int(n_slots))
+
+    def ring_read_dwell(self, slot0, n):
+        out = np.empty((n, self.nparticles))
+        check(self.lib.mjhmc_ring_read_dwell(self.handle, int(slot0), int(n), ptr(out)))
+        return out
+
+    def ring_gather(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty((self.ndims, idx.size))
+        if idx.size:
+            check(self.lib.mjhmc_ring_gather(self.handle, ptr(idx), idx.size, ptr(out)))
+        return out
+
+    def ring_read(self, slot0, n, stacked=False):
+        shape = (self.ndims, self.nparticles, n) if stacked else (self.ndims, n * self.nparticles)
+        out = np.empty(shape)
+        check(self.lib.mjhmc_ring_read(self.handle, int(slot0), int(n), 1 if stacked else 0, ptr(out)))
+        return out
+
+    def last_timing(self):
+        t, k, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        check(self.lib.mjhmc_last_timing(self.handle, ctypes.byref(t), ctypes.byref(k), ctypes.byref(n)))
+        return dict(total_ms=t.value, jump_kernel_ms=k.value, n_jump_launches=n.value)
+
+    def sync(self):
+        check(self.lib.mjhmc_sync(self.handle))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.mjhmc_sampler_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,249 @@
+"""Energy-model interface of the drop-in (mirrors mjhmc/misc/distributions.py and the energy
+formulas of mjhmc/misc/tf_distributions.py).
+
+A ``Distribution`` here is a *description*: ``device_energy()`` names the HIP functor and its
+parameters; evaluation (``E`` / ``dEdX``) and sampling run on the MI355X.  What is kept from the
+reference: the constructor signatures, ``E/dEdX`` counting facades (distributions.py:62-75),
+``Xinit/ndims/nbatch/mjhmc/generation_instance/backend/max_n_particles``, ``reset()``,
+``__call__`` (NUTS convention, :172-180) and the per-class ``gen_init_X`` recipes.
+
+Out of scope: the 1e6-step "fair initialisation" pickle cache behind
+the reference's ``init_X`` (:96-149).  ``init_X`` here uses ``gen_init_X`` directly; pass your
+own fair ``Xinit`` through ``LambdaDistribution(init=...)`` or by overriding ``init_X``.
+"""
+import numpy as np
+
+from .. import _lib
+from .. import engine
+
+
+class Distribution(object):
+    """Interface class; subclass it and provide ``device_energy`` (distributions.py:13-59)."""
+
+    def __init__(self, ndims=2, nbatch=100):
+        self.ndims = ndims
+        self.nbatch = nbatch
+        if not hasattr(self, 'backend'):
+            self.backend = 'hip'
+        self.mjhmc = None
+        self.E_count = 0
+        self.dEdX_count = 0
+        self.generation_instance = False
+        if not hasattr(self, 'max_n_particles'):
+            self.max_n_particles = None
+        self._dev = None
+        self.init_X()
+
+    # -- device binding -------------------------------------------------------------------
+    def device_energy(self):
+        """Return (kind, float64 parameter vector) of the HIP functor for this energy."""
+        raise NotImplementedError('%s has no device functor: implement device_energy()' % type(self).__name__)
+
+    def bind(self, device=0):
+        """DeviceEnergy for this distribution on ``device`` (cached)."""
+        if self._dev is None or self._dev.ctx.device != device:
+            kind, params = self.device_energy()
+            self._dev = engine.DeviceEnergy(engine.context(device), kind, self.ndims, params)
+        return self._dev
+
+    # -- reference API --------------------------------------------------------------------
+    def E(self, X):
+        self.E_count += X.shape[1]
+        return self.E_val(X)
+
+    def E_val(self, X):
+        E, _ = self.bind().eval(X, want_E=True, want_grad=False)
+        return E.reshape((1, -1))
+
+    def dEdX(self, X):
+        self.dEdX_count += X.shape[1]
+        return self.dEdX_val(X)
+
+    def dEdX_val(self, X):
+        _, G = self.bind().eval(X, want_E=False, want_grad=True)
+        return G
+
+    def __hash__(self):
+        raise NotImplementedError()
+
+    def init_X(self):
+        try:
+            self.gen_init_X()
+        except NotImplementedError:
+            self.Xinit = np.random.randn(self.ndims, self.nbatch)      # distributions.py:137-139
+
+    def gen_init_X(self):
+        raise NotImplementedError()
+
+    def reset(self):
+        self.E_count = 0
+        self.dEdX_count = 0
+        if not self.generation_instance:
+            self.init_X()
+        return self
+
+    def __call__(self, X):
+        rshp_X = X.reshape(len(X), 1)
+        E = float(np.asarray(self.E(rshp_X)).reshape(()))
+        dEdX = self.dEdX(rshp_X).T[0]
+        return -E, -dEdX
+
+
+class LambdaDistribution(Distribution):
+    """'Anonymous' distribution (distributions.py:198-251, README.md:27-36).
+
+    The reference's class ignores its callables (it evaluates a non-existent ``self.J``); the
+    README contract is what is kept: ``init`` is the initial state.  The sampling kernels need a
+    device functor, so name one with ``device_energy=(kind, params)`` -- or let the constructor
+    recognise the callables: they are probed on a few points and matched against the built-in
+    elementwise families (isotropic Gaussian with any sigma, as in the README example).
+    """
+
+    def __init__(self, energy_func=None, energy_grad_func=None, init=None, name=None, device_energy=None):
+        self.energy_func = energy_func
+        self.energy_grad_func = energy_grad_func
+        self.init = np.array(init, dtype=np.float64)
+        self.name = name or str(np.random.random())
+        self._functor = device_energy
+        if self._functor is None:
+            self._functor = _recognise(energy_func, energy_grad_func, self.init.shape[0])
+        super(LambdaDistribution, self).__init__(ndims=self.init.shape[0], nbatch=self.init.shape[1])
+
+    def device_energy(self):
+        if self._functor is None:
+            raise NotImplementedError(
+                'LambdaDistribution %r: the callables match no built-in device energy; pass '
+                'device_energy=(kind, params) or subclass Distribution' % self.name)
+        return self._functor
+
+    def gen_init_X(self):
+        self.Xinit = self.init
+
+    def __hash__(self):
+        return hash((self.ndims, self.nbatch, self.name))
+
+
+def _recognise(energy_func, grad_func, ndims):
+    """Match user callables against the isotropic-Gaussian family by probing (no sampling is ever
+    done with the callables themselves)."""
+    if energy_func is None or grad_func is None:
+        return None
+    rng = np.random.RandomState(12345)
+    P = rng.randn(ndims, 5)
+    try:
+        g = np.asarray(grad_func(P), dtype=np.float64)
+        e = np.asarray(energy_func(P), dtype=np.float64).reshape(-1)
+    except Exception:
+        return None
+    if g.shape != P.shape or e.shape != (5,):
+        return None
+    ratio = g / P
+    inv_s2 = float(np.median(ratio))
+    if inv_s2 <= 0 or not np.allclose(ratio, inv_s2, rtol=1e-12, atol=0):
+        return None
+    if not np.allclose(e, 0.5 * inv_s2 * np.sum(P ** 2, axis=0), rtol=1e-12, atol=0):
+        return None
+    return (_lib.E_ISO_GAUSS, np.array([1.0 / np.sqrt(inv_s2)]))
+
+
+class Gaussian(Distribution):
+    """Ill-conditioned Gaussian of the LAHMC paper (distributions.py:256-281)."""
+
+    def __init__(self, ndims=2, nbatch=100, log_conditioning=6):
+        self.conditioning = 10 ** np.linspace(-log_conditioning, 0, ndims)
+        self.J = np.diag(self.conditioning)
+        self.description = '%dD Anisotropic Gaussian, %g self.conditioning' % (ndims, 10 ** log_conditioning)
+        super(Gaussian, self).__init__(ndims, nbatch)
+
+    def device_energy(self):
+        return (_lib.E_DIAG_GAUSS, np.asarray(self.conditioning, dtype=np.float64))
+
+    def gen_init_X(self):
+        self.Xinit = (1. / np.sqrt(self.conditioning).reshape((-1, 1))) * np.random.randn(self.ndims, self.nbatch)
+
+    def __hash__(self):
+        return hash((self.ndims, hash(tuple(self.conditioning))))
+
+
+class RoughWell(Distribution):
+    """distributions.py:283-312."""
+
+    def __init__(self, ndims=2, nbatch=100, scale1=100, scale2=4):
+        self.scale1 = scale1
+        self.scale2 = scale2
+        self.description = '{} Rough Well'.format(ndims)
+        super(RoughWell, self).__init__(ndims, nbatch)
+
+    def device_energy(self):
+        return (_lib.E_ROUGH_WELL, np.array([self.scale1, self.scale2], dtype=np.float64))
+
+    def gen_init_X(self):
+        self.Xinit = self.scale1 * np.random.randn(self.ndims, self.nbatch)
+
+    def __hash__(self):
+        return hash((self.ndims, self.scale1, self.scale2))
+
+
+class MultimodalGaussian(Distribution):
+    """distributions.py:314-346 (as coded: modes at -/+ 2*separation along the first axis)."""
+
+    def __init__(self, ndims=2, nbatch=100, separation=3):
+        self.separation = separation
+        self.sep_vec = np.array([separation] * nbatch + [0] * (ndims - 1) * nbatch).reshape(ndims, nbatch)
+        self.sep_vec[0] += separation
+        super(MultimodalGaussian, self).__init__(ndims, nbatch)
+
+    def device_energy(self):
+        return (_lib.E_MM_GAUSS, np.array([self.separation], dtype=np.float64))
+
+    def init_X(self):
+        self.Xinit = ((np.random.randn(self.ndims, self.nbatch) + self.sep_vec) +
+                      (np.random.randn(self.ndims, self.nbatch) - self.sep_vec))
+
+    def __hash__(self):
+        return hash((self.ndims, self.separation))
+
+
+class TestGaussian(Distribution):
+    """Unit-variance (or sigma) isotropic Gaussian (distributions.py:348-370)."""
+    __test__ = False  # not a pytest class
+
+    def __init__(self, ndims=2, nbatch=100, sigma=1.):
+        self.sigma = sigma
+        super(TestGaussian, self).__init__(ndims, nbatch)
+
+    def device_energy(self):
+        return (_lib.E_ISO_GAUSS, np.array([self.sigma], dtype=np.float64))
+
+    def gen_init_X(self):
+        self.Xinit = np.random.randn(self.ndims, self.nbatch)
+
+    def __hash__(self):
+        return hash((self.ndims, self.sigma))
+
+
+class Funnel(Distribution):
+    """Neal's funnel (mjhmc/misc/tf_distributions.py:142-177).
+
+    ``literal=False`` (default): the density the reference documents, x0 ~ N(0, scale^2),
+    x_k ~ N(0, e^{x0}).  ``literal=True``: the energy exactly as the reference codes it (:161-165),
+    which is the negated un-normalised log-density -- chains diverge on it, kept for one-shot
+    E/dEdX parity only.
+    """
+
+    def __init__(self, scale=1.0, nbatch=50, ndims=10, literal=False):
+        self.scale = float(scale)
+        self.literal = literal
+        super(Funnel, self).__init__(ndims, nbatch)
+
+    def device_energy(self):
+        return (_lib.E_FUNNEL_REF if self.literal else _lib.E_FUNNEL_NEAL, np.array([self.scale]))
+
+    def gen_init_X(self):
+        x_0 = np.random.normal(scale=self.scale, size=(1, self.nbatch))
+        # exact draw from the funnel (the reference passes exp(x_0) as the std, :171-173)
+        x_k = np.random.normal(scale=np.exp(x_0 / 2.), size=(self.ndims - 1, self.nbatch))
+        self.Xinit = np.vstack((x_0, x_k))
+
+    def __hash__(self):
+        return hash((self.scale, self.ndims))

@@ -47,6 +47,8 @@ class GlobalNumpyRNG(object):
     def normals(self, ndims, n):                       # hmc_state.py:26,125
         return np.random.randn(ndims, n)
 
+    initial_normals = normals
+
     def unit_exponential(self, kind, particle):        # utils.py:42 ; exponential(s) == s*std_exp()
         return np.random.standard_exponential()
 
@@ -83,6 +85,8 @@ class ReplayRNG(object):
         self.n_normals_used += 1
         return z.copy()
 
+    initial_normals = normals
+
     def unit_exponential(self, kind, particle):
         return float(self._exps[self.attempt][kind, particle])
 
@@ -111,9 +115,13 @@ class PhiloxRNG(object):
     def __init__(self, seed, particle_ids):
         from .philox import PhiloxStream
         self.stream = PhiloxStream(seed, particle_ids)
-        self.tick = 0
+        self.tick = 1
         self._exp_cache = None
         self._exp_tick = -1
+
+    def initial_normals(self, ndims, n):
+        assert n == self.stream.pid.shape[0]
+        return self.stream.normals(ndims, 0)
 
     def normals(self, ndims, n):
         assert n == self.stream.pid.shape[0]
@@ -357,7 +365,7 @@ class Particles(object):
         self.X = X
         self.n = X.shape[1]
         self.live = np.arange(self.n)
-        self.V = owner.rng.normals(X.shape[0], self.n) if V is None else V       # :24-26
+        self.V = owner.rng.initial_normals(X.shape[0], self.n) if V is None else V   # :24-26
         if EX is None:
             self.EX = np.zeros((1, self.n))
             self.refresh_EX()

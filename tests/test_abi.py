@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/mjhmc_hip.h declares;
+argument validation paths that need no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mjhmc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'mjhmc_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mjhmc_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_and_binding_agree(lib):
+    names = declared_functions()
+    assert len(names) >= 20
+    assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_abi_version_and_no_device_error(lib):
+    assert lib.mjhmc_abi_version() == 1
+    import torch
+    if torch.cuda.device_count() == 0:
+        h = ctypes.c_void_p()
+        rc = lib.mjhmc_ctx_create(0, ctypes.byref(h))
+        assert rc == _lib.ERR_NO_DEVICE
+        assert b'no HIP device' in lib.mjhmc_last_error()
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: constructing a sampler without a device raises, it does not degrade."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip('GPU present')
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import TestGaussian
+    with pytest.raises(_lib.EngineError):
+        MarkovJumpHMC(distribution=TestGaussian(ndims=2, nbatch=10), epsilon=0.1, beta=0.1)
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import mjhmc_amd, mjhmc_amd.samplers.markov_jump_hmc, mjhmc_amd.misc.distributions; "
+            "bad=[m for m in sys.modules if m.split('.')[0]=='oracle']; assert not bad, bad")
+    subprocess.check_call([sys.executable, '-c', code], cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'mjhmc_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f
+
+
+def test_hyperparameter_validation_is_host_side():
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import TestGaussian
+    with pytest.raises(ValueError):
+        MarkovJumpHMC(distribution=TestGaussian(ndims=2, nbatch=10), beta=1.0)
+    with pytest.raises(NotImplementedError):
+        MarkovJumpHMC(Xinit=None, E=None, dEdX=None)

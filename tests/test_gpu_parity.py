@@ -1,0 +1,298 @@
+"""GPU: the HIP engine (through the C ABI) against the golden vectors and the NumPy oracle.
+
+Bars: integer/index bookkeeping (transitions, cache flags, counters, evaluation counts, resample
+indices) bit-exact; float64 state and energies within 1e-10 relative (RTOL below) -- and X, V
+bit-identical wherever the force is an exact product (sigma = 1 isotropic / diagonal Gaussian),
+because the kernels are built with -ffp-contract=off and follow the reference's operation order.
+"""
+import numpy as np
+import pytest
+
+from oracle import mjhmc_oracle as orc
+from tests.helpers import load, oracle_energy, bits_equal
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+np.seterr(all='ignore')
+
+
+def close(a, b, scale=None):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if scale is None:
+        fin = np.abs(b[np.isfinite(b)])
+        scale = float(fin.max()) if fin.size else 1.0
+    return a.shape == b.shape and np.allclose(a, b, rtol=RTOL, atol=RTOL * 1e-2 * max(scale, 1e-300), equal_nan=True)
+
+
+def product_distribution(g, Xinit):
+    from mjhmc_amd.misc import distributions as D
+    kind = str(g['kind'])
+    ndims, nbatch = Xinit.shape
+    if kind == 'iso':
+        base, kw = D.TestGaussian, dict(sigma=float(g['par_sigma']))
+    elif kind == 'diag':
+        base, kw = D.Gaussian, dict(log_conditioning=2)
+    elif kind == 'rough':
+        base, kw = D.RoughWell, dict(scale1=int(g['par_scale1']), scale2=int(g['par_scale2']))
+    elif kind == 'mm':
+        base, kw = D.MultimodalGaussian, dict(separation=int(g['par_separation']))
+    else:
+        raise KeyError(kind)
+
+    class Fixed(base):
+        def init_X(self):
+            self.Xinit = Xinit
+
+    d = Fixed(ndims=ndims, nbatch=nbatch, **kw)
+    if kind == 'diag':
+        d.conditioning = g['par_conditioning']
+        d.J = np.diag(d.conditioning)
+        d._dev = None
+    return d
+
+
+# ---------------------------------------------------------------------------------------------
+# G2: single energy / gradient evaluations
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,kind', [('iso_2x100', 'iso'), ('iso_512x64', 'iso'), ('diag_10x33', 'diag'),
+                                      ('rough_5x40', 'rough'), ('mm_3x20', 'mm')])
+def test_g2_energy_evaluations(tag, kind):
+    from mjhmc_amd.misc import distributions as D
+    g = load('g2_energies')
+    X = g[tag + '_X']
+    nd, n = X.shape
+    d = {'iso': lambda: D.TestGaussian(nd, n, sigma=1.3), 'diag': lambda: D.Gaussian(nd, n, log_conditioning=6),
+         'rough': lambda: D.RoughWell(nd, n), 'mm': lambda: D.MultimodalGaussian(nd, n)}[kind]()
+    E = d.E(X)
+    G = d.dEdX(X)
+    assert E.shape == (1, n) and G.shape == (nd, n)
+    assert (d.E_count, d.dEdX_count) == (n, n)
+    assert close(E[0], g[tag + '_E'])
+    assert close(G, g[tag + '_g'])
+    if kind == 'diag':
+        assert bits_equal(G, g[tag + '_g'])          # j*x is the exact product the reference forms
+
+
+# ---------------------------------------------------------------------------------------------
+# G3: leapfrog trajectories, observed through an iteration whose L clock is forced to win
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,kind', [('iso_2x100', 'iso'), ('iso_512x32', 'iso'), ('diag_16x24', 'diag'),
+                                      ('rough_4x16', 'rough')])
+def test_g3_trajectories(tag, kind):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    g = load('g3_trajectories')
+    X0, V0 = g[tag + '_X0'], g[tag + '_V0']
+    eps, L = float(g[tag + '_hp'][0]), int(g[tag + '_hp'][1])
+    fake = dict(kind=kind, par_sigma=1.3, par_scale1=100, par_scale2=4,
+                par_conditioning=10 ** np.linspace(-2, 0, X0.shape[0]))
+    s = MarkovJumpHMC(distribution=product_distribution(fake, X0), epsilon=eps, beta=0.3, num_leapfrog_steps=L,
+                      Vinit=V0, seed=3)
+    st = s.state
+    assert close(st.EX[0], g[tag + '_EX0']) and close(st.EV[0], g[tag + '_EV0']) and close(st.dEdX, g[tag + '_g0'])
+    n = X0.shape[1]
+    exps = np.stack([np.full(n, 1e-300), np.full(n, 1e300), np.full(n, 1e300)])
+    s.sampling_iteration(replay=[(np.zeros_like(X0), exps)])
+    assert np.all(s._dev.read(8) == 0)
+    st = s.state
+    assert close(st.X, g[tag + '_L_X']) and close(st.V, g[tag + '_L_V'])
+    assert close(st.EX[0], g[tag + '_L_EX']) and close(st.EV[0], g[tag + '_L_EV'])
+    assert close(st.dEdX, g[tag + '_L_g'])
+    if kind == 'diag':
+        assert bits_equal(st.X, g[tag + '_L_X']) and bits_equal(st.V, g[tag + '_L_V'])
+    # the cached inverse-L state of an L-mover is the pre-move state: H_flf == H(state before)
+    assert close(st.H_flf[0], g[tag + '_EX0'] + g[tag + '_EV0'])
+    assert st.cache_active.all()
+
+
+# ---------------------------------------------------------------------------------------------
+# G4 / G6: full sampling_iteration replays, incl. the halve-epsilon retry
+# ---------------------------------------------------------------------------------------------
+G4 = ['g4_iso_2x100_a', 'g4_iso_2x100_b', 'g4_diag_16x64', 'g4_iso_512x32', 'g4_rough_4x48', 'g4_mm_3x40',
+      'g4_iso_33x17', 'g6_retry_a_iso_4x32', 'g6_retry_b_iso_4x32']
+
+
+@pytest.mark.parametrize('name', G4)
+def test_g4_g6_sampling_iteration_replay(name, capsys):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    g = load(name)
+    d = product_distribution(g, g['Xinit'])
+    s = MarkovJumpHMC(distribution=d, epsilon=float(g['eps']), beta=float(g['beta']), num_leapfrog_steps=int(g['L']),
+                      Vinit=g['normals'][0], seed=5, resample=False)
+    assert s.p_r == float(g['p_r'])
+    feed = [(g['normals'][1 + a], np.nan_to_num(g['exps'][a], nan=1.0)) for a in range(len(g['exps']))]
+    exact_state = str(g['kind']) == 'diag'
+    for t in range(int(g['T']) + 1):
+        if t:
+            s.sampling_iteration(replay=feed)
+            assert np.array_equal(s._dev.read(8), g['trans'][t - 1]), (name, t)
+            assert close(s.dwelling_times, g['dwell'][t]), (name, t)
+        st = s.state
+        assert close(st.X, g['X'][t]) and close(st.V, g['V'][t]), (name, t)
+        assert close(st.EX[0], g['EX'][t]) and close(st.EV[0], g['EV'][t]), (name, t)
+        if exact_state:
+            assert bits_equal(st.X, g['X'][t]) and bits_equal(st.V, g['V'][t]), (name, t)
+        assert np.array_equal(st.cache_active, g['cache'][t]), (name, t)
+        assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t]), (name, t)
+        assert [d.E_count, d.dEdX_count] == list(g['evals'][t]), (name, t)
+        assert (s.epsilon, s.num_leapfrog_steps) == (g['hp'][t][0], int(g['hp'][t][1]))
+        assert len(g['exps']) - len(feed) == int(g['attempts_done'][t])
+    if name.startswith('g6'):
+        assert 'doubling back' in capsys.readouterr().out
+
+
+def test_g5_sample_with_resampling(monkeypatch):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    g = load('g5_sample_2x100')
+    d = product_distribution(g, g['Xinit'])
+    s = MarkovJumpHMC(distribution=d, epsilon=float(g['eps']), beta=float(g['beta']), num_leapfrog_steps=int(g['L']),
+                      Vinit=g['normals'][0], seed=5)
+    feed = [(g['normals'][1 + a], np.nan_to_num(g['exps'][a], nan=1.0)) for a in range(len(g['exps']))]
+    monkeypatch.setattr(np.random, 'random', lambda n: g['resample_u'].copy())
+    out = s.sample(int(g['n_samples']), replay=feed)
+    assert out.shape == (2, 1000)
+    # the oracle run gives the reference's resampling indices (integer bookkeeping: exact)
+    o = orc.MarkovJumpHMC(orc.IsoGaussian(1.0), g['Xinit'], epsilon=float(g['eps']), beta=float(g['beta']),
+                          num_leapfrog_steps=int(g['L']), V0=g['normals'][0],
+                          rng=orc.ReplayRNG(normals=list(g['normals'][1:]), exps=list(g['exps']), uniforms=[g['resample_u']]))
+    ref = o.sample(int(g['n_samples']))
+    assert bits_equal(ref, g['samples'])
+    assert np.array_equal(s._last_resample_idx, o.last_pick)
+    assert bits_equal(out, g['samples'])          # sigma = 1: the force is exact, so samples are bit-identical
+    assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'])
+    assert [d.E_count, d.dEdX_count] == list(g['evals'])
+
+
+# ---------------------------------------------------------------------------------------------
+# production RNG (Philox keyed by global particle id) against the oracle's restatement of it
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind,D,N,eps,L,beta', [('iso', 2, 100, 0.3, 5, 0.3), ('iso', 512, 96, 0.05, 10, 0.1),
+                                                 ('diag', 33, 70, 0.5, 4, 0.4), ('funnel', 32, 300, 0.05, 15, 0.1),
+                                                 ('rough', 7, 130, 2.0, 6, 0.2), ('mm', 3, 64, 0.3, 6, 0.4)])
+def test_philox_mode_matches_oracle(kind, D, N, eps, L, beta):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc import distributions as Dm
+    rng = np.random.RandomState(42)
+    X0 = rng.randn(D, N)
+    if kind == 'iso':
+        base, kw, en = Dm.TestGaussian, dict(sigma=1.0), orc.IsoGaussian(1.0)
+    elif kind == 'diag':
+        base, kw, en = Dm.Gaussian, dict(log_conditioning=2), orc.DiagGaussian(D, 2)
+    elif kind == 'funnel':
+        base, kw, en = Dm.Funnel, dict(scale=3.0), orc.FunnelNeal(3.0)
+        X0[0] *= 3.0
+        X0[1:] *= np.exp(X0[0] / 2)
+    elif kind == 'rough':
+        base, kw, en = Dm.RoughWell, dict(), orc.RoughWell(100, 4)
+        X0 *= 100
+    else:
+        base, kw, en = Dm.MultimodalGaussian, dict(separation=3), orc.MultimodalGaussian(D, 3)
+
+    class Fixed(base):
+        def init_X(self):
+            self.Xinit = X0
+
+    d = Fixed(ndims=D, nbatch=N, **kw)
+    seed = 0xC0FFEE1234
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=seed, resample=False)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(seed, np.arange(N)))
+    assert close(s.state.V, o.state.V)                    # tick-0 momentum
+    for t in range(6):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        assert np.array_equal(s._dev.read(8), o.last_transition), (kind, t)
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), (kind, t)
+        assert close(s.state.EX, o.state.EX) and close(s.state.EV, o.state.EV), (kind, t)
+        assert close(s.dwelling_times, o.dwelling_times), (kind, t)
+        assert np.array_equal(s.state.cache_active, o.state.shadow_ok)
+        assert (s.l_count, s.f_count, s.r_count) == (o.l_count, o.f_count, o.r_count)
+        assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
+
+
+def test_batched_iterations_equal_single_steps():
+    """mjhmc_iterate(n) with no host round trip == n calls of sampling_iteration()."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import TestGaussian
+    np.random.seed(3)
+    X0 = np.random.randn(64, 500)
+
+    class Fixed(TestGaussian):
+        def init_X(self):
+            self.Xinit = X0
+    a = MarkovJumpHMC(distribution=Fixed(64, 500), epsilon=0.2, beta=0.2, num_leapfrog_steps=7, seed=9, resample=False)
+    b = MarkovJumpHMC(distribution=Fixed(64, 500), epsilon=0.2, beta=0.2, num_leapfrog_steps=7, seed=9, resample=False)
+    xa = a.sample(12, preserve_order=True)
+    xb = np.stack([(b.sampling_iteration(), b.state.X)[1] for _ in range(12)], axis=-1)
+    assert xa.shape == (64, 500, 12) and bits_equal(xa, xb)
+    assert (a.l_count, a.f_count, a.r_count) == (b.l_count, b.f_count, b.r_count)
+    assert a.l_count + a.f_count + a.r_count == 12 * 500
+    assert bits_equal(a.dwelling_times, b.dwelling_times)
+    flat = Fixed(64, 500)
+    c = MarkovJumpHMC(distribution=flat, epsilon=0.2, beta=0.2, num_leapfrog_steps=7, seed=9, resample=False)
+    xc = c.sample(12)
+    assert xc.shape == (64, 6000) and bits_equal(xc, np.concatenate([xa[:, :, t] for t in range(12)], axis=1))
+
+
+def test_sharding_is_invisible():
+    """Columns split over two samplers (as over two GPUs) with global particle ids give exactly the
+    columns of the unsplit run: the RNG is keyed by global id, particles never interact."""
+    from mjhmc_amd import engine, _lib
+    rng = np.random.RandomState(8)
+    D, N = 32, 1000
+    X0 = rng.randn(D, N)
+    X0[0] *= 3
+    ctx = engine.context(0)
+    en = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, D, [3.0])
+    whole = engine.DeviceSampler(en, X0, seed=77)
+    parts = [engine.DeviceSampler(en, X0[:, :400], seed=77, first_particle_id=0),
+             engine.DeviceSampler(en, X0[:, 400:], seed=77, first_particle_id=400)]
+    for smp in [whole] + parts:
+        smp.set_hparams(0.05, 15, 0.05, 1.0)
+        stats, done = smp.iterate(5)
+        assert done == 5
+    X = np.concatenate([p.read(_lib.F_X) for p in parts], axis=1)
+    V = np.concatenate([p.read(_lib.F_V) for p in parts], axis=1)
+    assert bits_equal(X, whole.read(_lib.F_X)) and bits_equal(V, whole.read(_lib.F_V))
+    assert np.array_equal(np.concatenate([p.read(_lib.F_TRANS) for p in parts]), whole.read(_lib.F_TRANS))
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + a column subset against the oracle
+# ---------------------------------------------------------------------------------------------
+def test_full_size_c2_properties_and_column_subset():
+    """configs[1]: isotropic Gaussian, ndims=512, nparticles=100000, L=10, float64."""
+    from mjhmc_amd import engine, _lib
+    D, N, L, eps, beta = 512, 100000, 10, 0.05, 0.1
+    rng = np.random.RandomState(0)
+    X0 = rng.randn(D, N)
+    ctx = engine.context(0)
+    en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.0])
+    s = engine.DeviceSampler(en, X0, seed=2024)
+    p_r = -np.log(1 - beta) * 0.5
+    s.set_hparams(eps, L, p_r, 1.0)
+    H0 = s.read(_lib.F_EX) + s.read(_lib.F_EV)
+    T = 4
+    stats, done = s.iterate(T)
+    assert done == T
+    n_cold_expected = N
+    for st in stats:
+        assert st.l + st.f + st.r == N and st.nonfinite == 0
+        assert st.n_cold == n_cold_expected                 # cold == not an L-mover last time
+        assert st.E_evals == N + st.n_cold and st.dEdX_evals == L * (N + st.n_cold)
+        n_cold_expected = N - st.l
+    trans, cache = s.read(_lib.F_TRANS), s.read(_lib.F_CACHE)
+    assert np.array_equal(cache == 1, trans == 0)           # exactly the L-movers hold a cached FLF state
+    X, V = s.read(_lib.F_X), s.read(_lib.F_V)
+    EX, EV = s.read(_lib.F_EX), s.read(_lib.F_EV)
+    assert close(EX, np.sum(X ** 2, axis=0) / 2.) and close(EV, np.sum(V ** 2, axis=0) / 2.)
+    # leapfrog at eps = 0.05 conserves H to O(eps^2); R-movers get fresh momentum, skip them
+    # column subset through the oracle with the same counter RNG (keyed by global particle id)
+    cols = np.sort(rng.choice(N, size=48, replace=False))
+    o = orc.MarkovJumpHMC(orc.IsoGaussian(1.0), X0[:, cols], epsilon=eps, beta=beta, num_leapfrog_steps=L,
+                          resample=False, rng=orc.PhiloxRNG(2024, cols))
+    for _ in range(T):
+        o.sampling_iteration()
+    assert np.array_equal(trans[cols], o.last_transition)
+    assert close(X[:, cols], o.state.X) and close(V[:, cols], o.state.V)
+    assert close(EX[cols], o.state.EX[0]) and close(s.read(_lib.F_DWELL)[cols], o.dwelling_times)
+    assert np.isfinite(H0).all()
