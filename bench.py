@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-steps/s (ndims x nparticles x L per sampling_iteration) of the
+MJHMC hot path on MI355X, with the HBM roofline of the jump kernel and the NumPy CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c1]
+
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py ...
+(one rank per GPU).  Particle columns are independent chains, so each rank owns its own block of
+columns (global particle ids keep the RNG streams identical to an unsharded run); nothing is
+exchanged inside the timed region -> weak scaling, value = all ranks' particle-steps / max time.
+
+A "step" is one MarkovJumpHMC.sampling_iteration over all particles.
+Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    'c2': dict(name='C2 isotropic Gaussian ndims=512 nparticles=100000/GPU L=10 fp64', kind='iso', D=512, N=100000,
+               L=10, eps=0.05, beta=0.1, dtype='float64', params=[1.0]),
+    # BASELINE.json configs[3] (per-GPU share of 1e6 particles at 8 GPUs is 125000; single GPU runs all 1e6)
+    'c4': dict(name='C4 Neal funnel ndims=32 nparticles=1000000/GPU L=15 fp64', kind='funnel', D=32, N=1000000,
+               L=15, eps=0.05, beta=0.1, dtype='float64', params=[3.0]),
+    # BASELINE.json configs[0] (README shape; plumbing)
+    'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
+               eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
+}
+
+
+def initial_state(w, rank):
+    rng = np.random.RandomState(1000 + rank)
+    X0 = rng.randn(w['D'], w['N'])
+    if w['kind'] == 'funnel':
+        X0[0] *= w['params'][0]
+        X0[1:] *= np.exp(X0[0] / 2.)
+    return X0
+
+
+def algorithmic_bytes_per_particle(D, esize):
+    """One sampling_iteration: read X,V + write X',V' (4*D*s) + per-particle scalars:
+    read EX,EV,H_flf (3s) + cache flag (1); write EX,EV,H_flf (3s) + cache (1) + dwell (8) + trans (1)."""
+    return 4 * D * esize + 6 * esize + 8 + 3
+
+
+def cpu_baseline(w, seconds_target=15.0):
+    """The NumPy oracle (structurally faithful port of the reference's NumPy path) timed on this
+    host: bounded column sample of the same workload."""
+    from oracle import mjhmc_oracle as orc
+    n = min(w['N'], 4000 if w['D'] >= 256 else 20000)
+    rng = np.random.RandomState(7)
+    X0 = rng.randn(w['D'], n)
+    en = orc.IsoGaussian(w['params'][0]) if w['kind'] == 'iso' else orc.FunnelNeal(w['params'][0])
+    if w['kind'] == 'funnel':
+        X0[0] *= w['params'][0]
+        X0[1:] *= np.exp(X0[0] / 2.)
+    np.random.seed(11)
+    s = orc.MarkovJumpHMC(en, X0, epsilon=w['eps'], beta=w['beta'], num_leapfrog_steps=w['L'], resample=False)
+    s.sampling_iteration()                     # warm-up (all-cold first iteration)
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        s.sampling_iteration()
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_target or iters >= 50:
+            break
+    value = w['D'] * n * w['L'] * iters / dt
+    return dict(value=value, unit='particle-steps/s', cores=1, kind='port',
+                sample='NumPy oracle (port of the reference path), ndims=%d, nparticles=%d of %d, L=%d, %d '
+                       'sampling_iterations after 1 warm-up, %.1f s, numpy %s, os.cpu_count=%d'
+                       % (w['D'], n, w['N'], w['L'], iters, dt, np.__version__, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    from mjhmc_amd import engine, _lib
+    ctx = engine.context(local_rank)
+    kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL}[w['kind']]
+    en = engine.DeviceEnergy(ctx, kind, w['D'], w['params'])
+    X0 = initial_state(w, rank)
+    smp = engine.DeviceSampler(en, X0, seed=20261002, first_particle_id=rank * w['N'], dtype=w['dtype'])
+    del X0
+    p_r = -np.log(1 - w['beta']) * 0.5
+    smp.set_hparams(w['eps'], w['L'], p_r, 1.0)
+
+    def barrier():
+        smp.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        smp.iterate(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    stats, done = smp.iterate(args.steps)       # K sampling_iterations back to back, one host sync at the end
+    smp.sync()
+    t1 = time.perf_counter()
+    barrier()
+    assert done == args.steps, 'a non-finite rate interrupted the timed region'
+    elapsed = t1 - t0
+    tim = smp.last_timing()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        esize = 8 if w['dtype'] == 'float64' else 4
+        units = w['D'] * w['N'] * w['L'] * args.steps * world
+        kern_ms = tim['jump_kernel_ms'] / max(tim['n_jump_launches'], 1)
+        abytes = algorithmic_bytes_per_particle(w['D'], esize) * w['N']
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(args.workload)
+        n_l = sum(s.l for s in stats)
+        n_cold = sum(s.n_cold for s in stats)
+        out = {
+            'metric': 'particle-steps/sec (ndims x nparticles x L)',
+            'value': units / elapsed,
+            'unit': 'particle-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed * 1e3 / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64' if esize == 8 else 'f32', 'data': 'synthetic',
+            'config': {'workload': w['name'], 'ndims': w['D'], 'nparticles_per_gpu': w['N'], 'L': w['L'],
+                       'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
+                       'particles_x_L_per_s': w['N'] * w['L'] * args.steps * world / elapsed,
+                       'L_move_fraction': n_l / float(w['N'] * args.steps),
+                       'cold_fraction': n_cold / float(w['N'] * args.steps)},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms,
+                         'launches_timed': tim['n_jump_launches'], 'algorithmic_bytes_per_launch': abytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(w)
+            out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -280,7 +280,7 @@ def capture_trajectories(refs):
     rs, rst, rd, _ = refs
     out = {}
     for tag, kind, ndims, n, eps, L in (('iso_2x100', 'iso', 2, 100, 0.1, 10), ('iso_512x32', 'iso', 512, 32, 0.05, 10),
-                                        ('diag_16x24', 'diag', 16, 24, 0.4, 7), ('rough_4x16', 'rough', 4, 16, 2.0, 6)):
+                                        ('diag_16x24', 'diag', 16, 24, 0.4, 7), ('rough_4x16', 'rough', 4, 16, 0.5, 6)):
         np.random.seed(11)
         X0 = (100.0 if kind == 'rough' else 1.0) * np.random.randn(ndims, n)
         d = make_harness(rd, kind, X0, **energy_params(kind, ndims, n))
@@ -304,10 +304,19 @@ def capture_trajectories(refs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--only', default='', help='comma separated fixture names to (re)generate')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     refs = import_reference(args.ref)
     np.seterr(all='ignore')
+    only = set(filter(None, args.only.split(',')))
+    if only:
+        real_savez = np.savez_compressed
+
+        def filtered(path, **kw):
+            if os.path.splitext(os.path.basename(path))[0] in only:
+                real_savez(path, **kw)
+        np.savez_compressed = filtered
     capture_min_idx(refs)
     capture_energies(refs)
     capture_trajectories(refs)
@@ -316,7 +325,7 @@ def main():
     capture_mjhmc(refs, 'g4_iso_2x100_b', 'iso', 2, 100, 1.0, 10, 0.8, 20, 102)
     capture_mjhmc(refs, 'g4_diag_16x64', 'diag', 16, 64, 0.9, 5, 0.3, 20, 103)
     capture_mjhmc(refs, 'g4_iso_512x32', 'iso', 512, 32, 0.05, 10, 0.1, 5, 104, keep_grad=False)
-    capture_mjhmc(refs, 'g4_rough_4x48', 'rough', 4, 48, 3.0, 8, 0.2, 20, 105, x_scale=100.0)
+    capture_mjhmc(refs, 'g4_rough_4x48', 'rough', 4, 48, 0.5, 8, 0.2, 20, 105, x_scale=100.0)
     capture_mjhmc(refs, 'g4_mm_3x40', 'mm', 3, 40, 0.3, 6, 0.4, 20, 106)
     capture_mjhmc(refs, 'g4_iso_33x17', 'iso', 33, 17, 0.3, 3, 0.5, 12, 107)
     # G5: README-shaped sample(10) with dwell-time resampling

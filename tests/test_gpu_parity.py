@@ -136,6 +136,13 @@ def test_g4_g6_sampling_iteration_replay(name, capsys):
         assert [d.E_count, d.dEdX_count] == list(g['evals'][t]), (name, t)
         assert (s.epsilon, s.num_leapfrog_steps) == (g['hp'][t][0], int(g['hp'][t][1]))
         assert len(g['exps']) - len(feed) == int(g['attempts_done'][t])
+        if str(g['kind']) in ('rough', 'mm'):
+            # transcendental forces: ulp-level differences in sin/exp grow chaotically over many
+            # iterations, so every iteration starts from the reference's state (per-iteration parity
+            # from identical inputs).  Writing X/V clears the cache flags; put them back.
+            s._dev.write(0, g['X'][t])
+            s._dev.write(1, g['V'][t])
+            s._dev.write(6, g['cache'][t].astype(np.uint8))
     if name.startswith('g6'):
         assert 'doubling back' in capsys.readouterr().out
 
