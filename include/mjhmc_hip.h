@@ -81,8 +81,8 @@ typedef enum {
   MJHMC_F_EX = 2,     /* HMCState.EX                                 float64 (N)    r  */
   MJHMC_F_EV = 3,     /* HMCState.EV                                 float64 (N)    r  */
   MJHMC_F_DEDX = 4,   /* HMCState.dEdX (recomputed from X on demand) float64 (D,N)  r  */
-  MJHMC_F_HFLF = 5,   /* H() of HMCState.cached_flf_state            float64 (N)    r  */
-  MJHMC_F_CACHE = 6,  /* HMCState.cache_active                       uint8   (N)    rw */
+  MJHMC_F_HFLF = 5,   /* H() of HMCState.cached_flf_state, NaN where the cache is cold  float64 (N) rw */
+  MJHMC_F_CACHE = 6,  /* HMCState.cache_active (== H_flf is not NaN)  uint8   (N)    r  */
   MJHMC_F_DWELL = 7,  /* ContinuousTimeHMC.dwelling_times            float64 (N)    r  */
   MJHMC_F_TRANS = 8   /* argmin row of min_idx (0=L,1=F,2=R; CONTROL: bit0=FL accepted, bit1=flipped) uint8 (N) r */
 } mjhmc_field;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmjhmc_hip.so')
+LIB_PATH = os.environ.get('MJHMC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmjhmc_hip.so')
 
 # enums of include/mjhmc_hip.h
 E_ISO_GAUSS, E_DIAG_GAUSS, E_ROUGH_WELL, E_MM_GAUSS, E_FUNNEL_NEAL, E_FUNNEL_REF, E_PRODUCT_OF_T, E_SPARSE_CODE = range(8)

@@ -74,7 +74,6 @@ struct mjhmc_sampler {
   void* EX[2] = {nullptr, nullptr};
   void* EV[2] = {nullptr, nullptr};
   void* Hflf[2] = {nullptr, nullptr};
-  uint8_t* cache[2] = {nullptr, nullptr};
   double* dwell = nullptr;
   uint8_t* trans = nullptr;
   Control* ctl = nullptr;
@@ -201,49 +200,17 @@ __global__ void widen_vec(const T* __restrict__ src, double* __restrict__ dst, i
   if (i < n) dst[i] = (double)src[i];
 }
 
-// stats[0..3] += (#trans==0, #trans==1, #trans==2, #cold) for one attempt.
-// Control mode: trans bit0 = FL accepted, bit1 = flipped -> (both, flip only, -, accept only)
-__global__ void count_kernel(const uint8_t* __restrict__ trans, const uint8_t* __restrict__ cache_in, int64_t N,
-                             const Control* ctl, int iter, int control_mode, unsigned long long* stats) {
-  const bool failed = ctl->failed != 0;
-  if (failed && ctl->failed_iter < iter) return;
-  const bool failed_now = failed && ctl->failed_iter == iter;
-  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-    const int t = trans[i];
-    if (control_mode) {
-      c0 += (t == 3);
-      c1 += (t == 2);
-      c3 += (t == 1);
-    } else {
-      if (!failed_now) {
-        c0 += (t == 0);
-        c1 += (t == 1);
-        c2 += (t == 2);
-      }
-      c3 += (cache_in[i] == 0);
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    c0 += __shfl_xor(c0, o);
-    c1 += __shfl_xor(c1, o);
-    c2 += __shfl_xor(c2, o);
-    c3 += __shfl_xor(c3, o);
-  }
-  __shared__ unsigned long long sm[4][4];
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sm[w][0] = c0;
-    sm[w][1] = c1;
-    sm[w][2] = c2;
-    sm[w][3] = c3;
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    unsigned long long t = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sm[k][threadIdx.x];
-    if (t) atomicAdd(&stats[threadIdx.x], t);
-  }
+// cache_active[i] = !isnan(H_flf[i])
+template <typename T>
+__global__ void flags_from_hflf(const T* __restrict__ h, uint8_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (h[i] == h[i]) ? 1 : 0;
+}
+
+template <typename T>
+__global__ void narrow_vec(const double* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (T)src[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -496,7 +463,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void* ptrs[] = {s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
-                  s->EV[1],   s->Hflf[0], s->Hflf[1],  s->cache[0], s->cache[1], s->dwell,  s->trans,
+                  s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch};
   for (void* p : ptrs)
@@ -543,9 +510,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       HIPCHK(hipMalloc(&s->EX[i], s->N * s->sh.esize));
       HIPCHK(hipMalloc(&s->EV[i], s->N * s->sh.esize));
       HIPCHK(hipMalloc(&s->Hflf[i], s->N * s->sh.esize));
-      HIPCHK(hipMalloc((void**)&s->cache[i], s->N));
-      HIPCHK(hipMemsetAsync(s->Hflf[i], 0, s->N * s->sh.esize, s->stream));
-      HIPCHK(hipMemsetAsync(s->cache[i], 0, s->N, s->stream));
+      HIPCHK(hipMemsetAsync(s->Hflf[i], 0xFF, s->N * s->sh.esize, s->stream));  // all-ones = NaN = cold
     }
     HIPCHK(hipMalloc((void**)&s->dwell, s->N * sizeof(double)));
     HIPCHK(hipMemsetAsync(s->dwell, 0, s->N * sizeof(double), s->stream));
@@ -592,7 +557,7 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
 int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
-  HIPCHK(hipMemsetAsync(s->cache[s->scur], 0, s->N, s->stream));
+  HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->N * s->sh.esize, s->stream));
   return 0;
 }
 
@@ -657,8 +622,6 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.EV_out = (T*)s->EV[si ^ 1];
     a.Hflf_in = (const T*)s->Hflf[si];
     a.Hflf_out = (T*)s->Hflf[si ^ 1];
-    a.cache_in = s->cache[si];
-    a.cache_out = s->cache[si ^ 1];
     a.dwell = s->dwell;
     a.dwell_ring = dring;
     a.trans = s->trans;
@@ -666,6 +629,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.rexp = replay_exp ? s->rexp : nullptr;
     a.runif = nullptr;
     a.ctl = s->ctl;
+    a.stats = (unsigned long long*)(s->stats + 4 * i);
     a.N = s->N;
     a.first_pid = s->first_pid;
     a.D = s->D;
@@ -686,10 +650,6 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     if (i < n_timed) HIPCHK(hipEventRecord(s->ev_k[2 * i], s->stream));
     TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
     if (i < n_timed) HIPCHK(hipEventRecord(s->ev_k[2 * i + 1], s->stream));
-    const unsigned cgrid = (unsigned)std::min<int64_t>(64, (s->N + 4095) / 4096);
-    hipLaunchKernelGGL(count_kernel, dim3(cgrid), dim3(256), 0, s->stream, (const uint8_t*)s->trans,
-                       (const uint8_t*)s->cache[si], s->N, (const Control*)s->ctl, i, 0,
-                       (unsigned long long*)(s->stats + 4 * i));
     HIPCHK(hipGetLastError());
     xin = xo;
   }
@@ -743,6 +703,8 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
                   const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   if (n_iter < 1) return fail(MJHMC_ERR_INVALID, "n_iter must be >= 1");
+  if ((replay_normal == nullptr) != (replay_exp == nullptr))
+    return fail(MJHMC_ERR_INVALID, "replay_normal and replay_exp must be given together");
   if (ring_slot0 >= 0 && (!s->ring || ring_slot0 + n_iter > s->ring_slots))
     return fail(MJHMC_ERR_INVALID, "ring slots out of range (call mjhmc_ring_alloc)");
   HIPCHK(hipSetDevice(s->ctx->device));
@@ -793,11 +755,23 @@ int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
       HIPCHK(hipMemcpyAsync(host_dst, s->dwell, nbytes, hipMemcpyDeviceToHost, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
-    case MJHMC_F_CACHE:
+    case MJHMC_F_CACHE: {
+      if (nbytes != (size_t)s->N) return fail(MJHMC_ERR_INVALID, "expected N uint8");
+      TRY(ensure_stage(s, (size_t)(s->N + 7) / 8));
+      uint8_t* flags = (uint8_t*)s->stage;
+      const dim3 g((unsigned)((s->N + 255) / 256)), b(256);
+      if (s->dtype == MJHMC_F64)
+        hipLaunchKernelGGL(flags_from_hflf<double>, g, b, 0, s->stream, (const double*)s->Hflf[s->scur], flags, s->N);
+      else
+        hipLaunchKernelGGL(flags_from_hflf<float>, g, b, 0, s->stream, (const float*)s->Hflf[s->scur], flags, s->N);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(host_dst, flags, nbytes, hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      return 0;
+    }
     case MJHMC_F_TRANS:
       if (nbytes != (size_t)s->N) return fail(MJHMC_ERR_INVALID, "expected N uint8");
-      HIPCHK(hipMemcpyAsync(host_dst, field == MJHMC_F_CACHE ? s->cache[s->scur] : s->trans, nbytes,
-                            hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipMemcpyAsync(host_dst, s->trans, nbytes, hipMemcpyDeviceToHost, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
     default: return fail(MJHMC_ERR_INVALID, "unknown field");
@@ -815,15 +789,24 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       TRY(upload_matrix(s, (const double*)host_src, dst));
       TRY(run_eval(s, s->Xcur, nullptr, s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
-      HIPCHK(hipMemsetAsync(s->cache[s->scur], 0, s->N, s->stream));
+      HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->N * s->sh.esize, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
     }
-    case MJHMC_F_CACHE:
-      if (nbytes != (size_t)s->N) return fail(MJHMC_ERR_INVALID, "expected N uint8");
-      HIPCHK(hipMemcpyAsync(s->cache[s->scur], host_src, nbytes, hipMemcpyHostToDevice, s->stream));
+    case MJHMC_F_HFLF: {  // float64 (N); NaN marks a cold cache entry
+      if (nbytes != (size_t)s->N * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected N float64");
+      if (s->dtype == MJHMC_F64) {
+        HIPCHK(hipMemcpyAsync(s->Hflf[s->scur], host_src, nbytes, hipMemcpyHostToDevice, s->stream));
+      } else {
+        TRY(ensure_stage(s, (size_t)s->N));
+        HIPCHK(hipMemcpyAsync(s->stage, host_src, nbytes, hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(narrow_vec<float>, dim3((unsigned)((s->N + 255) / 256)), dim3(256), 0, s->stream,
+                           (const double*)s->stage, (float*)s->Hflf[s->scur], s->N);
+        HIPCHK(hipGetLastError());
+      }
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
+    }
     default: return fail(MJHMC_ERR_INVALID, "field is not writable");
   }
 }

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "philox.hpp"
 
 namespace mjhmc {
@@ -308,10 +310,8 @@ struct JumpArgs {
   const T* EV_in;
   T* EX_out;
   T* EV_out;
-  const T* Hflf_in;
+  const T* Hflf_in;   // H() of the cached inverse-L state; NaN = cache cold
   T* Hflf_out;
-  const uint8_t* cache_in;
-  uint8_t* cache_out;
   double* dwell;        // [N]
   double* dwell_ring;   // [N] slot or nullptr
   uint8_t* trans;       // [N]
@@ -319,6 +319,7 @@ struct JumpArgs {
   const double* rexp;   // replay unit exponentials [3][N], or nullptr
   const double* runif;  // replay uniforms (control mode) [2N+1], or nullptr
   Control* ctl;
+  unsigned long long* stats;  // [4]: #L, #F, #R, #cold of this attempt
   int64_t N;
   int64_t first_pid;
   int D, pitch, CH, logG;
@@ -390,6 +391,37 @@ __device__ __forceinline__ void store_row(T* row, const LaneMap& m, const T (&r)
   }
 }
 
+// per-wave LDS stripe [C][64] of 16-byte chunks
+template <typename T, int E>
+__device__ __forceinline__ void stash_put(typename VecOf<T>::type (*st)[64], int lane, const T (&r)[E]) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    if constexpr (VEC == 2) st[c][lane] = V{r[c * 2], r[c * 2 + 1]};
+    else st[c][lane] = V{r[c * 4], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
+  }
+}
+
+template <typename T, int E>
+__device__ __forceinline__ void stash_get(typename VecOf<T>::type (*st)[64], int lane, T (&r)[E]) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    const V q = st[c][lane];
+    if constexpr (VEC == 2) {
+      r[c * 2] = q.x;
+      r[c * 2 + 1] = q.y;
+    } else {
+      r[c * 4] = q.x;
+      r[c * 4 + 1] = q.y;
+      r[c * 4 + 2] = q.z;
+      r[c * 4 + 3] = q.w;
+    }
+  }
+}
+
 // M leapfrog steps, in place (hmc_state.py:86-100).  The half kicks are NOT merged, as in the
 // reference; c*g of the closing kick is reused by the next opening kick (same product).
 template <class En, typename T, int E>
@@ -447,6 +479,46 @@ __device__ __forceinline__ void refresh_noise(const T* noise_row, const RngKey& 
   }
 }
 
+// HMCState.R on the stashed momentum, chunk by chunk: v <- v*sqrt(1-beta) + n*sqrt(beta)
+// (hmc_state.py:125-126).  The chunk loop is deliberately NOT unrolled: one Box-Muller pair's
+// temporaries at a time keeps this rare branch from dictating the kernel's register budget.
+template <typename T, int E, bool REPLAY>
+__device__ __forceinline__ void refresh_stash(typename VecOf<T>::type (*st)[64], int lane, const T* noise_row,
+                                              const RngKey& key, uint32_t pid, const LaneMap& m, T keep, T mix) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll 1
+  for (int c = 0; c < E / VEC; ++c) {
+    const int chunk = c * m.G + m.j;
+    if (chunk >= m.CH) continue;  // stays zero
+    const V v0 = st[c][lane];
+    V z;
+    if constexpr (REPLAY) {
+      z = *reinterpret_cast<const V*>(noise_row + (size_t)chunk * VEC);
+    } else {
+      const int d = chunk * VEC;
+      double z0, z1;
+      normal_pair(key, pid, (uint32_t)(d >> 1), z0, z1);
+      z.x = (T)z0;
+      z.y = (d + 1 < m.D) ? (T)z1 : T(0);
+      if constexpr (VEC == 4) {
+        double z2 = 0.0, z3 = 0.0;
+        if (d + 2 < m.D) normal_pair(key, pid, (uint32_t)((d + 2) >> 1), z2, z3);
+        z.z = (T)z2;
+        z.w = (d + 3 < m.D) ? (T)z3 : T(0);
+      }
+    }
+    V r;
+    r.x = v0.x * keep + z.x * mix;
+    r.y = v0.y * keep + z.y * mix;
+    if constexpr (VEC == 4) {
+      r.z = v0.z * keep + z.z * mix;
+      r.w = v0.w * keep + z.w * mix;
+    }
+    st[c][lane] = r;
+  }
+}
+
 __device__ __forceinline__ double wait_time(double rate, double e, bool& bad) {
   // utils.py:37-48: rate == 0 -> inf; finite -> exponential(scale=1/rate) == (1/rate)*std_exp; else error
   if (rate == 0.0) return __builtin_huge_val();
@@ -480,133 +552,214 @@ __device__ __forceinline__ int first_min3(double a, double b, double c) {
 // the jump kernel (MJHMC mode)
 // ------------------------------------------------------------------------------------------
 
-template <class En, typename T, int E>
-__global__ __launch_bounds__(256) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
+// per-particle scalars travelling with a slot
+template <typename T>
+struct SlotScalars {
+  T EX, EV, Hflf;  // Hflf is NaN <=> the inverse-L cache of this particle is cold
+};
+
+// pins the first use of a prefetched value to this program point (otherwise the scheduler may pull
+// the use -- and with it a vmcnt wait that drains the whole prefetch -- up to the load)
+__device__ __forceinline__ void use_here(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void use_here(float& v) { asm volatile("" : "+v"(v)); }
+
+// REPLAY = true: random numbers come from host-supplied arrays (parity tests against recorded
+// reference runs).  It is a compile-time switch because any global load consumed inside the slot
+// body forces an in-order vmcnt wait that would also drain the prefetch of the next slot.
+template <class En, typename T, int E, bool REPLAY>
+__global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
+  // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
+  // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
   const int G = 1 << a.logG;
-  const int64_t p_raw = tid >> a.logG;
-  const bool alive = p_raw < a.N;
-  const int64_t p = alive ? p_raw : a.N - 1;
+  const int lane = threadIdx.x & 63;
+  const int ppw = 64 >> a.logG;
+  const int64_t nslots = (a.N + ppw - 1) >> (6 - a.logG);
+  const int64_t W = (int64_t)gridDim.x * 4;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gi = lane >> a.logG;
   LaneMap m;
-  m.j = (int)(tid & (G - 1));
+  m.j = lane & (G - 1);
   m.G = G;
   m.D = a.D;
   m.CH = a.CH;
-  m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
-
-  T x0[E], v0[E];
-  load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, x0);
-  load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v0);
-  const T EX0 = a.EX_in[p];
-  const T EV0 = a.EV_in[p];
-  const T H0 = EX0 + EV0;  // HMCState.H (hmc_state.py:80-84)
-  const bool warm = a.cache_in[p] != 0;
+  m.lane0 = lane & ~(G - 1);
   const auto lc = en.template local<E>(m);
+  unsigned nL = 0, nF = 0, nR = 0, nCold = 0;  // per-lane tallies (group leaders only)
+  using Vec = typename VecOf<T>::type;
+  constexpr int C = E / VecOf<T>::n;
+  __shared__ Vec stash[4][2][C][64];
+  Vec(*stash_x)[64] = stash[threadIdx.x >> 6][0];
+  Vec(*stash_v)[64] = stash[threadIdx.x >> 6][1];
 
-  // inverse-L proposal F L F; only H() of it is ever read (markov_jump_hmc.py:360,367)
-  T Hflf;
-  if (warm) {
-    Hflf = a.Hflf_in[p];
-  } else {
+  auto particle_of = [&](int64_t slot) -> int64_t {
+    const int64_t pr = slot * ppw + gi;
+    return pr < a.N ? pr : a.N - 1;
+  };
+  T nx[E], nv[E];
+  SlotScalars<T> ns;
+  auto fetch = [&](int64_t slot) {
+    const int64_t p = particle_of(slot);
+    ns.EX = a.EX_in[p];  // scalars first: they are the oldest loads, so waiting for them later
+    ns.EV = a.EV_in[p];  // never waits for the rows behind them
+    ns.Hflf = a.Hflf_in[p];
+    load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, nx);
+    load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, nv);
+  };
+  if (wave < nslots) fetch(wave);
+
+  for (int64_t slot = wave; slot < nslots; slot += W) {
+    const int64_t p_raw = slot * ppw + gi;
+    const bool alive = p_raw < a.N;
+    const int64_t p = alive ? p_raw : a.N - 1;
+    // The slot's pre-move state (x0, v0) is parked in this wave's private LDS stripe (lane-linear
+    // 16-byte chunks: conflict-free ds_write_b128 / ds_read_b128, no barrier -- every lane reads
+    // back only what it wrote).  Registers then hold just the working trajectory and the
+    // prefetched next slot, which is what lets 4 waves/SIMD stay resident.
     T x[E], v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      x[e] = x0[e];
-      v[e] = -v0[e];
+      x[e] = nx[e];
+      v[e] = nv[e];
     }
+    stash_put<T, E>(stash_x, lane, x);
+    stash_put<T, E>(stash_v, lane, v);
+    T EX0 = ns.EX, EV0 = ns.EV, Hcached = ns.Hflf;
+    use_here(EX0);
+    use_here(EV0);
+    use_here(Hcached);
+    const bool warm = Hcached == Hcached;  // cache_active (hmc_state.py:43-44) is carried as "H_flf is not NaN"
+    if (slot + W < nslots) fetch(slot + W);  // prefetch: in flight during everything below
+    const T H0 = EX0 + EV0;  // HMCState.H (hmc_state.py:80-84)
+
+    // inverse-L proposal F L F; only H() of it is ever read (markov_jump_hmc.py:360,367)
+    T Hflf;
+    if (warm) {
+      Hflf = Hcached;
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = -v[e];
+      trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+      const T ev = kinetic<T, E>(v, m);
+      const T ex = en.energy(x, m, lc);
+      Hflf = ex + ev;
+      stash_get<T, E>(stash_x, lane, x);
+      stash_get<T, E>(stash_v, lane, v);
+    }
+
+    // forward proposal L
     trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
-    const T ev = kinetic<T, E>(v, m);
-    const T ex = en.energy(x, m, lc);
-    Hflf = ex + ev;
-  }
+    const T EVL = kinetic<T, E>(v, m);
+    const T EXL = en.energy(x, m, lc);
+    const T HL = EXL + EVL;
 
-  // forward proposal L
-  T x[E], v[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    x[e] = x0[e];
-    v[e] = v0[e];
-  }
-  trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
-  const T EVL = kinetic<T, E>(v, m);
-  const T EXL = en.energy(x, m, lc);
-  const T HL = EXL + EVL;
+    // rates: exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347, 366-369).
+    // The sched_barriers keep hipcc from interleaving the five independent fp64 transcendental
+    // expansions (2 exp, 3 log): interleaved they need ~90 extra VGPRs for polynomial
+    // coefficients and would halve the kernel's occupancy; serialised they cost nothing measurable.
+    const double l_rate = sqrt(exp((double)(H0 - HL)));
+    __builtin_amdgcn_sched_barrier(0);
+    const double flf_rate = sqrt(exp((double)(H0 - Hflf)));
+    __builtin_amdgcn_sched_barrier(0);
+    const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
+    const double f_rate = flf_rate - mn;
+    const double r_rate = a.p_r;
 
-  // rates: exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347, 366-369)
-  const double l_rate = sqrt(exp((double)(H0 - HL)));
-  const double flf_rate = sqrt(exp((double)(H0 - Hflf)));
-  const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
-  const double f_rate = flf_rate - mn;
-  const double r_rate = a.p_r;
-
-  // unit exponentials
-  double eL, eF, eR;
-  const uint32_t pid = (uint32_t)(a.first_pid + p);
-  if (a.rexp) {
-    eL = a.rexp[p];
-    eF = a.rexp[a.N + p];
-    eR = a.rexp[2 * a.N + p];
-  } else {
-    const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
-    const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
-    eL = -log(u53(w.w0, w.w1));
-    eF = -log(u53(w.w2, w.w3));
-    eR = -log(u53(q.w0, q.w1));
-  }
-  bool bad = false;
-  const double dL = wait_time(l_rate, eL, bad);
-  const double dF = wait_time(f_rate, eF, bad);
-  const double dR = wait_time(r_rate, eR, bad);
-  if (bad && alive) {
-    a.ctl->failed = 1;
-    a.ctl->failed_iter = a.iter;
-  }
-  const int k = first_min3(dL, dF, dR);
-  const double dwell = (k == 0) ? dL : (k == 1 ? dF : dR);
-
-  // successor state (markov_jump_hmc.py:399-410)
-  T EXn, EVn, Hc;
-  uint8_t cn;
-  if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
-    EXn = EXL;
-    EVn = EVL;
-    Hc = H0;
-    cn = 1;
-  } else if (k == 1) {  // F: flip the momentum
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      x[e] = x0[e];
-      v[e] = -v0[e];
+    // unit exponentials
+    double eL, eF, eR;
+    const uint32_t pid = (uint32_t)(a.first_pid + p);
+    if constexpr (REPLAY) {
+      eL = a.rexp[p];
+      eF = a.rexp[a.N + p];
+      eR = a.rexp[2 * a.N + p];
+    } else {
+      const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      __builtin_amdgcn_sched_barrier(0);
+      eL = -log(u53(w.w0, w.w1));
+      __builtin_amdgcn_sched_barrier(0);
+      eF = -log(u53(w.w2, w.w3));
+      __builtin_amdgcn_sched_barrier(0);
+      eR = -log(u53(q.w0, q.w1));
+      __builtin_amdgcn_sched_barrier(0);
     }
-    EXn = EX0;
-    EVn = EV0;
-    Hc = Hflf;
-    cn = 0;
-  } else {  // R: refresh the momentum (hmc_state.py:121-129)
-    T z[E];
-    refresh_noise<T, E>(a.noise ? a.noise + (size_t)p * a.pitch : nullptr, a.key, pid, m, z);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      x[e] = x0[e];
-      v[e] = v0[e] * a.r_keep + z[e] * a.r_mix;
+    bool bad = false;
+    const double dL = wait_time(l_rate, eL, bad);
+    __builtin_amdgcn_sched_barrier(0);
+    const double dF = wait_time(f_rate, eF, bad);
+    __builtin_amdgcn_sched_barrier(0);
+    const double dR = wait_time(r_rate, eR, bad);
+    __builtin_amdgcn_sched_barrier(0);
+    if (bad && alive) {
+      a.ctl->failed = 1;
+      a.ctl->failed_iter = a.iter;
     }
-    EXn = EX0;
-    EVn = kinetic<T, E>(v, m);
-    Hc = Hflf;
-    cn = 0;
+    const int k = first_min3(dL, dF, dR);
+    const double dwell = (k == 0) ? dL : (k == 1 ? dF : dR);
+
+    // successor state (markov_jump_hmc.py:399-410)
+    T EXn, EVn, Hc;
+    if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
+      EXn = EXL;
+      EVn = EVL;
+      Hc = H0;
+    } else if (k == 1) {  // F: flip the momentum
+      stash_get<T, E>(stash_x, lane, x);
+      stash_get<T, E>(stash_v, lane, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = -v[e];
+      EXn = EX0;
+      EVn = EV0;
+      Hc = (T)__builtin_nan("");  // clear_flf_cache (markov_jump_hmc.py:409-410)
+    } else {  // R: refresh the momentum (hmc_state.py:121-129)
+      stash_get<T, E>(stash_x, lane, x);
+      refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)p * a.pitch, a.key, pid, m, a.r_keep, a.r_mix);
+      stash_get<T, E>(stash_v, lane, v);
+      EXn = EX0;
+      EVn = kinetic<T, E>(v, m);
+      Hc = (T)__builtin_nan("");
+    }
+    if (alive) {
+      store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
+      store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+      if (m.j == 0) {
+        a.EX_out[p] = EXn;
+        a.EV_out[p] = EVn;
+        a.Hflf_out[p] = Hc;
+        a.dwell[p] = dwell;
+        if (a.dwell_ring) a.dwell_ring[p] = dwell;
+        a.trans[p] = (uint8_t)k;
+        nL += (k == 0);
+        nF += (k == 1);
+        nR += (k == 2);
+        nCold += warm ? 0u : 1u;
+      }
+    }
   }
-  if (!alive) return;
-  store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
-  store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
-  if (m.j == 0) {
-    a.EX_out[p] = EXn;
-    a.EV_out[p] = EVn;
-    a.Hflf_out[p] = Hc;
-    a.cache_out[p] = cn;
-    a.dwell[p] = dwell;
-    if (a.dwell_ring) a.dwell_ring[p] = dwell;
-    a.trans[p] = (uint8_t)k;
+
+  // integer bookkeeping: l/f/r counts and the number of cold inverse-L caches of this attempt
+  // (markov_jump_hmc.py:413-415; Distribution.E_count / dEdX_count, distributions.py:62-75)
+  __shared__ unsigned tally[4][4];
+  for (int o = 32; o > 0; o >>= 1) {
+    nL += __shfl_xor(nL, o);
+    nF += __shfl_xor(nF, o);
+    nR += __shfl_xor(nR, o);
+    nCold += __shfl_xor(nCold, o);
+  }
+  if (lane == 0) {
+    const int w = threadIdx.x >> 6;
+    tally[w][0] = nL;
+    tally[w][1] = nF;
+    tally[w][2] = nR;
+    tally[w][3] = nCold;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long t =
+        (unsigned long long)tally[0][threadIdx.x] + tally[1][threadIdx.x] + tally[2][threadIdx.x] + tally[3][threadIdx.x];
+    if (t) atomicAdd(&a.stats[threadIdx.x], t);
   }
 }
 
@@ -680,11 +833,30 @@ struct EnergyParams {
   const void* dev_f32;
 };
 
+// Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
+// (occupancy query, cached per instantiation), never more than there are slots to hand out.
+template <class En, typename T, int E, bool REPLAY>
+inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
+  static int resident_blocks = 0;
+  if (resident_blocks == 0) {
+    int dev = 0, per_cu = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, REPLAY>, 256, 0);
+    resident_blocks = std::max(1, per_cu) * std::max(1, cus);
+  }
+  const int ppw = 64 >> a.logG;
+  const int64_t nslots = (a.N + ppw - 1) / ppw;
+  const int64_t want = (nslots + 3) / 4;
+  const unsigned grid = (unsigned)std::min<int64_t>(want, resident_blocks);
+  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, REPLAY>), dim3(grid), dim3(256), 0, st, a, en);
+}
+
+// replay needs BOTH recorded streams (normals and unit exponentials)
 template <class En, typename T, int E>
 inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
-  const int64_t threads = a.N << a.logG;
-  const unsigned grid = (unsigned)((threads + 255) / 256);
-  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E>), dim3(grid), dim3(256), 0, st, a, en);
+  if (a.rexp && a.noise) launch_jump_r<En, T, E, true>(a, en, st);
+  else launch_jump_r<En, T, E, false>(a, en, st);
 }
 
 template <class En, typename T, int E>

@@ -52,9 +52,8 @@ __device__ inline void normal_pair(const RngKey& k, uint32_t pid, uint32_t pair,
   const double u1 = u53(w.w0, w.w1);
   const double u2 = u53(w.w2, w.w3);
   const double r = sqrt(-2.0 * log(u1));
-  const double ang = 2.0 * 3.141592653589793 * u2;
   double s, c;
-  sincos(ang, &s, &c);
+  sincospi(2.0 * u2, &s, &c);  // angle 2*pi*u2; the pi-scaled form needs no Payne-Hanek reduction
   z0 = r * c;
   z1 = r * s;
 }

@@ -131,8 +131,8 @@ class DeviceSampler(object):
         return out
 
     def write(self, field, arr):
-        if field == _lib.F_CACHE:
-            a = np.ascontiguousarray(arr, dtype=np.uint8)
+        if field == _lib.F_HFLF:
+            a = as_f64(np.asarray(arr, dtype=np.float64).reshape(-1), (self.nparticles,))
         else:
             a = as_f64(arr, (self.ndims, self.nparticles))
         check(self.lib.mjhmc_write(self.handle, int(field), ptr(a), a.nbytes))

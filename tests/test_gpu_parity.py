@@ -139,10 +139,12 @@ def test_g4_g6_sampling_iteration_replay(name, capsys):
         if str(g['kind']) in ('rough', 'mm'):
             # transcendental forces: ulp-level differences in sin/exp grow chaotically over many
             # iterations, so every iteration starts from the reference's state (per-iteration parity
-            # from identical inputs).  Writing X/V clears the cache flags; put them back.
+            # from identical inputs).  Writing X/V clears the FLF cache; put it back.
+            hflf = s._dev.read(5)
+            assert np.array_equal(~np.isnan(hflf), g['cache'][t])
             s._dev.write(0, g['X'][t])
             s._dev.write(1, g['V'][t])
-            s._dev.write(6, g['cache'][t].astype(np.uint8))
+            s._dev.write(5, hflf)
     if name.startswith('g6'):
         assert 'doubling back' in capsys.readouterr().out
 
@@ -174,7 +176,7 @@ def test_g5_sample_with_resampling(monkeypatch):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('kind,D,N,eps,L,beta', [('iso', 2, 100, 0.3, 5, 0.3), ('iso', 512, 96, 0.05, 10, 0.1),
                                                  ('diag', 33, 70, 0.5, 4, 0.4), ('funnel', 32, 300, 0.05, 15, 0.1),
-                                                 ('rough', 7, 130, 2.0, 6, 0.2), ('mm', 3, 64, 0.3, 6, 0.4)])
+                                                 ('rough', 7, 130, 0.5, 6, 0.2), ('mm', 3, 64, 0.3, 6, 0.4)])
 def test_philox_mode_matches_oracle(kind, D, N, eps, L, beta):
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
     from mjhmc_amd.misc import distributions as Dm
