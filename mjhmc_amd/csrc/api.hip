@@ -63,7 +63,7 @@ static const int kMaxTimed = 256;
 struct mjhmc_sampler {
   mjhmc_ctx* ctx;
   mjhmc_energy* en;
-  int64_t N, first_pid;
+  int64_t N, Npad, first_pid;  // Npad: rows allocated (N rounded up to 64; padding rows stay zero)
   int D, dtype, mode;
   Shape sh;
   hipStream_t stream = nullptr;
@@ -75,6 +75,7 @@ struct mjhmc_sampler {
   void* EV[2] = {nullptr, nullptr};
   void* Hflf[2] = {nullptr, nullptr};
   double* dwell = nullptr;
+  double* dwell_scratch = nullptr;  // dwell_ring target when no ring slot is recorded
   uint8_t* trans = nullptr;
   Control* ctl = nullptr;
   long long* stats = nullptr;  // [stats_cap][4]
@@ -98,7 +99,7 @@ struct mjhmc_sampler {
 };
 
 static size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s->sh.esize; }
-static size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->N * row_bytes(s); }
+static size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_bytes(s); }
 
 static int pow2ceil(int v) {
   int p = 1;
@@ -463,7 +464,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void* ptrs[] = {s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
-                  s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->trans,
+                  s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch};
   for (void* p : ptrs)
@@ -489,6 +490,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   s->ctx = ctx;
   s->en = e;
   s->N = nparticles;
+  s->Npad = (nparticles + 63) / 64 * 64;
   s->first_pid = first_particle_id;
   s->D = e->ep.ndims;
   s->dtype = dtype;
@@ -507,15 +509,18 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       HIPCHK(hipMalloc(&s->Vbuf[i], mb));
       HIPCHK(hipMemsetAsync(s->Xbuf[i], 0, mb, s->stream));
       HIPCHK(hipMemsetAsync(s->Vbuf[i], 0, mb, s->stream));
-      HIPCHK(hipMalloc(&s->EX[i], s->N * s->sh.esize));
-      HIPCHK(hipMalloc(&s->EV[i], s->N * s->sh.esize));
-      HIPCHK(hipMalloc(&s->Hflf[i], s->N * s->sh.esize));
-      HIPCHK(hipMemsetAsync(s->Hflf[i], 0xFF, s->N * s->sh.esize, s->stream));  // all-ones = NaN = cold
+      HIPCHK(hipMalloc(&s->EX[i], s->Npad * s->sh.esize));
+      HIPCHK(hipMalloc(&s->EV[i], s->Npad * s->sh.esize));
+      HIPCHK(hipMalloc(&s->Hflf[i], s->Npad * s->sh.esize));
+      HIPCHK(hipMemsetAsync(s->EX[i], 0, s->Npad * s->sh.esize, s->stream));
+      HIPCHK(hipMemsetAsync(s->EV[i], 0, s->Npad * s->sh.esize, s->stream));
+      HIPCHK(hipMemsetAsync(s->Hflf[i], 0xFF, s->Npad * s->sh.esize, s->stream));  // all-ones = NaN = cold
     }
-    HIPCHK(hipMalloc((void**)&s->dwell, s->N * sizeof(double)));
-    HIPCHK(hipMemsetAsync(s->dwell, 0, s->N * sizeof(double), s->stream));
-    HIPCHK(hipMalloc((void**)&s->trans, s->N));
-    HIPCHK(hipMemsetAsync(s->trans, 0, s->N, s->stream));
+    HIPCHK(hipMalloc((void**)&s->dwell, s->Npad * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->dwell, 0, s->Npad * sizeof(double), s->stream));
+    HIPCHK(hipMalloc((void**)&s->dwell_scratch, s->Npad * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&s->trans, s->Npad));
+    HIPCHK(hipMemsetAsync(s->trans, 0, s->Npad, s->stream));
     HIPCHK(hipMalloc((void**)&s->ctl, sizeof(Control)));
     HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
     HIPCHK(hipEventCreate(&s->ev_total[0]));
@@ -557,7 +562,7 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
 int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
-  HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->N * s->sh.esize, s->stream));
+  HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * s->sh.esize, s->stream));
   return 0;
 }
 
@@ -592,10 +597,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i = 0; i < n_iter; ++i) {
     void* xo;
-    double* dring = nullptr;
+    double* dring = s->dwell_scratch;
     if (ring_slot0 >= 0) {
       xo = (char*)s->ring + (size_t)(ring_slot0 + i) * mb;
-      dring = s->dwell_ring + (size_t)(ring_slot0 + i) * s->N;
+      dring = s->dwell_ring + (size_t)(ring_slot0 + i) * s->Npad;
       if (xo == xin) {  // the live state sits in the slot about to be overwritten: move it out first
         void* spare = s->Xbuf[0];
         HIPCHK(hipMemcpyAsync(spare, xin, mb, hipMemcpyDeviceToDevice, s->stream));
@@ -627,10 +632,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.trans = s->trans;
     a.noise = replay_normal ? (const T*)s->noise : nullptr;
     a.rexp = replay_exp ? s->rexp : nullptr;
-    a.runif = nullptr;
     a.ctl = s->ctl;
     a.stats = (unsigned long long*)(s->stats + 4 * i);
     a.N = s->N;
+    a.Npad = s->Npad;
     a.first_pid = s->first_pid;
     a.D = s->D;
     a.pitch = s->sh.pitch;
@@ -789,7 +794,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       TRY(upload_matrix(s, (const double*)host_src, dst));
       TRY(run_eval(s, s->Xcur, nullptr, s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
-      HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->N * s->sh.esize, s->stream));
+      HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * s->sh.esize, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
     }
@@ -829,7 +834,7 @@ int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots) {
   s->ring_slots = 0;
   HIPCHK(hipMalloc(&s->ring, (size_t)n_slots * mb));
   HIPCHK(hipMemset(s->ring, 0, (size_t)n_slots * mb));
-  HIPCHK(hipMalloc((void**)&s->dwell_ring, (size_t)n_slots * s->N * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&s->dwell_ring, (size_t)n_slots * s->Npad * sizeof(double)));
   s->ring_slots = n_slots;
   return 0;
 }
@@ -838,8 +843,9 @@ int mjhmc_ring_read_dwell(mjhmc_sampler* s, int slot0, int n, double* host_dst) 
   if (!s || !host_dst) return fail(MJHMC_ERR_INVALID, "NULL argument");
   if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return fail(MJHMC_ERR_INVALID, "slots out of range");
   HIPCHK(hipSetDevice(s->ctx->device));
-  HIPCHK(hipMemcpyAsync(host_dst, s->dwell_ring + (size_t)slot0 * s->N, (size_t)n * s->N * sizeof(double),
-                        hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpy2DAsync(host_dst, (size_t)s->N * sizeof(double), s->dwell_ring + (size_t)slot0 * s->Npad,
+                          (size_t)s->Npad * sizeof(double), (size_t)s->N * sizeof(double), (size_t)n,
+                          hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return 0;
 }
@@ -850,11 +856,13 @@ int mjhmc_ring_gather(mjhmc_sampler* s, const int64_t* idx, int64_t n, double* h
   const int64_t pool = (int64_t)s->ring_slots * s->N;
   for (int64_t k = 0; k < n; ++k)
     if (idx[k] < 0 || idx[k] >= pool) return fail(MJHMC_ERR_INVALID, "gather index outside the sample ring");
+  std::vector<int64_t> rows((size_t)n);  // pool index (slot * N + p) -> padded row (slot * Npad + p)
+  for (int64_t k = 0; k < n; ++k) rows[k] = (idx[k] / s->N) * s->Npad + idx[k] % s->N;
   int64_t* didx = nullptr;
   HIPCHK(hipMalloc((void**)&didx, n * sizeof(int64_t)));
   int rc = 0;
   do {
-    if (hipMemcpyAsync(didx, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream) != hipSuccess) {
+    if (hipMemcpyAsync(didx, rows.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream) != hipSuccess) {
       rc = fail(MJHMC_ERR_HIP, "index upload failed");
       break;
     }
@@ -875,7 +883,9 @@ int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* hos
   const size_t mb = mat_bytes(s);
   const char* base = (const char*)s->ring + (size_t)slot0 * mb;
   if (!stacked) {
-    TRY(download_cols(s, base, nullptr, (int64_t)n * s->N, host_out, total, (int64_t)n * s->N, 1, 0, true));
+    for (int k = 0; k < n; ++k)
+      TRY(download_cols(s, base + (size_t)k * mb, nullptr, s->N, host_out, total, (int64_t)n * s->N, 1,
+                        (int64_t)k * s->N, k == n - 1));
   } else {
     for (int k = 0; k < n; ++k)
       TRY(download_cols(s, base + (size_t)k * mb, nullptr, s->N, host_out, total, (int64_t)s->N * n, n, k, k == n - 1));
@@ -907,6 +917,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   w.ctx = e->ctx;
   w.en = e;
   w.N = n;
+  w.Npad = (n + 63) / 64 * 64;
   w.first_pid = 0;
   w.D = e->ep.ndims;
   w.dtype = dtype;

