@@ -26,6 +26,10 @@
 
 #include "philox.hpp"
 
+#ifndef MJHMC_NT
+#define MJHMC_NT 1  // streaming (nontemporal) row loads/stores: +1-2 % on C2, state rows are touched once per launch
+#endif
+
 namespace mjhmc {
 
 struct Control {
@@ -620,7 +624,16 @@ __device__ __forceinline__ void slot_load(const char* base, uint32_t lane_off, u
   for (int c = 0; c < E / VEC; ++c) {
     V v;
     if (FULLROW || c * m.G + m.j < m.CH) {
+#if MJHMC_NT
+      {
+        using NV = T __attribute__((ext_vector_type(VecOf<T>::n)));
+        const NV q = __builtin_nontemporal_load(reinterpret_cast<const NV*>(base + lane_off + c * chunk_stride));
+        if constexpr (VEC == 2) v = V{q[0], q[1]};
+        else v = V{q[0], q[1], q[2], q[3]};
+      }
+#else
       v = *reinterpret_cast<const V*>(base + lane_off + c * chunk_stride);
+#endif
     } else {
       if constexpr (VEC == 2) v = V{0, 0};
       else v = V{0, 0, 0, 0};
@@ -648,7 +661,17 @@ __device__ __forceinline__ void slot_store(char* base, uint32_t lane_off, uint32
       V v;
       if constexpr (VEC == 2) v = V{r[c * 2], r[c * 2 + 1]};
       else v = V{r[c * 4], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
+#if MJHMC_NT
+      {
+        using NV = T __attribute__((ext_vector_type(VecOf<T>::n)));
+        NV q;
+        if constexpr (VEC == 2) q = NV{v.x, v.y};
+        else q = NV{v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(q, reinterpret_cast<NV*>(base + lane_off + c * chunk_stride));
+      }
+#else
       *reinterpret_cast<V*>(base + lane_off + c * chunk_stride) = v;
+#endif
     }
   }
 }
