@@ -482,7 +482,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   if (!ctx || !e || !out || !Xinit) return fail(MJHMC_ERR_INVALID, "NULL argument");
   if (nparticles < 1) return fail(MJHMC_ERR_INVALID, "nparticles must be >= 1");
   if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
-  if (mode != MJHMC_MODE_MJHMC) return fail(MJHMC_ERR_UNSUPPORTED, "only MJHMC mode is built so far");
+  if (mode < MJHMC_MODE_MJHMC || mode > MJHMC_MODE_CTHMC) return fail(MJHMC_ERR_INVALID, "unknown sampler mode");
   if (first_particle_id < 0 || first_particle_id + nparticles > 0xFFFFFFFFLL)
     return fail(MJHMC_ERR_INVALID, "global particle ids must fit 32 bits");
   HIPCHK(hipSetDevice(ctx->device));
@@ -583,6 +583,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     HIPCHK(hipMemsetAsync(s->noise, 0, mb, s->stream));
   }
   if (replay_exp && !s->rexp) HIPCHK(hipMalloc((void**)&s->rexp, 3 * s->N * sizeof(double)));
+  if (replay_unif && !s->runif) HIPCHK(hipMalloc((void**)&s->runif, (2 * s->N + 1) * sizeof(double)));
   const int n_timed = std::min(n_iter, kMaxTimed);
   while ((int)s->ev_k.size() < 2 * n_timed) {
     hipEvent_t e;
@@ -616,6 +617,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     if (replay_exp)
       HIPCHK(hipMemcpyAsync(s->rexp, replay_exp + (size_t)i * 3 * s->N, 3 * s->N * sizeof(double),
                             hipMemcpyHostToDevice, s->stream));
+    if (replay_unif)
+      HIPCHK(hipMemcpyAsync(s->runif, replay_unif + (size_t)i * (2 * s->N + 1), (2 * s->N + 1) * sizeof(double),
+                            hipMemcpyHostToDevice, s->stream));
     JumpArgs<T> a;
     a.X_in = (const T*)xin;
     a.V_in = (const T*)s->Vbuf[vi];
@@ -632,6 +636,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.trans = s->trans;
     a.noise = replay_normal ? (const T*)s->noise : nullptr;
     a.rexp = replay_exp ? s->rexp : nullptr;
+    a.runif = replay_unif ? s->runif : nullptr;
+    a.mode = s->mode;
     a.ctl = s->ctl;
     a.stats = (unsigned long long*)(s->stats + 4 * i);
     a.N = s->N;
@@ -671,11 +677,22 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     for (int i = 0; i < attempts; ++i) {
       mjhmc_iter_stats& st = per_iter[i];
       std::memset(&st, 0, sizeof(st));
-      st.l = hs[4 * i + 0];
-      st.f = hs[4 * i + 1];
-      st.r = hs[4 * i + 2];
-      st.n_cold = hs[4 * i + 3];
-      st.E_evals = s->N + st.n_cold;                          // L on all + FLF on the cold ones
+      if (s->mode == MJHMC_MODE_MJHMC) {
+        st.l = hs[4 * i + 0];
+        st.f = hs[4 * i + 1];
+        st.r = hs[4 * i + 2];
+        st.n_cold = hs[4 * i + 3];
+      } else if (s->mode == MJHMC_MODE_CTHMC) {  // clocks FL, F, R (markov_jump_hmc.py:288-290)
+        st.fl = hs[4 * i + 0];
+        st.f = hs[4 * i + 1];
+        st.r = hs[4 * i + 2];
+      } else {  // markov_jump_hmc.py:138-148
+        st.l = hs[4 * i + 0];
+        st.f = hs[4 * i + 1];
+        st.r = hs[4 * i + 2];
+        st.fl = hs[4 * i + 3];
+      }
+      st.E_evals = s->N + st.n_cold;                          // L on all (+ FLF on the cold ones)
       st.dEdX_evals = (int64_t)s->L * (s->N + st.n_cold);
       st.nonfinite = (hc.failed && i == done) ? 1 : 0;
       st.L_used = s->L;
@@ -708,8 +725,12 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
                   const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   if (n_iter < 1) return fail(MJHMC_ERR_INVALID, "n_iter must be >= 1");
-  if ((replay_normal == nullptr) != (replay_exp == nullptr))
-    return fail(MJHMC_ERR_INVALID, "replay_normal and replay_exp must be given together");
+  if (s->mode == MJHMC_MODE_CONTROL) {
+    if ((replay_normal == nullptr) != (replay_unif == nullptr) || replay_exp)
+      return fail(MJHMC_ERR_INVALID, "CONTROL replay takes replay_normal and replay_unif together");
+  } else if ((replay_normal == nullptr) != (replay_exp == nullptr) || replay_unif) {
+    return fail(MJHMC_ERR_INVALID, "jump-process replay takes replay_normal and replay_exp together");
+  }
   if (ring_slot0 >= 0 && (!s->ring || ring_slot0 + n_iter > s->ring_slots))
     return fail(MJHMC_ERR_INVALID, "ring slots out of range (call mjhmc_ring_alloc)");
   HIPCHK(hipSetDevice(s->ctx->device));

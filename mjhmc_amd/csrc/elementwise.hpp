@@ -32,6 +32,10 @@
 
 namespace mjhmc {
 
+constexpr int kModeMJHMC = 0;    // MarkovJumpHMC.sampling_iteration      (markov_jump_hmc.py:355-415)
+constexpr int kModeControl = 1;  // HMCBase / HMC / ControlHMC            (markov_jump_hmc.py:116-148)
+constexpr int kModeCT = 2;       // ContinuousTimeHMC.sampling_iteration  (markov_jump_hmc.py:251-290)
+
 struct Control {
   int failed;       // some attempt hit a non-finite rate
   int failed_iter;  // index (within the current mjhmc_iterate call) of that attempt
@@ -366,6 +370,7 @@ struct JumpArgs {
   uint8_t* trans;       // [N]
   const T* noise;       // replay normals, particle-major [N][pitch], or nullptr
   const double* rexp;   // replay unit exponentials [3][N], or nullptr
+  const double* runif;  // replay uniforms of the discrete-time samplers [2N+1] (accept, flip, R gate)
   Control* ctl;
   unsigned long long* stats;  // [4]: #L, #F, #R, #cold of this attempt
   int64_t N;
@@ -374,6 +379,7 @@ struct JumpArgs {
   int D, pitch, CH, logG;
   int L;
   int iter;             // index of this attempt inside the current mjhmc_iterate call
+  int mode;             // kModeMJHMC / kModeControl / kModeCT
   T eps, chalf;         // epsilon and -epsilon/2 (hmc_state.py:88-91)
   T r_keep, r_mix;      // sqrt(1-beta), sqrt(beta) of HMCState.R (hmc_state.py:125-126)
   double p_r, p_flip;
@@ -750,11 +756,71 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T
   dwell = (k == 0) ? dL : (k == 1 ? dF : dR);
 }
 
+// ContinuousTimeHMC (markov_jump_hmc.py:251-290): clocks FL (rate sqrt(exp(H0 - H_fl))), F (rate 1),
+// R (rate p_r); min_idx is called with [f, fl, r], so ties go F, FL, R.  Returns k: 0 = FL, 1 = F, 2 = R.
+template <typename T, bool REPLAY>
+__device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const LaneMap& m, T H0, T HL, int64_t p, uint32_t pid,
+                                          int& k, double& dwell, bool& bad) {
+  const double fl_rate = sqrt(exp((double)(H0 - HL)));
+  const double r_rate = a.p_r;
+  double dFL, dF, dR;
+  if (m.G >= 4) {
+    const int role = m.j;  // 0: FL clock, 1: R clock, 2..: F clock
+    double e;
+    if constexpr (REPLAY) {
+      const int row = (role == 0) ? 0 : (role == 1 ? 2 : 1);
+      e = a.rexp[(size_t)row * a.N + p];
+    } else {
+      const u32x4 w =
+          philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, a.key.k0, a.key.k1);
+      const double uA = u53(w.w0, w.w1);
+      const double uF = group_lane(u53(w.w2, w.w3), m, 0);
+      e = -log(role >= 2 ? uF : uA);
+    }
+    const double rate = (role == 0) ? fl_rate : (role == 1 ? r_rate : 1.0);
+    bool ignore = false;
+    const double d = wait_time(rate, e, ignore);
+    dFL = group_lane(d, m, 0);
+    dR = group_lane(d, m, 1);
+    dF = group_lane(d, m, 2);
+  } else {
+    double eFL, eF, eR;
+    if constexpr (REPLAY) {
+      eFL = a.rexp[p];
+      eF = a.rexp[a.N + p];
+      eR = a.rexp[2 * a.N + p];
+    } else {
+      const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      __builtin_amdgcn_sched_barrier(0);
+      eFL = -log(u53(w.w0, w.w1));
+      __builtin_amdgcn_sched_barrier(0);
+      eF = -log(u53(w.w2, w.w3));
+      __builtin_amdgcn_sched_barrier(0);
+      eR = -log(u53(q.w0, q.w1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bool ignore = false;
+    dFL = wait_time(fl_rate, eFL, ignore);
+    __builtin_amdgcn_sched_barrier(0);
+    dF = wait_time(1.0, eF, ignore);
+    __builtin_amdgcn_sched_barrier(0);
+    dR = wait_time(r_rate, eR, ignore);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bad = !(isfinite(fl_rate) && isfinite(r_rate));
+  const int kk = first_min3(dF, dFL, dR);  // rows f, fl, r (markov_jump_hmc.py:271)
+  k = (kk == 0) ? 1 : (kk == 1 ? 0 : 2);
+  dwell = (kk == 0) ? dF : (kk == 1 ? dFL : dR);
+}
+
 // REPLAY = true: random numbers come from host-supplied arrays (parity tests against recorded
 // reference runs).  It is a compile-time switch because any global load consumed inside the slot
 // body forces an in-order vmcnt wait that would also drain the prefetch of the next slot.
 // FULLROW = true: every lane's chunks are inside the row (pitch == G * E), no per-chunk predicates.
-template <class En, typename T, int E, bool REPLAY, bool FULLROW>
+// MODE: which sampler family's iteration this is (kModeMJHMC / kModeControl / kModeCT).
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW>
 __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
@@ -824,10 +890,8 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     const T H0 = EX0 + EV0;  // HMCState.H (hmc_state.py:80-84)
 
     // inverse-L proposal F L F; only H() of it is ever read (markov_jump_hmc.py:360,367)
-    T Hflf;
-    if (warm) {
-      Hflf = Hcached;
-    } else {
+    T Hflf = Hcached;
+    if (MODE == kModeMJHMC && !warm) {
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = -v[e];
       trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
@@ -845,35 +909,108 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     const T HL = EXL + EVL;
 
     int k;
-    double dwell;
-    bool bad;
+    double dwell = 0.0;
+    bool bad = false;
     const uint32_t pid = (uint32_t)(a.first_pid + p);
-    decide<T, REPLAY>(a, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
+    T EXn, EVn, Hc = (T)__builtin_nan("");
+    bool tally_cold = false, r_applied = false;
+    if constexpr (MODE == kModeMJHMC) {
+      decide<T, REPLAY>(a, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
+      tally_cold = !warm;
+      // successor state (markov_jump_hmc.py:399-410)
+      if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
+        EXn = EXL;
+        EVn = EVL;
+        Hc = H0;
+      } else if (k == 1) {  // F: flip the momentum; clear_flf_cache (:409-410)
+        stash_get<T, E>(stash_x, lane, x);
+        stash_get<T, E>(stash_v, lane, v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = -v[e];
+        EXn = EX0;
+        EVn = EV0;
+      } else {  // R: refresh the momentum (hmc_state.py:121-129)
+        stash_get<T, E>(stash_x, lane, x);
+        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m,
+                                    a.r_keep, a.r_mix);
+        stash_get<T, E>(stash_v, lane, v);
+        EXn = EX0;
+        EVn = kinetic<T, E>(v, m);
+      }
+    } else if constexpr (MODE == kModeCT) {
+      decide_ct<T, REPLAY>(a, m, H0, HL, alive ? p : 0, pid, k, dwell, bad);
+      if (k == 0) {  // FL: leap, then flip (markov_jump_hmc.py:258,278)
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = -v[e];
+        EXn = EXL;
+        EVn = EVL;
+      } else if (k == 1) {  // F
+        stash_get<T, E>(stash_x, lane, x);
+        stash_get<T, E>(stash_v, lane, v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = -v[e];
+        EXn = EX0;
+        EVn = EV0;
+      } else {  // R (:285-286)
+        stash_get<T, E>(stash_x, lane, x);
+        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m,
+                                    a.r_keep, a.r_mix);
+        stash_get<T, E>(stash_v, lane, v);
+        EXn = EX0;
+        EVn = kinetic<T, E>(v, m);
+      }
+    } else {
+      // Discrete-time control samplers (markov_jump_hmc.py:116-148): propose L then F, accept with
+      // min(1, exp(H0 - H1)) (a NaN difference accepts, as `Ediff < 0` is False, :112-113), flip with
+      // probability p_flip, then refresh EVERY particle's momentum when the batch-wide gate fires.
+      double uacc, uflip, ugate;
+      if constexpr (REPLAY) {
+        const int64_t pp = alive ? p : 0;
+        uacc = a.runif[pp];
+        uflip = a.runif[a.N + pp];
+        ugate = a.runif[2 * a.N];
+      } else {
+        const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+        const u32x4 f = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+        const u32x4 g = philox4x32_10(0xFFFFFFFFu, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+        uacc = u53(q.w2, q.w3);
+        uflip = u53(f.w0, f.w1);
+        ugate = u53(g.w2, g.w3);
+      }
+      const double dH = (double)(H0 - HL);
+      const bool accept = !(dH < 0.0) || (uacc < exp(dH));
+      const bool flip = uflip < a.p_flip;
+      const bool gate = ugate < a.p_r;
+      if (accept) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = -v[e];
+        EXn = EXL;
+        EVn = EVL;
+      } else {
+        stash_get<T, E>(stash_x, lane, x);
+        stash_get<T, E>(stash_v, lane, v);
+        EXn = EX0;
+        EVn = EV0;
+      }
+      if (flip) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = -v[e];
+      }
+      r_applied = gate;
+      if (gate) {  // state.R() on the whole batch (:138-141)
+        stash_put<T, E>(stash_v, lane, v);
+        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m,
+                                    a.r_keep, a.r_mix);
+        stash_get<T, E>(stash_v, lane, v);
+        EVn = kinetic<T, E>(v, m);
+      }
+      k = (accept ? 1 : 0) | (flip ? 2 : 0);
+      // tallies: slot 0 = accepted & flipped (l_count), 1 = flipped only (f_count), 2 = R applied,
+      // 3 = accepted only (fl_count)   (markov_jump_hmc.py:143-148)
+      tally_cold = (accept && !flip);
+    }
     any_bad |= (bad && alive);
 
-    // successor state (markov_jump_hmc.py:399-410)
-    T EXn, EVn, Hc;
-    if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
-      EXn = EXL;
-      EVn = EVL;
-      Hc = H0;
-    } else if (k == 1) {  // F: flip the momentum
-      stash_get<T, E>(stash_x, lane, x);
-      stash_get<T, E>(stash_v, lane, v);
-#pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = -v[e];
-      EXn = EX0;
-      EVn = EV0;
-      Hc = (T)__builtin_nan("");  // clear_flf_cache (markov_jump_hmc.py:409-410)
-    } else {  // R: refresh the momentum (hmc_state.py:121-129)
-      stash_get<T, E>(stash_x, lane, x);
-      refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m, a.r_keep,
-                                  a.r_mix);
-      stash_get<T, E>(stash_v, lane, v);
-      EXn = EX0;
-      EVn = kinetic<T, E>(v, m);
-      Hc = (T)__builtin_nan("");
-    }
     // Stores are unconditional on purpose: rows beyond N are padding (allocated, never read back),
     // and every lane of a group writes the same scalar to the same address.  With no store behind
     // a branch the compiler can COUNT them, so the wait for the prefetched loads at the loop end is
@@ -887,10 +1024,16 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     a.dwell_ring[p] = dwell;
     a.trans[p] = (uint8_t)k;
     if (alive && m.j == 0) {
-      nL += (k == 0);
-      nF += (k == 1);
-      nR += (k == 2);
-      nCold += warm ? 0u : 1u;
+      if constexpr (MODE == kModeControl) {
+        nL += (k == 3);
+        nF += (k == 2);
+        nR += r_applied ? 1u : 0u;
+      } else {
+        nL += (k == 0);
+        nF += (k == 1);
+        nR += (k == 2);
+      }
+      nCold += tally_cold ? 1u : 0u;
     }
   }
   if (any_bad) {  // draw_from's ValueError (utils.py:43-48): the host rolls this attempt back
@@ -993,30 +1136,40 @@ struct EnergyParams {
 
 // Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
 // (occupancy query, cached per instantiation), never more than there are slots to hand out.
-template <class En, typename T, int E, bool REPLAY, bool FULLROW>
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW>
 inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   static int resident_blocks = 0;
   if (resident_blocks == 0) {
     int dev = 0, per_cu = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, REPLAY, FULLROW>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW>, 256,
+                                                       0);
     resident_blocks = std::max(1, per_cu) * std::max(1, cus);
   }
   const int64_t nslots = a.Npad >> (6 - a.logG);
   const int64_t want = (nslots + 3) / 4;
   const unsigned grid = (unsigned)std::min<int64_t>(want, resident_blocks);
-  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, REPLAY, FULLROW>), dim3(grid), dim3(256), 0, st, a, en);
+  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW>), dim3(grid), dim3(256), 0, st, a, en);
 }
 
-// replay needs BOTH recorded streams (normals and unit exponentials); it is a test path, so it
-// only exists in the predicated (non-FULLROW) form
+// Replay needs every recorded stream of the mode; it is a test path and exists only in the
+// predicated (non-FULLROW) form, as do the control-arm samplers.
 template <class En, typename T, int E>
 inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool full = a.CH == (E / VecOf<T>::n) << a.logG;
-  if (a.rexp && a.noise) launch_jump_r<En, T, E, true, false>(a, en, st);
-  else if (full) launch_jump_r<En, T, E, false, true>(a, en, st);
-  else launch_jump_r<En, T, E, false, false>(a, en, st);
+  const bool replay = a.noise != nullptr;
+  if (a.mode == kModeMJHMC) {
+    if (replay) launch_jump_r<En, T, E, kModeMJHMC, true, false>(a, en, st);
+    else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true>(a, en, st);
+    else launch_jump_r<En, T, E, kModeMJHMC, false, false>(a, en, st);
+  } else if (a.mode == kModeCT) {
+    if (replay) launch_jump_r<En, T, E, kModeCT, true, false>(a, en, st);
+    else launch_jump_r<En, T, E, kModeCT, false, false>(a, en, st);
+  } else {
+    if (replay) launch_jump_r<En, T, E, kModeControl, true, false>(a, en, st);
+    else launch_jump_r<En, T, E, kModeControl, false, false>(a, en, st);
+  }
 }
 
 template <class En, typename T, int E>

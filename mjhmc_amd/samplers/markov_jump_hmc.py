@@ -95,6 +95,56 @@ class HMCBase(object):
         self.distribution.E_count += st.E_evals
         self.distribution.dEdX_count += st.dEdX_evals
 
+    def _commit(self, st):
+        self.l_count += st.l
+        self.f_count += st.f
+        self.r_count += st.r
+        self.fl_count += st.fl
+
+    # -- iteration driver (discrete-time samplers; the jump processes override _one) -----------
+    def _one(self, ring_slot=-1, replay=None):
+        self._push_hparams()
+        rn = ru = None
+        if replay is not None:
+            rn, ru = replay.pop(0)
+        stats, n_done = self._dev.iterate(1, replay_normal=rn, replay_unif=ru, ring_slot0=ring_slot)
+        self._account(stats[0])
+        self._commit(stats[0])
+
+    def _run(self, n_iter, ring_slot0=-1, replay=None):
+        """n_iter iterations launched back to back; the host only steps in on a non-finite rate."""
+        if replay is not None:                            # recorded random numbers: one attempt at a time
+            for i in range(n_iter):
+                self._one(ring_slot0 + i if ring_slot0 >= 0 else -1, replay)
+            return
+        done = 0
+        while done < n_iter:
+            self._push_hparams()
+            slot = ring_slot0 + done if ring_slot0 >= 0 else -1
+            stats, n_done = self._dev.iterate(n_iter - done, ring_slot0=slot)
+            for st in stats[:n_done]:
+                self._account(st)
+                self._commit(st)
+            done += n_done
+            if len(stats) > n_done:                       # the attempt after the committed ones failed
+                self._account(stats[n_done])
+                self._retry(ring_slot0 + done if ring_slot0 >= 0 else -1, None)
+                done += 1
+
+    def _retry(self, ring_slot, replay):
+        raise ValueError('Infinite rate.')                # only the jump processes can get here
+
+    def sampling_iteration(self, replay=None):
+        """One step of every particle (markov_jump_hmc.py:116-148).  ``replay=[(normals (D,N),
+        uniforms (2N+1) = accept, flip, R gate), ...]`` feeds recorded random numbers."""
+        self._one(-1, replay)
+
+    def sample(self, n_samples=1000, preserve_order=False, replay=None):
+        """markov_jump_hmc.py:150-173."""
+        self._dev.ring_alloc(n_samples)
+        self._run(n_samples, ring_slot0=0, replay=replay)
+        return self._dev.ring_read(0, n_samples, stacked=bool(preserve_order))
+
 
 class HMC(HMCBase):
     def __init__(self, *args, **kwargs):
@@ -142,24 +192,10 @@ class ContinuousTimeHMC(HMCBase):
         return np.exp(Ediff) ** .5
 
     # -- iteration driver --------------------------------------------------------------------
-    def _commit(self, st):
-        self.l_count += st.l
-        self.f_count += st.f
-        self.r_count += st.r
-        self.fl_count += st.fl
-
     def _retry(self, ring_slot, replay):
-        """markov_jump_hmc.py:376-389: halve epsilon, double L, wipe the FLF cache, try again, restore."""
-        self.epsilon *= 0.5
-        self.num_leapfrog_steps *= 2
-        depth = np.log(self.original_epsilon / self.epsilon) / np.log(2)
-        print("Ecountered infinite rate, doubling back. Depth: {}".format(depth))
-        if depth > MAX_RETRY_DEPTH:
-            raise RuntimeError('non-finite transition rates persist after %d halvings' % MAX_RETRY_DEPTH)
-        self._dev.reset_flf_cache()
-        self._one(ring_slot, replay)
-        self.epsilon *= 2
-        self.num_leapfrog_steps = int(self.num_leapfrog_steps / 2)
+        """ContinuousTimeHMC lets draw_from's ValueError propagate (markov_jump_hmc.py:266-268)."""
+        raise ValueError("Infinite rate. This occurs when calculating transition rates between states that "
+                         "have a very large energy difference (mjhmc/misc/utils.py:43-48).")
 
     def _one(self, ring_slot=-1, replay=None):
         """One sampling_iteration including the reference's retry recursion."""
@@ -175,25 +211,7 @@ class ContinuousTimeHMC(HMCBase):
             self._retry(ring_slot, replay)
 
     def _run(self, n_iter, ring_slot0=-1, replay=None):
-        """n_iter iterations launched back to back; the host only steps in on a non-finite rate."""
-        if replay is not None:                            # recorded random numbers: one attempt at a time
-            for i in range(n_iter):
-                self._one(ring_slot0 + i if ring_slot0 >= 0 else -1, replay)
-            self.dwelling_times = self._dev.read(_lib.F_DWELL)
-            return
-        done = 0
-        while done < n_iter:
-            self._push_hparams()
-            slot = ring_slot0 + done if ring_slot0 >= 0 else -1
-            stats, n_done = self._dev.iterate(n_iter - done, ring_slot0=slot)
-            for st in stats[:n_done]:
-                self._account(st)
-                self._commit(st)
-            done += n_done
-            if len(stats) > n_done:                       # the attempt after the committed ones failed
-                self._account(stats[n_done])
-                self._retry(ring_slot0 + done if ring_slot0 >= 0 else -1, None)
-                done += 1
+        super(ContinuousTimeHMC, self)._run(n_iter, ring_slot0, replay)
         self.dwelling_times = self._dev.read(_lib.F_DWELL)
 
     def sampling_iteration(self, replay=None):
@@ -229,3 +247,16 @@ class MarkovJumpHMC(ContinuousTimeHMC):
     """Markov Jump HMC, arXiv:1509.03808 (markov_jump_hmc.py:350-415)."""
 
     _mode = _lib.MODE_MJHMC
+
+    def _retry(self, ring_slot, replay):
+        """markov_jump_hmc.py:376-389: halve epsilon, double L, wipe the FLF cache, try again, restore."""
+        self.epsilon *= 0.5
+        self.num_leapfrog_steps *= 2
+        depth = np.log(self.original_epsilon / self.epsilon) / np.log(2)
+        print("Ecountered infinite rate, doubling back. Depth: {}".format(depth))
+        if depth > MAX_RETRY_DEPTH:
+            raise RuntimeError('non-finite transition rates persist after %d halvings' % MAX_RETRY_DEPTH)
+        self._dev.reset_flf_cache()
+        self._one(ring_slot, replay)
+        self.epsilon *= 2
+        self.num_leapfrog_steps = int(self.num_leapfrog_steps / 2)

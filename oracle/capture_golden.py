@@ -159,14 +159,15 @@ def stack(snaps, key):
     return np.stack([sn[key] for sn in snaps])
 
 
-def capture_mjhmc(refs, name, kind, ndims, nbatch, eps, L, beta, T, seed, x_scale=1.0, keep_grad=True):
+def capture_mjhmc(refs, name, kind, ndims, nbatch, eps, L, beta, T, seed, x_scale=1.0, keep_grad=True,
+                  cls_name='MarkovJumpHMC'):
     rs, _, rd, ru = refs
     np.random.seed(seed)
     X0 = x_scale * np.random.randn(ndims, nbatch)
     par = energy_params(kind, ndims, nbatch)
     d = make_harness(rd, kind, X0, **par)
     with Recorder(rs, ru, nbatch) as rec:
-        s = rs.MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False)
+        s = getattr(rs, cls_name)(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False)
         snaps = [snapshot(s, d)]
         n_attempts = [len(rec.exps)]
         for _ in range(T):
@@ -337,6 +338,8 @@ def main():
     capture_control(refs, 'g7_control_iso_2x100', 'ControlHMC', 'iso', 2, 100, 0.4, 5, 0.5, 12, 401)
     capture_control(refs, 'g7_hmc_diag_8x32', 'HMC', 'diag', 8, 32, 0.5, 4, 0.4, 12, 402)
     capture_control(refs, 'g7_base_iso_3x50', 'HMCBase', 'iso', 3, 50, 0.3, 6, 0.6, 12, 403)
+    # G8: ContinuousTimeHMC (F / FL / R clocks); trans rows are min_idx's [f, fl, r] order
+    capture_mjhmc(refs, 'g8_cthmc_diag_6x40', 'diag', 6, 40, 0.5, 4, 0.4, 15, 501, cls_name='ContinuousTimeHMC')
 
 
 if __name__ == '__main__':

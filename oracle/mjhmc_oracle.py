@@ -134,10 +134,22 @@ class PhiloxRNG(object):
         return float(self._exp_cache[kind, particle])
 
     def uniforms(self, n):
-        raise NotImplementedError("control-sampler uniforms come from accept/flip_uniforms")
+        """1st request of a tick: accept uniforms; 2nd: flip uniforms (markov_jump_hmc.py:125,132)."""
+        assert n == self.stream.pid.shape[0]
+        self._ucalls = getattr(self, '_ucalls', 0) + 1
+        return self.stream.accept_uniforms(self.tick) if self._ucalls == 1 else self.stream.flip_uniforms(self.tick)
+
+    def uniform(self):
+        """Batch-wide R gate (markov_jump_hmc.py:138): one number per tick, particle id 0xFFFFFFFF."""
+        from .philox import PhiloxStream, SLOT_FLIP, philox4x32_10, u53
+        import numpy as _np
+        w = philox4x32_10(_np.array([0xFFFFFFFF], dtype=_np.uint64), self.tick & 0xFFFFFFFF, (self.tick >> 32) & 0xFFFFFFFF,
+                          SLOT_FLIP, self.stream.k0, self.stream.k1)
+        return float(u53(w[2], w[3])[0])
 
     def next_attempt(self):
         self.tick += 1
+        self._ucalls = 0
 
 
 # --------------------------------------------------------------------------------------------
@@ -554,6 +566,7 @@ class HMCBase(_SamplerCore):
         self.f_count += len(flips - moved)
         self.fl_count += len(moved - flips)
         self.last_fl_idx, self.last_flip_idx = fl_idx, flip_idx
+        self.rng.next_attempt()
 
     def sample(self, n_samples=1000, preserve_order=False):                                # :150-173
         out = []
@@ -600,7 +613,6 @@ class ContinuousTimeHMC(HMCBase):
         fl_draws = waiting_times(fl_rates[0], self.rng, 0)
         f_draws = waiting_times(f_rates[0], self.rng, 1)
         r_draws = waiting_times(r_rates[0], self.rng, 2)
-        self.rng.next_attempt()
         (f_idx, fl_idx, r_idx), _ = first_minimum([f_draws, fl_draws, r_draws])
         self.dwelling_times = np.amin(np.concatenate((fl_draws, f_draws, r_draws)), axis=0)
         self.state.overwrite(fl_idx, fl_state)
@@ -610,6 +622,7 @@ class ContinuousTimeHMC(HMCBase):
         self.fl_count += len(fl_idx)
         self.f_count += len(f_idx)
         self.r_count += len(r_idx)
+        self.rng.next_attempt()
 
     def sample(self, n_samples=1000, preserve_order=False):                                # :293-338
         if self.resample:

@@ -312,3 +312,151 @@ def test_full_size_c2_properties_and_column_subset():
     assert close(X[:, cols], o.state.X) and close(V[:, cols], o.state.V)
     assert close(EX[cols], o.state.EX[0]) and close(s.read(_lib.F_DWELL)[cols], o.dwelling_times)
     assert np.isfinite(H0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# G7 / G8: discrete-time control samplers and ContinuousTimeHMC
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['g7_control_iso_2x100', 'g7_hmc_diag_8x32', 'g7_base_iso_3x50'])
+def test_g7_control_samplers_replay(name):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    g = load(name)
+    d = product_distribution(g, g['Xinit'])
+    cls = getattr(M, str(g['cls']))
+    s = cls(distribution=d, epsilon=float(g['eps']), beta=float(g['beta_in']), num_leapfrog_steps=int(g['L']),
+            Vinit=g['normals'][0], seed=5)
+    assert (s.beta, s.p_r, s.p_flip) == (float(g['beta']), float(g['p_r']), float(g['p_flip']))
+    N = g['Xinit'].shape[1]
+    used = 1
+    exact_state = str(g['kind']) == 'diag' and float(g['beta']) == 1.0
+    for t in range(int(g['T']) + 1):
+        if t:
+            fired = g['u_r'][t - 1] < float(g['p_r'])
+            noise = g['normals'][used] if fired else np.zeros_like(g['Xinit'])
+            used += int(fired)
+            unif = np.concatenate([g['u_acc'][t - 1], g['u_flip'][t - 1], [g['u_r'][t - 1]]])
+            s.sampling_iteration(replay=[(noise, unif)])
+            assert used == int(g['normals_done'][t])
+        st = s.state
+        assert close(st.X, g['X'][t]) and close(st.V, g['V'][t]), (name, t)
+        assert close(st.EX[0], g['EX'][t]) and close(st.EV[0], g['EV'][t]), (name, t)
+        if exact_state:
+            assert bits_equal(st.X, g['X'][t]) and bits_equal(st.V, g['V'][t])
+        assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t]), (name, t)
+        assert [d.E_count, d.dEdX_count] == list(g['evals'][t]), (name, t)
+
+
+def test_g8_continuous_time_hmc_replay():
+    from mjhmc_amd.samplers.markov_jump_hmc import ContinuousTimeHMC
+    g = load('g8_cthmc_diag_6x40')
+    d = product_distribution(g, g['Xinit'])
+    s = ContinuousTimeHMC(distribution=d, epsilon=float(g['eps']), beta=float(g['beta']),
+                          num_leapfrog_steps=int(g['L']), Vinit=g['normals'][1], seed=5, resample=False)
+    feed = [(g['normals'][2 + a], np.nan_to_num(g['exps'][a], nan=1.0)) for a in range(len(g['exps']))]
+    for t in range(int(g['T']) + 1):
+        if t:
+            s.sampling_iteration(replay=feed)
+            # device codes 0 = FL, 1 = F, 2 = R ; fixture rows follow min_idx([f, fl, r])
+            want = np.array([1, 0, 2], dtype=np.uint8)[g['trans'][t - 1]]
+            assert np.array_equal(s._dev.read(8), want), t
+            assert close(s.dwelling_times, g['dwell'][t]), t
+        st = s.state
+        assert bits_equal(st.X, g['X'][t]) and bits_equal(st.V, g['V'][t]), t
+        assert close(st.EX[0], g['EX'][t]) and close(st.EV[0], g['EV'][t]), t
+        assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t]), t
+        assert [d.E_count, d.dEdX_count] == list(g['evals'][t]), t
+
+
+@pytest.mark.parametrize('cls_name,kind,D,N,eps,L,beta', [('ControlHMC', 'iso', 16, 200, 0.3, 5, 0.5),
+                                                          ('HMC', 'diag', 9, 150, 0.4, 4, 0.4),
+                                                          ('HMCBase', 'iso', 3, 64, 0.3, 6, 0.6),
+                                                          ('ContinuousTimeHMC', 'iso', 64, 90, 0.2, 5, 0.3)])
+def test_philox_mode_control_and_ct(cls_name, kind, D, N, eps, L, beta):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc import distributions as Dm
+    rng = np.random.RandomState(4)
+    X0 = rng.randn(D, N)
+    base, kw, en = ((Dm.TestGaussian, dict(sigma=1.0), orc.IsoGaussian(1.0)) if kind == 'iso'
+                    else (Dm.Gaussian, dict(log_conditioning=2), orc.DiagGaussian(D, 2)))
+
+    class Fixed(base):
+        def init_X(self):
+            self.Xinit = X0
+
+    d = Fixed(ndims=D, nbatch=N, **kw)
+    seed = 31337
+    extra = dict(resample=False) if cls_name == 'ContinuousTimeHMC' else {}
+    s = getattr(M, cls_name)(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=seed, **extra)
+    o = getattr(orc, cls_name)(en, X0, epsilon=eps, beta=beta, num_leapfrog_steps=L,
+                               rng=orc.PhiloxRNG(seed, np.arange(N)), **extra)
+    assert (s.beta, s.p_r, s.p_flip) == (o.beta, o.p_r, o.p_flip)
+    for t in range(8):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), (cls_name, t)
+        assert close(s.state.EX, o.state.EX) and close(s.state.EV, o.state.EV), (cls_name, t)
+        assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count)
+        assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
+    assert s.r_count > 0 or cls_name == 'ContinuousTimeHMC'
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[0]: the README example, and the reference's statistical acceptance tests
+# ---------------------------------------------------------------------------------------------
+def test_readme_example_runs_unchanged():
+    """README.md:12-37 with only the import lines switched (BASELINE.json configs[0])."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import LambdaDistribution
+
+    def E(X, sigma=1.):
+        return np.sum(X ** 2, axis=0).reshape((1, -1)) / 2. / sigma ** 2
+
+    def dEdX(X, sigma=1.):
+        return X / sigma ** 2
+
+    np.random.seed(0)
+    Xinit = np.random.randn(2, 100)
+    anonymous_gaussian = LambdaDistribution(energy_func=E, energy_grad_func=dEdX, init=Xinit, name='IsotropicGaussian')
+    mjhmc = MarkovJumpHMC(distribution=anonymous_gaussian)
+    X = mjhmc.sample(num_steps=10)
+    assert X.shape == (2, 1000) and np.isfinite(X).all()
+    assert mjhmc.l_count + mjhmc.f_count + mjhmc.r_count == 11 * 100
+    assert mjhmc.r_count == 0                      # defaults give beta = 0.2**2000 = 0 -> p_r = 0 (SURVEY 3.1)
+    assert anonymous_gaussian.E_count >= 100 * 12
+
+
+@pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC', 'HMC', 'HMCBase'])
+def test_statistical_1d_gaussian(cls_name):
+    """mjhmc/tests/test_continuous_samplers.py:19-41 with usable hyper-parameters: mean, std within 0.05."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import TestGaussian
+    np.random.seed(1)
+    extra = dict(resample=False) if cls_name == 'MarkovJumpHMC' else {}
+    s = getattr(M, cls_name)(distribution=TestGaussian(ndims=1, nbatch=100), epsilon=0.5, beta=0.3,
+                             num_leapfrog_steps=3, seed=11, **extra)
+    s.burn_in()
+    samples = s.sample(10000)
+    assert samples.shape == (1, 100 * 10000)
+    if cls_name == 'MarkovJumpHMC':
+        s2 = M.MarkovJumpHMC(distribution=TestGaussian(ndims=1, nbatch=100), epsilon=0.5, beta=0.3,
+                             num_leapfrog_steps=3, seed=12)          # resample=True: dwell-time weighted
+        s2.burn_in()
+        samples = s2.sample(2000)
+    assert abs(np.mean(samples)) < 0.05, np.mean(samples)
+    assert abs(np.std(samples) - 1) < 0.05, np.std(samples)
+
+
+@pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC'])
+def test_statistical_ill_conditioned_gaussian(cls_name):
+    """mjhmc/tests/test_continuous_samplers.py:43-63: 2-D Gaussian, conditioning 10, covariance error < 0.05
+    (relative Frobenius norm here: the target covariance has an entry of 10)."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import Gaussian
+    np.random.seed(1)
+    g = Gaussian(ndims=2, nbatch=200, log_conditioning=1)
+    target = np.linalg.inv(g.J)
+    s = getattr(M, cls_name)(distribution=g, epsilon=0.6, beta=0.2, num_leapfrog_steps=4, seed=21)
+    s.burn_in()
+    samples = s.sample(3000)
+    err = np.linalg.norm(np.cov(samples) - target) / np.linalg.norm(target)
+    assert err < 0.05, err

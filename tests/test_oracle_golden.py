@@ -138,3 +138,22 @@ def test_global_rng_mode_equals_replay():
     for t in range(1, int(g['T']) + 1):
         s.sampling_iteration()
         assert bits_equal(s.state.X, g['X'][t]) and bits_equal(s.state.V, g['V'][t])
+
+
+def test_g8_continuous_time_hmc_replay():
+    """ContinuousTimeHMC (F / FL / R clocks, markov_jump_hmc.py:251-290).  The reference builds the state
+    twice for this class (HMCBase.__init__ then ContinuousTimeHMC.__init__), so V0 is the 2nd randn block."""
+    g = load('g8_cthmc_diag_6x40')
+    en = oracle_energy(g)
+    rng = orc.ReplayRNG(normals=list(g['normals'][2:]), exps=list(g['exps']))
+    s = orc.ContinuousTimeHMC(en, g['Xinit'], epsilon=float(g['eps']), beta=float(g['beta']),
+                              num_leapfrog_steps=int(g['L']), V0=g['normals'][1], rng=rng, resample=False)
+    for t in range(int(g['T']) + 1):
+        if t:
+            s.sampling_iteration()
+            assert bits_equal(s.dwelling_times, g['dwell'][t])
+        st = s.state
+        for f, arr in (('X', st.X), ('V', st.V), ('EX', st.EX[0]), ('EV', st.EV[0]), ('dEdX', st.dEdX)):
+            assert bits_equal(arr, g[f][t]), (t, f)
+        assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t])
+        assert [en.E_count, en.dEdX_count] == list(g['evals'][t])
