@@ -136,6 +136,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_info = None
+    if dist is not None:
+        # the one collective of the path: all-gather of sample columns at the end of sample()
+        # (RCCL over xGMI).  Outside the timed region; bounded to 8192 columns per rank.
+        try:
+            from mjhmc_amd.parallel import Comm, ShardPlan, gather_state_columns
+            comm = Comm()
+            smp.ring_alloc(1)
+            smp.iterate(1, ring_slot0=0)
+            ncol = min(8192, w['N'])
+            cols = smp.ring_gather(np.arange(ncol, dtype=np.int64))
+            tg0 = time.perf_counter()
+            full = gather_state_columns(comm, ShardPlan(ncol * world, world), cols)
+            tg1 = time.perf_counter()
+            gather_info = {'ok': bool(full.shape == (w['D'], ncol * world) and np.array_equal(full[:, rank * ncol:(rank + 1) * ncol], cols)),
+                           'backend': comm.backend, 'columns_per_rank': ncol, 'ms': (tg1 - tg0) * 1e3}
+        except Exception as exc:  # the bench line must survive a collective problem
+            gather_info = {'ok': False, 'error': repr(exc)[:300]}
+
     if rank == 0:
         esize = 8 if w['dtype'] == 'float64' else 4
         units = w['D'] * w['N'] * w['L'] * args.steps * world
@@ -166,6 +185,8 @@ def main():
                          'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms,
                          'launches_timed': tim['n_jump_launches'], 'algorithmic_bytes_per_launch': abytes},
         }
+        if gather_info is not None:
+            out['config']['sample_gather'] = gather_info
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w)
             out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']

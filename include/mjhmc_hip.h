@@ -152,6 +152,16 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
 int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                   const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
 
+/* Transaction support for multi-GPU runs: the reference aborts and retries the WHOLE batch when any
+ * particle hits a non-finite rate (markov_jump_hmc.py:376-389).  With columns sharded over ranks a
+ * rank may have run past the iteration that failed elsewhere; it restores the checkpoint taken at the
+ * start of the batch and replays (the counter RNG makes the replay bit-identical).
+ * checkpoint: device copy of X, V, EX, EV, H_flf, dwell + the RNG tick.  restore: put it back. */
+int mjhmc_checkpoint(mjhmc_sampler* s);
+int mjhmc_restore(mjhmc_sampler* s);
+/* skip n RNG ticks (a rank that did not execute a failed attempt must still consume its tick) */
+int mjhmc_advance_tick(mjhmc_sampler* s, int64_t n);
+
 /* HMCState.reset_flf_cache (hmc_state.py:145-148). */
 int mjhmc_reset_flf_cache(mjhmc_sampler* s);
 

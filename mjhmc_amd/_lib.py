@@ -51,6 +51,9 @@ PROTOTYPES = {
                                          ctypes.c_double]),
     'mjhmc_iterate': (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_int, ctypes.POINTER(IterStats),
                                      ctypes.POINTER(ctypes.c_int)]),
+    'mjhmc_checkpoint': (ctypes.c_int, [_P]),
+    'mjhmc_restore': (ctypes.c_int, [_P]),
+    'mjhmc_advance_tick': (ctypes.c_int, [_P, ctypes.c_int64]),
     'mjhmc_reset_flf_cache': (ctypes.c_int, [_P]),
     'mjhmc_read': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_size_t]),
     'mjhmc_write': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_size_t]),

@@ -76,6 +76,9 @@ struct mjhmc_sampler {
   void* Hflf[2] = {nullptr, nullptr};
   double* dwell = nullptr;
   double* dwell_scratch = nullptr;  // dwell_ring target when no ring slot is recorded
+  void* ck[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // checkpoint: X, V, EX, EV, Hflf, dwell
+  uint64_t ck_tick = 0;
+  bool ck_valid = false;
   uint8_t* trans = nullptr;
   Control* ctl = nullptr;
   long long* stats = nullptr;  // [stats_cap][4]
@@ -466,7 +469,8 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   void* ptrs[] = {s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
-                  s->runif,   s->scratch};
+                  s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
+                  s->ck[5]};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : s->ev_total)
@@ -556,6 +560,41 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
   s->p_r = p_r;
   s->beta = beta;
   s->p_flip = p_flip;
+  return 0;
+}
+
+int mjhmc_checkpoint(mjhmc_sampler* s) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * s->sh.esize, db = (size_t)s->Npad * sizeof(double);
+  const size_t sizes[6] = {mb, mb, vb, vb, vb, db};
+  const void* src[6] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell};
+  for (int i = 0; i < 6; ++i) {
+    if (!s->ck[i]) HIPCHK(hipMalloc(&s->ck[i], sizes[i]));
+    HIPCHK(hipMemcpyAsync(s->ck[i], src[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
+  }
+  s->ck_tick = s->tick;
+  s->ck_valid = true;
+  return 0;
+}
+
+int mjhmc_restore(mjhmc_sampler* s) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  if (!s->ck_valid) return fail(MJHMC_ERR_INVALID, "no checkpoint taken");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * s->sh.esize, db = (size_t)s->Npad * sizeof(double);
+  const size_t sizes[6] = {mb, mb, vb, vb, vb, db};
+  s->Xcur = s->Xbuf[0];
+  void* dst[6] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell};
+  for (int i = 0; i < 6; ++i) HIPCHK(hipMemcpyAsync(dst[i], s->ck[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
+  s->tick = s->ck_tick;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int mjhmc_advance_tick(mjhmc_sampler* s, int64_t n) {
+  if (!s || n < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
+  s->tick += (uint64_t)n;
   return 0;
 }
 

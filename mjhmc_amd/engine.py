@@ -119,6 +119,15 @@ class DeviceSampler(object):
     def reset_flf_cache(self):
         check(self.lib.mjhmc_reset_flf_cache(self.handle))
 
+    def checkpoint(self):
+        check(self.lib.mjhmc_checkpoint(self.handle))
+
+    def restore(self):
+        check(self.lib.mjhmc_restore(self.handle))
+
+    def advance_tick(self, n=1):
+        check(self.lib.mjhmc_advance_tick(self.handle, int(n)))
+
     def read(self, field):
         D, N = self.ndims, self.nparticles
         if field in (_lib.F_X, _lib.F_V, _lib.F_DEDX):

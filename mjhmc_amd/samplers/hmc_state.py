@@ -42,7 +42,14 @@ class DeviceHMCState(object):
         self.active_idx = np.arange(self.nbatch)
 
     def _read(self, field):
-        return self.parent._dev.read(field)
+        local = self.parent._dev.read(field)
+        comm = getattr(self.parent, '_comm', None)
+        if comm is None:
+            return local
+        from ..parallel import gather_state_columns
+        if local.ndim == 2:
+            return gather_state_columns(comm, self.parent._plan, local)
+        return gather_state_columns(comm, self.parent._plan, local.astype(np.float64).reshape(1, -1))[0].astype(local.dtype)
 
     @property
     def X(self):

@@ -24,7 +24,8 @@ class HMCBase(object):
     _mode = _lib.MODE_CONTROL
 
     def __init__(self, Xinit=None, E=None, dEdX=None, epsilon=1e-4, alpha=0.2, beta=None,
-                 num_leapfrog_steps=5, distribution=None, seed=None, dtype='float64', device=0, Vinit=None):
+                 num_leapfrog_steps=5, distribution=None, seed=None, dtype='float64', device=0, Vinit=None,
+                 comm=None):
         self.num_leapfrog_steps = num_leapfrog_steps
         self.epsilon = epsilon
         self.beta = beta or alpha ** (1. / (self.epsilon * self.num_leapfrog_steps))
@@ -39,6 +40,8 @@ class HMCBase(object):
         self.r_count = 0
         self.grad_per_sample_step = self.num_leapfrog_steps
         self._seed, self._dtype, self._device, self._Vinit = seed, dtype, device, Vinit
+        self._comm, self._plan = comm, None      # mjhmc_amd.parallel.Comm: shard particle columns over ranks
+        self._pending = np.zeros(6, dtype=np.int64)  # local l, f, r, fl, E, dEdX increments not yet reduced
         self._dev = None
         if not isinstance(self, ContinuousTimeHMC):
             if not isinstance(distribution, Distribution):
@@ -61,9 +64,18 @@ class HMCBase(object):
         if seed is None:
             lo, hi = np.random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
             seed = int(lo) | (int(hi) << 32)
+            if self._comm is not None:                      # every rank must use rank 0's seed
+                seed = int(self._comm.allreduce_ints([seed >> 1 if self._comm.rank == 0 else 0], 'sum')[0]) << 1
         self.seed = int(seed)
-        self._dev = engine.DeviceSampler(distribution.bind(self._device), distribution.Xinit.copy(), Vinit=self._Vinit,
-                                         seed=self.seed, dtype=self._dtype, mode=self._mode)
+        X0, V0, first = distribution.Xinit, self._Vinit, 0
+        if self._comm is not None:
+            from ..parallel import ShardPlan
+            self._plan = ShardPlan(self.nbatch, self._comm.world)
+            first, stop = self._plan.span(self._comm.rank)
+            X0 = X0[:, first:stop]
+            V0 = None if V0 is None else V0[:, first:stop]
+        self._dev = engine.DeviceSampler(distribution.bind(self._device), np.ascontiguousarray(X0), Vinit=V0,
+                                         seed=self.seed, first_particle_id=first, dtype=self._dtype, mode=self._mode)
         # HMCState.__init__ evaluates E and dEdX once on every particle (hmc_state.py:28-39)
         distribution.E_count += self.nbatch
         distribution.dEdX_count += self.nbatch
@@ -90,16 +102,25 @@ class HMCBase(object):
 
     def burn_in(self):
         self._run(self.n_burn_in)
+        self._publish()
 
     def _account(self, st):
-        self.distribution.E_count += st.E_evals
-        self.distribution.dEdX_count += st.dEdX_evals
+        self._pending[4] += st.E_evals
+        self._pending[5] += st.dEdX_evals
 
     def _commit(self, st):
-        self.l_count += st.l
-        self.f_count += st.f
-        self.r_count += st.r
-        self.fl_count += st.fl
+        self._pending[:4] += (st.l, st.f, st.r, st.fl)
+
+    def _publish(self):
+        """Fold this call's integer bookkeeping into the public counters (summed over ranks)."""
+        inc = self._pending if self._comm is None else self._comm.allreduce_ints(self._pending, 'sum')
+        self.l_count += int(inc[0])
+        self.f_count += int(inc[1])
+        self.r_count += int(inc[2])
+        self.fl_count += int(inc[3])
+        self.distribution.E_count += int(inc[4])
+        self.distribution.dEdX_count += int(inc[5])
+        self._pending[:] = 0
 
     # -- iteration driver (discrete-time samplers; the jump processes override _one) -----------
     def _one(self, ring_slot=-1, replay=None):
@@ -121,12 +142,30 @@ class HMCBase(object):
         while done < n_iter:
             self._push_hparams()
             slot = ring_slot0 + done if ring_slot0 >= 0 else -1
+            if self._comm is not None:
+                self._dev.checkpoint()
             stats, n_done = self._dev.iterate(n_iter - done, ring_slot0=slot)
+            if self._comm is not None:
+                # the reference aborts the WHOLE batch on one bad particle: every rank keeps only the
+                # iterations all ranks committed; a rank that ran ahead restores + replays (bit-identical:
+                # the RNG is a pure function of (seed, particle id, tick))
+                from ..parallel import agree_on_progress
+                common = agree_on_progress(self._comm, n_done)
+                if common < n_done:
+                    self._dev.restore()
+                    if common:
+                        redo, again = self._dev.iterate(common, ring_slot0=slot)
+                        assert again == common
+                    self._dev.advance_tick(1)             # the failed attempt's tick, consumed everywhere
+                failed_somewhere = common < n_iter - done
+                n_done = common
+            else:
+                failed_somewhere = len(stats) > n_done
             for st in stats[:n_done]:
                 self._account(st)
                 self._commit(st)
             done += n_done
-            if len(stats) > n_done:                       # the attempt after the committed ones failed
+            if failed_somewhere:                          # the attempt after the committed ones failed
                 self._account(stats[n_done])
                 self._retry(ring_slot0 + done if ring_slot0 >= 0 else -1, None)
                 done += 1
@@ -137,13 +176,28 @@ class HMCBase(object):
     def sampling_iteration(self, replay=None):
         """One step of every particle (markov_jump_hmc.py:116-148).  ``replay=[(normals (D,N),
         uniforms (2N+1) = accept, flip, R gate), ...]`` feeds recorded random numbers."""
-        self._one(-1, replay)
+        self._step(replay)
+        self._publish()
+
+    def _step(self, replay):
+        if self._comm is not None:
+            self._run(1)
+        else:
+            self._one(-1, replay)
+
+    def _stack(self, n_samples, preserve_order):
+        local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order))
+        if self._comm is None:
+            return local
+        from ..parallel import assemble_stacked
+        return assemble_stacked(self._comm, self._plan, local, n_samples, bool(preserve_order))
 
     def sample(self, n_samples=1000, preserve_order=False, replay=None):
         """markov_jump_hmc.py:150-173."""
         self._dev.ring_alloc(n_samples)
         self._run(n_samples, ring_slot0=0, replay=replay)
-        return self._dev.ring_read(0, n_samples, stacked=bool(preserve_order))
+        self._publish()
+        return self._stack(n_samples, preserve_order)
 
 
 class HMC(HMCBase):
@@ -210,15 +264,23 @@ class ContinuousTimeHMC(HMCBase):
         else:
             self._retry(ring_slot, replay)
 
-    def _run(self, n_iter, ring_slot0=-1, replay=None):
-        super(ContinuousTimeHMC, self)._run(n_iter, ring_slot0, replay)
-        self.dwelling_times = self._dev.read(_lib.F_DWELL)
+    def _read_dwell(self):
+        d = self._dev.read(_lib.F_DWELL)
+        if self._comm is not None:
+            from ..parallel import gather_vector
+            d = gather_vector(self._comm, self._plan, d)
+        self.dwelling_times = d
 
     def sampling_iteration(self, replay=None):
         """One jump of every particle.  ``replay=[(normals (D,N), unit_exps (3,N)), ...]`` feeds
         recorded random numbers (one pair per attempt) instead of the counter RNG."""
-        self._one(-1, replay)
-        self.dwelling_times = self._dev.read(_lib.F_DWELL)
+        self._step(replay)
+        self._publish()
+        self._read_dwell()
+
+    def burn_in(self):
+        super(ContinuousTimeHMC, self).burn_in()
+        self._read_dwell()
 
     def sample(self, n_samples=1000, preserve_order=False, num_steps=None, replay=None):
         """markov_jump_hmc.py:293-338.  ``num_steps`` is accepted as an alias of ``n_samples``
@@ -228,6 +290,13 @@ class ContinuousTimeHMC(HMCBase):
         if self.resample:
             self._dev.ring_alloc(n_samples + 1)
             self._run(n_samples + 1, ring_slot0=0, replay=replay)
+            self._publish()
+            self._read_dwell()
+            if self._comm is not None:
+                from ..parallel import assemble_resample
+                out, self._last_resample_idx = assemble_resample(
+                    self._comm, self._plan, n_samples, self._dev.ring_read_dwell(0, n_samples), self._dev.ring_gather)
+                return out
             dwell_t = self._dev.ring_read_dwell(0, n_samples).reshape(-1)   # time-major, as np.concatenate
             total_t = np.sum(dwell_t)
             cumul_t = np.cumsum(dwell_t)
@@ -240,7 +309,9 @@ class ContinuousTimeHMC(HMCBase):
             return self._dev.ring_gather(sample_idx)
         self._dev.ring_alloc(n_samples)
         self._run(n_samples, ring_slot0=0, replay=replay)
-        return self._dev.ring_read(0, n_samples, stacked=bool(preserve_order))
+        self._publish()
+        self._read_dwell()
+        return self._stack(n_samples, preserve_order)
 
 
 class MarkovJumpHMC(ContinuousTimeHMC):
@@ -257,6 +328,9 @@ class MarkovJumpHMC(ContinuousTimeHMC):
         if depth > MAX_RETRY_DEPTH:
             raise RuntimeError('non-finite transition rates persist after %d halvings' % MAX_RETRY_DEPTH)
         self._dev.reset_flf_cache()
-        self._one(ring_slot, replay)
+        if self._comm is not None:
+            self._run(1, ring_slot)
+        else:
+            self._one(ring_slot, replay)
         self.epsilon *= 2
         self.num_leapfrog_steps = int(self.num_leapfrog_steps / 2)
