@@ -32,14 +32,33 @@ WORKLOADS = {
     # BASELINE.json configs[3] (per-GPU share of 1e6 particles at 8 GPUs is 125000; single GPU runs all 1e6)
     'c4': dict(name='C4 Neal funnel ndims=32 nparticles=1000000/GPU L=15 fp64', kind='funnel', D=32, N=1000000,
                L=15, eps=0.05, beta=0.1, dtype='float64', params=[3.0]),
+    # BASELINE.json configs[2]: ProductOfT on the matrix cores (distr_data/dump_512.pkl is absent from the
+    # reference checkout -> weights from the reference's init_weights recipe)
+    'c3': dict(name='C3 ProductOfT ndims=nbasis=512 nparticles=100000/GPU L=20 fp32', kind='pot', D=512, N=100000,
+               L=20, eps=0.05, beta=0.1, dtype='float32', params=None),
     # BASELINE.json configs[0] (README shape; plumbing)
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
 }
 
 
+def pot_model(D):
+    """init_weights of mjhmc/search/MJHMC_poe_36/mjhmc_objective.py:15-23 (seed 2015) plus I (invertible)."""
+    rs = np.random.RandomState(2015)
+    sp_var = rs.rand(D, D)
+    W = rs.randn(D, D)
+    W[sp_var > 0.05] = 0
+    lognu = np.log(rs.rand(D) * 2 + 2.1)
+    return W + np.eye(D), lognu
+
+
 def initial_state(w, rank):
     rng = np.random.RandomState(1000 + rank)
+    if w['kind'] == 'pot':
+        # gen_init_X of ProductOfT (distributions.py:437-445): Student-t draws mapped through inv(W)
+        W, lognu = pot_model(w['D'])
+        Z = np.stack([rng.standard_t(np.float32(np.exp(lognu[i])), size=w['N']) for i in range(w['D'])])
+        return np.linalg.solve(W.astype(np.float32).astype(np.float64), Z)
     X0 = rng.randn(w['D'], w['N'])
     if w['kind'] == 'funnel':
         X0[0] *= w['params'][0]
@@ -49,8 +68,8 @@ def initial_state(w, rank):
 
 def algorithmic_bytes_per_particle(D, esize):
     """One sampling_iteration: read X,V + write X',V' (4*D*s) + per-particle scalars:
-    read EX,EV,H_flf (3s) + cache flag (1); write EX,EV,H_flf (3s) + cache (1) + dwell (8) + trans (1)."""
-    return 4 * D * esize + 6 * esize + 8 + 3
+    read EX,EV,H_flf (3s); write EX,EV,H_flf (3s) + dwell (8) + dwell-ring slot (8) + trans (1)."""
+    return 4 * D * esize + 6 * esize + 17
 
 
 def cpu_baseline(w, seconds_target=15.0):
@@ -59,8 +78,19 @@ def cpu_baseline(w, seconds_target=15.0):
     from oracle import mjhmc_oracle as orc
     n = min(w['N'], 4000 if w['D'] >= 256 else 20000)
     rng = np.random.RandomState(7)
-    X0 = rng.randn(w['D'], n)
-    en = orc.IsoGaussian(w['params'][0]) if w['kind'] == 'iso' else orc.FunnelNeal(w['params'][0])
+    threads = 1
+    if w['kind'] == 'pot':
+        W, lognu = pot_model(w['D'])
+        en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float32)   # float32 force, float64 state: as the reference
+        X0 = initial_state(dict(w, N=n), 7)
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])   # BLAS threads used by np.dot
+        except Exception:
+            threads = os.cpu_count()
+    else:
+        X0 = rng.randn(w['D'], n)
+        en = orc.IsoGaussian(w['params'][0]) if w['kind'] == 'iso' else orc.FunnelNeal(w['params'][0])
     if w['kind'] == 'funnel':
         X0[0] *= w['params'][0]
         X0[1:] *= np.exp(X0[0] / 2.)
@@ -75,7 +105,7 @@ def cpu_baseline(w, seconds_target=15.0):
         if dt > seconds_target or iters >= 50:
             break
     value = w['D'] * n * w['L'] * iters / dt
-    return dict(value=value, unit='particle-steps/s', cores=1, kind='port',
+    return dict(value=value, unit='particle-steps/s', cores=threads, kind='port',
                 sample='NumPy oracle (port of the reference path), ndims=%d, nparticles=%d of %d, L=%d, %d '
                        'sampling_iterations after 1 warm-up, %.1f s, numpy %s, os.cpu_count=%d'
                        % (w['D'], n, w['N'], w['L'], iters, dt, np.__version__, os.cpu_count()))
@@ -104,8 +134,12 @@ def main():
 
     from mjhmc_amd import engine, _lib
     ctx = engine.context(local_rank)
-    kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL}[w['kind']]
-    en = engine.DeviceEnergy(ctx, kind, w['D'], w['params'])
+    kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T}[w['kind']]
+    params = w['params']
+    if w['kind'] == 'pot':
+        W, lognu = pot_model(w['D'])
+        params = np.concatenate([[float(w['D'])], W.ravel(), np.exp(lognu), np.zeros(w['D'])])
+    en = engine.DeviceEnergy(ctx, kind, w['D'], params)
     X0 = initial_state(w, rank)
     smp = engine.DeviceSampler(en, X0, seed=20261002, first_particle_id=rank * w['N'], dtype=w['dtype'])
     del X0
@@ -167,6 +201,20 @@ def main():
             traffic = json.load(open(tfile)).get(args.workload)
         n_l = sum(s.l for s in stats)
         n_cold = sum(s.n_cold for s in stats)
+        if w['kind'] == 'pot':
+            # dense energy: the bound is the fp32 matrix pipe.  Algorithmic flops from the exact counters
+            # (SURVEY.md 8d): dEdX_evals * 4*D*K + E_evals * 2*D*K
+            DK = float(w['D']) * w['D']
+            flops = sum(s.dEdX_evals * 4 * DK + s.E_evals * 2 * DK for s in stats) / len(stats)
+            achieved_tf = flops / (kern_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': achieved_tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': achieved_tf / 157.3,
+                    'traffic': None, 'kernel': 'pot_jump_kernel', 'avg_launch_ms': kern_ms,
+                    'launches_timed': tim['n_jump_launches'], 'algorithmic_flops_per_launch': flops}
+        else:
+            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                    'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms,
+                    'launches_timed': tim['n_jump_launches'], 'algorithmic_bytes_per_launch': abytes}
         out = {
             'metric': 'particle-steps/sec (ndims x nparticles x L)',
             'value': units / elapsed,
@@ -180,10 +228,7 @@ def main():
                        'particles_x_L_per_s': w['N'] * w['L'] * args.steps * world / elapsed,
                        'L_move_fraction': n_l / float(w['N'] * args.steps),
                        'cold_fraction': n_cold / float(w['N'] * args.steps)},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms,
-                         'launches_timed': tim['n_jump_launches'], 'algorithmic_bytes_per_launch': abytes},
+            'roofline': roof,
         }
         if gather_info is not None:
             out['config']['sample_gather'] = gather_info

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mjhmc_hip.h"
+#include "dense_pot.hpp"
 #include "elementwise.hpp"
 
 using namespace mjhmc;
@@ -52,6 +53,9 @@ struct mjhmc_energy {
   std::vector<double> params;
   void* dev64 = nullptr;
   void* dev32 = nullptr;
+  float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
+  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3]}; }
+  bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
 };
 
 struct Shape {
@@ -70,6 +74,7 @@ struct mjhmc_sampler {
   void* Xbuf[2] = {nullptr, nullptr};
   void* Vbuf[2] = {nullptr, nullptr};
   void* Xcur = nullptr;
+  void* Gbuf[2] = {nullptr, nullptr};  // dEdX (dense energies keep it, like HMCState.dEdX); follows vcur
   int vcur = 0, scur = 0;
   void* EX[2] = {nullptr, nullptr};
   void* EV[2] = {nullptr, nullptr};
@@ -346,7 +351,27 @@ static int run_eval_t(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, c
   return 0;
 }
 
+static int run_eval_pot(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen,
+                        void* EVout) {
+  PotEvalArgs a;
+  a.X = (const float*)X;
+  a.G = (float*)Gout;
+  a.E = (float*)Eout;
+  a.EV = (float*)EVout;
+  a.V = (const float*)V;
+  a.V_gen = (float*)Vgen;
+  a.N = s->N;
+  a.ntiles = s->Npad / 32;
+  a.first_pid = s->first_pid;
+  a.D = s->D;
+  a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), 0u, 0u};
+  pot_launch_eval(a, s->en->pot_model(), s->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
+  if (s->en->is_pot()) return run_eval_pot(s, X, Gout, Eout, V, Vgen, EVout);
   return s->dtype == MJHMC_F64 ? run_eval_t<double>(s, X, Gout, Eout, V, Vgen, EVout)
                                : run_eval_t<float>(s, X, Gout, Eout, V, Vgen, EVout);
 }
@@ -443,6 +468,42 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
       e->ep.dev_f32 = e->dev32;
       break;
     }
+    case MJHMC_E_PRODUCT_OF_T: {
+      // params = {nbasis, W[D*nbasis] row-major, nu[nbasis], b[nbasis]}  (distributions.py:379-406)
+      const int K = nparams ? (int)params[0] : 0;
+      if (K != ndims || nparams != (size_t)1 + (size_t)ndims * K + 2 * (size_t)K) {
+        rc = fail(MJHMC_ERR_INVALID, "PRODUCT_OF_T expects {nbasis == ndims, W[D*K], nu[K], b[K]}");
+        break;
+      }
+      if (ndims > kPotDim) {
+        rc = fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T supports ndims <= 512 in this build");
+        break;
+      }
+      const double* W = params + 1;
+      const double* nu = W + (size_t)ndims * K;
+      const double* b = nu + K;
+      const size_t M = (size_t)kPotDim * kPotDim;
+      std::vector<float> w1(M, 0.f), w2t(M, 0.f), cb(kPotDim, 0.f), al(kPotDim, 0.f);
+      for (int j = 0; j < K; ++j) {
+        // parameters are float32 in the reference (theano.shared(np.array(.., dtype='float32')), :398-406)
+        const double nuj = (double)(float)nu[j];
+        cb[j] = (float)((double)(float)b[j] / nuj);
+        al[j] = (float)((nuj + 1.0) / 2.0);
+        for (int d = 0; d < ndims; ++d) {
+          const double wdj = (double)(float)W[(size_t)d * K + j];
+          w1[(size_t)d * kPotDim + j] = (float)(wdj / nuj);
+          w2t[(size_t)j * kPotDim + d] = (float)(wdj * (nuj + 1.0) / nuj);
+        }
+      }
+      const void* src[4] = {w1.data(), w2t.data(), cb.data(), al.data()};
+      const size_t bytes[4] = {M * 4, M * 4, (size_t)kPotDim * 4, (size_t)kPotDim * 4};
+      for (int i = 0; i < 4 && !rc; ++i) {
+        if (hipMalloc((void**)&e->pot[i], bytes[i]) != hipSuccess ||
+            hipMemcpy(e->pot[i], src[i], bytes[i], hipMemcpyHostToDevice) != hipSuccess)
+          rc = fail(MJHMC_ERR_HIP, "allocating PRODUCT_OF_T parameters failed");
+      }
+      break;
+    }
     default:
       rc = fail(MJHMC_ERR_UNSUPPORTED, "energy kind not implemented in this build");
   }
@@ -458,6 +519,8 @@ int mjhmc_energy_destroy(mjhmc_energy* e) {
   if (!e) return 0;
   if (e->dev64) (void)hipFree(e->dev64);
   if (e->dev32) (void)hipFree(e->dev32);
+  for (float* q : e->pot)
+    if (q) (void)hipFree(q);
   delete e;
   return 0;
 }
@@ -466,7 +529,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void* ptrs[] = {s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
+  void* ptrs[] = {s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
@@ -500,7 +563,16 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   s->dtype = dtype;
   s->mode = mode;
   s->seed = seed;
-  int rc = pick_shape(s->D, dtype, &s->sh);
+  int rc = 0;
+  if (e->is_pot()) {
+    if (dtype != MJHMC_F32 || mode != MJHMC_MODE_MJHMC) {
+      delete s;
+      return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs in float32, MJHMC mode (the reference evaluates it in float32)");
+    }
+    s->sh = Shape{0, 0, kPotDim, kPotDim / 4, 4};
+  } else {
+    rc = pick_shape(s->D, dtype, &s->sh);
+  }
   if (rc) {
     delete s;
     return rc;
@@ -513,6 +585,10 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       HIPCHK(hipMalloc(&s->Vbuf[i], mb));
       HIPCHK(hipMemsetAsync(s->Xbuf[i], 0, mb, s->stream));
       HIPCHK(hipMemsetAsync(s->Vbuf[i], 0, mb, s->stream));
+      if (e->is_pot()) {
+        HIPCHK(hipMalloc(&s->Gbuf[i], mb));
+        HIPCHK(hipMemsetAsync(s->Gbuf[i], 0, mb, s->stream));
+      }
       HIPCHK(hipMalloc(&s->EX[i], s->Npad * s->sh.esize));
       HIPCHK(hipMalloc(&s->EV[i], s->Npad * s->sh.esize));
       HIPCHK(hipMalloc(&s->Hflf[i], s->Npad * s->sh.esize));
@@ -533,9 +609,9 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
     TRY(upload_matrix(s, Xinit, s->Xcur));
     if (Vinit) {
       TRY(upload_matrix(s, Vinit, s->Vbuf[0]));
-      TRY(run_eval(s, s->Xcur, nullptr, s->EX[0], s->Vbuf[0], nullptr, s->EV[0]));
+      TRY(run_eval(s, s->Xcur, s->Gbuf[0], s->EX[0], s->Vbuf[0], nullptr, s->EV[0]));
     } else {
-      TRY(run_eval(s, s->Xcur, nullptr, s->EX[0], nullptr, s->Vbuf[0], s->EV[0]));
+      TRY(run_eval(s, s->Xcur, s->Gbuf[0], s->EX[0], nullptr, s->Vbuf[0], s->EV[0]));
     }
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
@@ -698,7 +774,46 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), (uint32_t)(tick & 0xFFFFFFFFu),
                    (uint32_t)(tick >> 32)};
     if (i < n_timed) HIPCHK(hipEventRecord(s->ev_k[2 * i], s->stream));
-    TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+    if (s->en->is_pot()) {
+      if constexpr (sizeof(T) == 4) {
+        PotJumpArgs pa;
+        pa.X_in = a.X_in;
+        pa.V_in = a.V_in;
+        pa.G_in = (const float*)s->Gbuf[vi];
+        pa.X_out = a.X_out;
+        pa.V_out = a.V_out;
+        pa.G_out = (float*)s->Gbuf[vi ^ 1];
+        pa.EX_in = a.EX_in;
+        pa.EV_in = a.EV_in;
+        pa.Hflf_in = a.Hflf_in;
+        pa.EX_out = a.EX_out;
+        pa.EV_out = a.EV_out;
+        pa.Hflf_out = a.Hflf_out;
+        pa.dwell = a.dwell;
+        pa.dwell_ring = a.dwell_ring;
+        pa.trans = a.trans;
+        pa.noise = a.noise;
+        pa.rexp = a.rexp;
+        pa.ctl = a.ctl;
+        pa.stats = a.stats;
+        pa.N = a.N;
+        pa.Npad = a.Npad;
+        pa.ntiles = a.Npad / 32;
+        pa.first_pid = a.first_pid;
+        pa.D = a.D;
+        pa.L = a.L;
+        pa.iter = a.iter;
+        pa.eps = a.eps;
+        pa.chalf = a.chalf;
+        pa.r_keep = a.r_keep;
+        pa.r_mix = a.r_mix;
+        pa.p_r = a.p_r;
+        pa.key = a.key;
+        pot_launch_jump(pa, s->en->pot_model(), s->stream);
+      }
+    } else {
+      TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+    }
     if (i < n_timed) HIPCHK(hipEventRecord(s->ev_k[2 * i + 1], s->stream));
     HIPCHK(hipGetLastError());
     xin = xo;
@@ -805,7 +920,9 @@ int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       TRY(ensure_stage(s, mat));
       const void* src = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
-      if (field == MJHMC_F_DEDX) {
+      if (field == MJHMC_F_DEDX && s->en->is_pot()) {
+        src = s->Gbuf[s->vcur];
+      } else if (field == MJHMC_F_DEDX) {
         if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, mat_bytes(s)));
         TRY(run_eval(s, s->Xcur, s->scratch, nullptr, nullptr, nullptr, nullptr));
         src = s->scratch;
@@ -853,7 +970,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       TRY(upload_matrix(s, (const double*)host_src, dst));
-      TRY(run_eval(s, s->Xcur, nullptr, s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
+      TRY(run_eval(s, s->Xcur, s->Gbuf[s->vcur], s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
       HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * s->sh.esize, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
@@ -981,7 +1098,12 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   w.first_pid = 0;
   w.D = e->ep.ndims;
   w.dtype = dtype;
-  TRY(pick_shape(w.D, dtype, &w.sh));
+  if (e->is_pot()) {
+    if (dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T evaluates in float32");
+    w.sh = Shape{0, 0, kPotDim, kPotDim / 4, 4};
+  } else {
+    TRY(pick_shape(w.D, dtype, &w.sh));
+  }
   void *Xd = nullptr, *Gd = nullptr, *Ed = nullptr;
   auto body = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -989,7 +1111,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
     HIPCHK(hipMalloc(&Xd, mb));
     HIPCHK(hipMemsetAsync(Xd, 0, mb, w.stream));
     if (dEdX_out) HIPCHK(hipMalloc(&Gd, mb));
-    if (E_out) HIPCHK(hipMalloc(&Ed, n * w.sh.esize));
+    if (E_out) HIPCHK(hipMalloc(&Ed, w.Npad * w.sh.esize));
     TRY(upload_matrix(&w, X, Xd));
     TRY(run_eval(&w, Xd, Gd, Ed, nullptr, nullptr, nullptr));
     if (E_out) TRY(read_vec(&w, Ed, E_out, (size_t)n * sizeof(double)));

@@ -29,6 +29,8 @@ class Distribution(object):
         self.E_count = 0
         self.dEdX_count = 0
         self.generation_instance = False
+        if not hasattr(self, 'state_dtype'):
+            self.state_dtype = 'float64'         # arithmetic type of state and force on the device
         if not hasattr(self, 'max_n_particles'):
             self.max_n_particles = None
         self._dev = None
@@ -52,7 +54,7 @@ class Distribution(object):
         return self.E_val(X)
 
     def E_val(self, X):
-        E, _ = self.bind().eval(X, want_E=True, want_grad=False)
+        E, _ = self.bind().eval(X, want_E=True, want_grad=False, dtype=self.state_dtype)
         return E.reshape((1, -1))
 
     def dEdX(self, X):
@@ -60,7 +62,7 @@ class Distribution(object):
         return self.dEdX_val(X)
 
     def dEdX_val(self, X):
-        _, G = self.bind().eval(X, want_E=False, want_grad=True)
+        _, G = self.bind().eval(X, want_E=False, want_grad=True, dtype=self.state_dtype)
         return G
 
     def __hash__(self):
@@ -247,3 +249,40 @@ class Funnel(Distribution):
 
     def __hash__(self):
         return hash((self.scale, self.ndims))
+
+
+class ProductOfT(Distribution):
+    """Product of Student-t experts (distributions.py:373-453).  The reference builds E and its
+    gradient with Theano in float32; here both GEMMs of the gradient run on the MI355X matrix
+    cores (exact-f32 MFMA).  ndims == nbasis <= 512, as the reference's initialiser requires (:391-392)."""
+
+    def __init__(self, ndims=36, nbasis=36, nbatch=100, lognu=None, W=None, b=None):
+        if ndims != nbasis:
+            raise NotImplementedError("Initializer only works for ndims == nbasis")
+        self.nbasis = nbasis
+        self.state_dtype = 'float32'
+        self.backend = 'hip-mfma'
+        if W is None:
+            W = np.eye(ndims, nbasis)
+        self.weights = np.array(W, dtype='float32')
+        pre_nu = np.random.rand(nbasis,) * 2 + 2.1 if lognu is None else np.exp(lognu)
+        self.nu = np.array(pre_nu, dtype='float32')
+        self.bias = np.array(np.zeros((nbasis,)) if b is None else b, dtype='float32')
+        super(ProductOfT, self).__init__(ndims, nbatch)
+
+    def device_energy(self):
+        params = np.concatenate([[float(self.nbasis)], self.weights.astype(np.float64).ravel(),
+                                 self.nu.astype(np.float64), self.bias.astype(np.float64)])
+        return (_lib.E_PRODUCT_OF_T, params)
+
+    def gen_init_X(self):
+        from scipy import stats
+        Zinit = np.zeros((self.ndims, self.nbatch))
+        for ii in range(self.ndims):
+            Zinit[ii] = stats.t.rvs(self.nu[ii], size=self.nbatch)
+        Yinit = Zinit - self.bias.reshape((-1, 1))
+        self.Xinit = np.dot(np.linalg.inv(self.weights), Yinit)
+
+    def __hash__(self):
+        return hash((self.ndims, self.nbasis, hash(tuple(self.nu)), hash(tuple(self.weights.ravel())),
+                     hash(tuple(self.bias.ravel()))))

@@ -24,7 +24,7 @@ class HMCBase(object):
     _mode = _lib.MODE_CONTROL
 
     def __init__(self, Xinit=None, E=None, dEdX=None, epsilon=1e-4, alpha=0.2, beta=None,
-                 num_leapfrog_steps=5, distribution=None, seed=None, dtype='float64', device=0, Vinit=None,
+                 num_leapfrog_steps=5, distribution=None, seed=None, dtype=None, device=0, Vinit=None,
                  comm=None):
         self.num_leapfrog_steps = num_leapfrog_steps
         self.epsilon = epsilon
@@ -75,7 +75,9 @@ class HMCBase(object):
             X0 = X0[:, first:stop]
             V0 = None if V0 is None else V0[:, first:stop]
         self._dev = engine.DeviceSampler(distribution.bind(self._device), np.ascontiguousarray(X0), Vinit=V0,
-                                         seed=self.seed, first_particle_id=first, dtype=self._dtype, mode=self._mode)
+                                         seed=self.seed, first_particle_id=first,
+                                         dtype=self._dtype or getattr(distribution, 'state_dtype', 'float64'),
+                                         mode=self._mode)
         # HMCState.__init__ evaluates E and dEdX once on every particle (hmc_state.py:28-39)
         distribution.E_count += self.nbatch
         distribution.dEdX_count += self.nbatch

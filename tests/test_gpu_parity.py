@@ -460,3 +460,80 @@ def test_statistical_ill_conditioned_gaussian(cls_name):
     samples = s.sample(3000)
     err = np.linalg.norm(np.cov(samples) - target) / np.linalg.norm(target)
     assert err < 0.05, err
+
+
+# ---------------------------------------------------------------------------------------------
+# ProductOfT on the matrix cores (float32; parity unpinned by reference tests -> oracle in float64)
+# ---------------------------------------------------------------------------------------------
+def pot_weights(ndims, seed=2015):
+    """init_weights of mjhmc/search/MJHMC_poe_36/mjhmc_objective.py:15-23 (+ I to keep W invertible)."""
+    rs = np.random.RandomState(seed)
+    sp_var = rs.rand(ndims, ndims)
+    w_sp = rs.randn(ndims, ndims)
+    w_sp[sp_var > 0.05] = 0
+    lognu = np.log(rs.rand(ndims) * 2 + 2.1)
+    return w_sp + np.eye(ndims), lognu
+
+
+@pytest.mark.parametrize('ndims,n', [(36, 25), (100, 40), (512, 70)])
+def test_pot_energy_and_gradient(ndims, n):
+    from mjhmc_amd.misc.distributions import ProductOfT
+    W, lognu = pot_weights(ndims)
+    b = 0.1 * np.random.RandomState(1).randn(ndims)
+    d = ProductOfT(ndims=ndims, nbasis=ndims, nbatch=n, lognu=lognu, W=W, b=b)
+    o = orc.ProductOfT(W, lognu=lognu, b=b, force_dtype=np.float64)
+    X = np.random.RandomState(2).randn(ndims, n) * 1.5
+    E, G = d.E(X), d.dEdX(X)
+    Eo, Go = o.E_val(X), o.dEdX_val(X)
+    assert E.shape == (1, n) and G.shape == (ndims, n)
+    assert np.allclose(E, Eo, rtol=2e-5, atol=2e-5 * np.abs(Eo).max())
+    assert np.allclose(G, Go, rtol=0, atol=3e-5 * np.abs(Go).max())
+
+
+@pytest.mark.parametrize('ndims,N,eps,L,beta', [(36, 50, 0.1, 6, 0.3), (512, 96, 0.05, 8, 0.2)])
+def test_pot_iterations_vs_oracle(ndims, N, eps, L, beta):
+    """Per-iteration parity from identical inputs (float32 device vs float64 oracle): transitions equal
+    (a differing particle must be a near tie), state within float32 tolerance."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import ProductOfT
+    W, lognu = pot_weights(ndims)
+    X0 = np.random.RandomState(3).randn(ndims, N)
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0
+
+    d = Fixed(ndims=ndims, nbasis=ndims, nbatch=N, lognu=lognu, W=W)
+    en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
+    seed = 99
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=seed, resample=False)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(seed, np.arange(N)))
+    assert np.allclose(s.state.V, o.state.V, atol=1e-6)
+    assert np.allclose(s.state.EX, o.state.EX, rtol=2e-5) and np.allclose(s.state.dEdX, o.state.dEdX, atol=1e-4)
+    # start both from the float32-rounded momentum so the inputs are identical
+    V32 = s.state.V
+    o.state.V[:] = V32
+    o.state.refresh_EV()
+    for t in range(5):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        tr, tro = s._dev.read(8), o.last_transition
+        same = tr == tro
+        assert same.mean() > 0.97, (t, same.mean())
+        scale = max(1.0, np.abs(o.state.X).max())
+        assert np.allclose(s.state.X[:, same], o.state.X[:, same], atol=2e-4 * scale), t
+        assert np.allclose(s.state.V[:, same], o.state.V[:, same], atol=2e-4 * scale), t
+        assert np.allclose(s.state.EX[0, same], o.state.EX[0, same], rtol=1e-4, atol=1e-3), t
+        # dwell = e / sqrt(exp(H0 - H1)): a float32 energy of O(1e3) carries ~1e-3 absolute error
+        assert np.allclose(s.dwelling_times[same], o.dwelling_times[same], rtol=2e-2), t
+        assert np.array_equal(s.state.cache_active[same], o.state.shadow_ok[same])
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        # re-synchronise: next iteration starts from the device state on both sides
+        Xd, Vd = s.state.X, s.state.V
+        hflf = s._dev.read(5)
+        o.state.X[:], o.state.V[:] = Xd, Vd
+        o.state.refresh_EX(); o.state.refresh_EV(); o.state.refresh_grad()
+        o.state.shadow_ok[:] = ~np.isnan(hflf)
+        o.state.shadow.EX[0, :] = np.nan_to_num(hflf)
+        o.state.shadow.EV[0, :] = 0.0
