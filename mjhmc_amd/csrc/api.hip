@@ -75,6 +75,8 @@ struct mjhmc_sampler {
   void* Vbuf[2] = {nullptr, nullptr};
   void* Xcur = nullptr;
   void* Gbuf[2] = {nullptr, nullptr};  // dEdX (dense energies keep it, like HMCState.dEdX); follows vcur
+  float* Hwork = nullptr;              // dense energies: per-attempt H_flf work vector
+  int* cold_list = nullptr;            // + compacted cold-particle list (Npad entries, then the counter)
   int vcur = 0, scur = 0;
   void* EX[2] = {nullptr, nullptr};
   void* EV[2] = {nullptr, nullptr};
@@ -529,7 +531,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void* ptrs[] = {s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
+  void* ptrs[] = {s->Hwork, s->cold_list, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
@@ -588,6 +590,10 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       if (e->is_pot()) {
         HIPCHK(hipMalloc(&s->Gbuf[i], mb));
         HIPCHK(hipMemsetAsync(s->Gbuf[i], 0, mb, s->stream));
+        if (!s->Hwork) {
+          HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * sizeof(float)));
+          HIPCHK(hipMalloc((void**)&s->cold_list, (s->Npad + 1) * sizeof(int)));
+        }
       }
       HIPCHK(hipMalloc(&s->EX[i], s->Npad * s->sh.esize));
       HIPCHK(hipMalloc(&s->EV[i], s->Npad * s->sh.esize));
@@ -786,6 +792,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.EX_in = a.EX_in;
         pa.EV_in = a.EV_in;
         pa.Hflf_in = a.Hflf_in;
+        pa.Hwork = s->Hwork;
+        pa.cold_list = s->cold_list;
+        pa.cold_count = s->cold_list + s->Npad;
         pa.EX_out = a.EX_out;
         pa.EV_out = a.EV_out;
         pa.Hflf_out = a.Hflf_out;

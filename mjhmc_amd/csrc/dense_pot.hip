@@ -88,29 +88,48 @@ __device__ __forceinline__ void publish(PubWave& dst, int lane, const Tile& t) {
 // acc[r][i][c] += sum over all 512 k-rows of  M[k][128w + 4i + r] * B[k][c]
 //   M   : row-major [512][512] matrix in global memory (pre-scaled W or W^T)
 //   pub : the four waves' published B tiles (k-rows in accumulator layout)
+// The k-range is walked in 16 chunks of 16 k-pairs (one published block (ws, r) each).  With one wave
+// per SIMD nothing else hides the L2 latency of the A rows, so they are software-pipelined by hand:
+// chunk n+1's sixteen 16-byte A loads are issued (and fenced against sinking) before chunk n's 64 MFMAs
+// (4096 matrix-pipe cycles) start.
+__device__ __forceinline__ void a_chunk_load(const float* mlane, int chunk, f32x4 (&dst)[16]) {
+  const float* base = mlane + (size_t)(128 * (chunk >> 2) + (chunk & 3)) * kDim;
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    dst[q] = *reinterpret_cast<const f32x4*>(base + (size_t)(4 * ((q & 3) + 8 * (q >> 2))) * kDim);
+}
+
+__device__ __forceinline__ void chunk_mfma(const PubWave* pub, int chunk, int lane, const f32x4 (&a)[16], Tile& acc) {
+  const f32x4(*blk)[64] = pub[chunk >> 2][chunk & 3];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const f32x4 b4 = blk[q4][lane];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const f32x4 a4 = a[4 * q4 + qq];
+      acc.b[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[qq], acc.b[0], 0, 0, 0);
+      acc.b[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[qq], acc.b[1], 0, 0, 0);
+      acc.b[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[qq], acc.b[2], 0, 0, 0);
+      acc.b[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[qq], acc.b[3], 0, 0, 0);
+    }
+  }
+}
+
 __device__ __forceinline__ void gemm_512(const float* __restrict__ M, const PubWave* pub, int w, int c, int h, int lane,
                                          Tile& acc) {
   const float* mlane = M + (size_t)(16 * h) * kDim + 128 * w + 4 * c;
+  f32x4 a0[16], a1[16];
+  a_chunk_load(mlane, 0, a0);
 #pragma unroll 1
-  for (int ws = 0; ws < 4; ++ws) {
-    const float* mw = mlane + (size_t)(128 * ws) * kDim;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 b4 = pub[ws][r][q4][lane];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const int q = 4 * q4 + qq;
-          const int krow = 4 * ((q & 3) + 8 * (q >> 2)) + r;  // + 16h through mlane
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(mw + (size_t)krow * kDim);
-          acc.b[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[qq], acc.b[0], 0, 0, 0);
-          acc.b[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[qq], acc.b[1], 0, 0, 0);
-          acc.b[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[qq], acc.b[2], 0, 0, 0);
-          acc.b[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[qq], acc.b[3], 0, 0, 0);
-        }
-      }
-    }
+  for (int chunk = 0; chunk < 16; chunk += 2) {
+    a_chunk_load(mlane, chunk + 1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_mfma(pub, chunk, lane, a0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    a_chunk_load(mlane, chunk + 2 < 16 ? chunk + 2 : 15, a0);  // (the last one is a harmless re-read)
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_mfma(pub, chunk + 1, lane, a1, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -265,6 +284,54 @@ __global__ __launch_bounds__(256, 1) void pot_eval_kernel(const PotEvalArgs a, c
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cold-cache compaction.  A tile of 32 particles costs the same whether 1 or 32 of them need the
+// inverse-L trajectory, so the cold particles (5-60 % of the batch) are gathered into dense tiles
+// first: the F L F work stays proportional to the cold fraction, as in the reference (hmc_state.py:109-119).
+// ---------------------------------------------------------------------------------------------------
+__global__ void pot_cold_list_kernel(const float* __restrict__ Hflf_in, float* __restrict__ Hwork, int64_t N,
+                                     int64_t Npad, int* __restrict__ list, int* __restrict__ count,
+                                     const Control* ctl, unsigned long long* stats) {
+  if (ctl->failed) return;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Npad) return;
+  const float hc = Hflf_in[p];
+  Hwork[p] = hc;
+  const bool cold = (p < N) && !(hc == hc);
+  const unsigned long long m = __ballot(cold);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) {
+    base = atomicAdd(count, (int)__popcll(m));
+    atomicAdd(&stats[3], (unsigned long long)__popcll(m));
+  }
+  base = __shfl(base, 0);
+  if (cold) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+}
+
+__global__ __launch_bounds__(256, 1) void pot_flf_kernel(const PotJumpArgs a, const PotModel mdl) {
+  __shared__ Shared sh;
+  if (a.ctl->failed) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  const int ncold = *a.cold_count;
+  for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
+    const int slot = tile * kP + c;
+    const int64_t p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
+    Tile x, v, g;
+    tile_load(a.X_in, p, w, h, x);
+    tile_load(a.V_in, p, w, h, v);
+    tile_load(a.G_in, p, w, h, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v.b[r] = -v.b[r];
+    float ex = 0.f;
+    pot_trajectory(mdl, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &ex);
+    const float ev = pot_kinetic(sh, w, c, h, v);
+    if (w == 0 && h == 0) a.Hwork[p] = ex + ev;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // the jump kernel (MJHMC mode): one sampling_iteration attempt for a tile of 32 particles
 // ---------------------------------------------------------------------------------------------------
 template <bool REPLAY>
@@ -280,21 +347,9 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
     const float EX0 = a.EX_in[p], EV0 = a.EV_in[p], Hc = a.Hflf_in[p];
     const float H0 = EX0 + EV0;
     const bool warm = (Hc == Hc) || !alive;
-    // is any particle of the tile cold?  (wave-uniform after the ballot; all four waves agree)
-    const bool tile_cold = __ballot(!warm) != 0ull;
+    // H of the inverse-L proposal: cached, or integrated by pot_flf_kernel for the cold particles
+    const float Hflf = a.Hwork[p];
     Tile x, v, g;
-    float Hflf = Hc;
-    if (tile_cold) {  // inverse-L proposal F L F: only its H is needed (markov_jump_hmc.py:360,367)
-      tile_load(a.X_in, p, w, h, x);
-      tile_load(a.V_in, p, w, h, v);
-      tile_load(a.G_in, p, w, h, g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v.b[r] = -v.b[r];
-      float ex = 0.f;
-      pot_trajectory(mdl, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &ex);
-      const float ev = pot_kinetic(sh, w, c, h, v);
-      if (!warm) Hflf = ex + ev;
-    }
     tile_load(a.X_in, p, w, h, x);
     tile_load(a.V_in, p, w, h, v);
     tile_load(a.G_in, p, w, h, g);
@@ -347,7 +402,6 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
         nL += (k == 0);
         nF += (k == 1);
         nR += (k == 2);
-        nCold += warm ? 0u : 1u;
       }
       // scalars of the L and F successors; R's kinetic energy is filled in below
       a.EX_out[p] = (k == 0) ? EXL : EX0;
@@ -418,6 +472,10 @@ static int resident_cus() {
 }
 
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
+  (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
+  hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
+                     a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+  hipLaunchKernelGGL(pot_flf_kernel, dim3((unsigned)std::min<int64_t>(a.ntiles, resident_cus())), dim3(256), 0, st, a, mdl);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus());
   if (a.rexp && a.noise) hipLaunchKernelGGL(pot_jump_kernel<true>, dim3(grid), dim3(256), 0, st, a, mdl);
   else hipLaunchKernelGGL(pot_jump_kernel<false>, dim3(grid), dim3(256), 0, st, a, mdl);

@@ -27,6 +27,9 @@ struct PotJumpArgs {
   const float* EX_in;
   const float* EV_in;
   const float* Hflf_in;
+  float* Hwork;        // [Npad] H of the inverse-L proposal for this attempt (cached or freshly integrated)
+  int* cold_list;      // [Npad] compacted indices of the cold particles
+  int* cold_count;
   float* EX_out;
   float* EV_out;
   float* Hflf_out;
