@@ -64,7 +64,9 @@ typedef enum {
   MJHMC_E_SPARSE_CODE = 7
 } mjhmc_energy_kind;
 
-typedef enum { MJHMC_F64 = 0, MJHMC_F32 = 1 } mjhmc_dtype;  /* arithmetic type of state and force */
+/* arithmetic type of state and force.  BF16: bfloat16 state in HBM and as MFMA operands, float32
+ * accumulation and integrator registers (SPARSE_CODE only). */
+typedef enum { MJHMC_F64 = 0, MJHMC_F32 = 1, MJHMC_BF16 = 2 } mjhmc_dtype;
 
 /* Sampler families (mjhmc/samplers/markov_jump_hmc.py). */
 typedef enum {

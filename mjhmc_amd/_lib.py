@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('MJHMC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmjh
 
 # enums of include/mjhmc_hip.h
 E_ISO_GAUSS, E_DIAG_GAUSS, E_ROUGH_WELL, E_MM_GAUSS, E_FUNNEL_NEAL, E_FUNNEL_REF, E_PRODUCT_OF_T, E_SPARSE_CODE = range(8)
-F64, F32 = 0, 1
+F64, F32, BF16 = 0, 1, 2
 MODE_MJHMC, MODE_CONTROL, MODE_CTHMC = 0, 1, 2
 F_X, F_V, F_EX, F_EV, F_DEDX, F_HFLF, F_CACHE, F_DWELL, F_TRANS = range(9)
 ERR_NO_DEVICE = -4

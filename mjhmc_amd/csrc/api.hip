@@ -11,6 +11,7 @@
 
 #include "../../include/mjhmc_hip.h"
 #include "dense_pot.hpp"
+#include "dense_sic.hpp"
 #include "elementwise.hpp"
 
 using namespace mjhmc;
@@ -56,6 +57,12 @@ struct mjhmc_energy {
   float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
   PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3]}; }
   bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
+  void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32)
+  float sic_lambda = 0.f;
+  int sic_cauchy = 1;
+  SicModel sic_model() const { return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy}; }
+  bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
+  bool is_dense() const { return is_pot() || is_sic(); }
 };
 
 struct Shape {
@@ -99,6 +106,7 @@ struct mjhmc_sampler {
   double* rexp = nullptr;   // [3][N]
   double* runif = nullptr;  // [2N+1]
   void* scratch = nullptr;  // [N][pitch] scratch (dEdX reads)
+  bool download_f32 = false;  // bf16 state: the next download_cols source is a float32 matrix (dEdX)
   double eps = 1e-4, p_r = 0, beta = 1, p_flip = 0.5;
   int L = 5;
   uint64_t seed = 0, tick = 1;
@@ -109,6 +117,8 @@ struct mjhmc_sampler {
 };
 
 static size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s->sh.esize; }
+// per-particle scalars (EX, EV, H_flf): float64 for float64 state, float32 otherwise (bf16 state included)
+static size_t ssize(const mjhmc_sampler* s) { return s->dtype == MJHMC_F64 ? 8 : 4; }
 static size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_bytes(s); }
 
 static int pow2ceil(int v) {
@@ -307,6 +317,9 @@ static int upload_matrix(mjhmc_sampler* s, const double* host, void* dst) {
   if (s->dtype == MJHMC_F64)
     hipLaunchKernelGGL(to_particle_major<double>, grid, block, 0, s->stream, s->stage, (double*)dst, s->D, s->N,
                        s->sh.pitch);
+  else if (s->dtype == MJHMC_BF16)
+    hipLaunchKernelGGL(to_particle_major<__bf16>, grid, block, 0, s->stream, s->stage, (__bf16*)dst, s->D, s->N,
+                       s->sh.pitch);
   else
     hipLaunchKernelGGL(to_particle_major<float>, grid, block, 0, s->stream, s->stage, (float*)dst, s->D, s->N,
                        s->sh.pitch);
@@ -320,6 +333,9 @@ static int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_i
   dim3 grid((unsigned)((ncols + 31) / 32), (unsigned)((s->D + 31) / 32)), block(32, 8);
   if (s->dtype == MJHMC_F64)
     hipLaunchKernelGGL(to_dim_major<double>, grid, block, 0, s->stream, (const double*)src, dev_idx, s->stage, s->D,
+                       ncols, s->sh.pitch, rs, cs, off);
+  else if (s->dtype == MJHMC_BF16 && !s->download_f32)
+    hipLaunchKernelGGL(to_dim_major<__bf16>, grid, block, 0, s->stream, (const __bf16*)src, dev_idx, s->stage, s->D,
                        ncols, s->sh.pitch, rs, cs, off);
   else
     hipLaunchKernelGGL(to_dim_major<float>, grid, block, 0, s->stream, (const float*)src, dev_idx, s->stage, s->D,
@@ -372,8 +388,27 @@ static int run_eval_pot(mjhmc_sampler* s, const void* X, void* Gout, void* Eout,
   return 0;
 }
 
+static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen,
+                        void* EVout) {
+  SicEvalArgs a;
+  a.X = (const __bf16*)X;
+  a.G = (float*)Gout;  // float32 [Npad][1024]
+  a.E = (float*)Eout;
+  a.EV = (float*)EVout;
+  a.V = (const __bf16*)V;
+  a.V_gen = (__bf16*)Vgen;
+  a.N = s->N;
+  a.ntiles = s->Npad / 32;
+  a.first_pid = s->first_pid;
+  a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), 0u, 0u};
+  sic_launch_eval(a, s->en->sic_model(), s->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
   if (s->en->is_pot()) return run_eval_pot(s, X, Gout, Eout, V, Vgen, EVout);
+  if (s->en->is_sic()) return run_eval_sic(s, X, Gout, Eout, V, Vgen, EVout);
   return s->dtype == MJHMC_F64 ? run_eval_t<double>(s, X, Gout, Eout, V, Vgen, EVout)
                                : run_eval_t<float>(s, X, Gout, Eout, V, Vgen, EVout);
 }
@@ -506,6 +541,62 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
       }
       break;
     }
+    case MJHMC_E_SPARSE_CODE: {
+      // params = {n_patches, img, n_coeffs, lambda, cauchy, B[img*n_coeffs] (img, n_coeffs) row-major, Y[n_patches*img]}
+      if (nparams < 5) {
+        rc = fail(MJHMC_ERR_INVALID, "SPARSE_CODE expects {n_patches, img, n_coeffs, lambda, cauchy, B, Y}");
+        break;
+      }
+      const int P = (int)params[0], I = (int)params[1], C = (int)params[2];
+      if (P != 1 || I != kSicImg || C != kSicCoeffs || ndims != P * C) {
+        rc = fail(MJHMC_ERR_UNSUPPORTED,
+                  "SPARSE_CODE device kernel is built for n_patches=1, img_size=256, n_coeffs=1024 (BASELINE config 5)");
+        break;
+      }
+      if (nparams != (size_t)5 + (size_t)I * C + (size_t)P * I) {
+        rc = fail(MJHMC_ERR_INVALID, "SPARSE_CODE parameter vector has the wrong length");
+        break;
+      }
+      e->sic_lambda = (float)params[3];
+      e->sic_cauchy = params[4] != 0.0 ? 1 : 0;
+      const double* B = params + 5;
+      const double* Y = B + (size_t)I * C;
+      auto bf16_of = [](double v) -> uint16_t {  // round-to-nearest-even float32 -> bfloat16
+        float f = (float)v;
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+      };
+      std::vector<uint16_t> a1((size_t)64 * 2 * I * 8), a2((size_t)16 * 2 * C * 8);
+      for (int ks = 0; ks < 64; ++ks)
+        for (int h = 0; h < 2; ++h)
+          for (int i = 0; i < I; ++i)
+            for (int j = 0; j < 8; ++j) {
+              const int ws = ks >> 3, b = (ks >> 1) & 3, sx = ks & 1;
+              const int c = 128 * ws + 32 * b + 16 * sx + 8 * (j >> 2) + 4 * h + (j & 3);
+              a1[(((size_t)ks * 2 + h) * I + i) * 8 + j] = bf16_of(B[(size_t)i * C + c]);
+            }
+      for (int ks = 0; ks < 16; ++ks)
+        for (int h = 0; h < 2; ++h)
+          for (int c = 0; c < C; ++c)
+            for (int j = 0; j < 8; ++j) {
+              const int ws = ks >> 1, sx = ks & 1;
+              const int i = 32 * ws + 16 * sx + 8 * (j >> 2) + 4 * h + (j & 3);
+              a2[(((size_t)ks * 2 + h) * C + c) * 8 + j] = bf16_of(B[(size_t)i * C + c]);
+            }
+      std::vector<float> yv(I);
+      for (int i = 0; i < I; ++i) yv[i] = (float)Y[i];
+      const void* src[3] = {a1.data(), a2.data(), yv.data()};
+      const size_t bytes[3] = {a1.size() * 2, a2.size() * 2, (size_t)I * 4};
+      for (int i = 0; i < 3 && !rc; ++i) {
+        if (hipMalloc(&e->sic[i], bytes[i]) != hipSuccess ||
+            hipMemcpy(e->sic[i], src[i], bytes[i], hipMemcpyHostToDevice) != hipSuccess)
+          rc = fail(MJHMC_ERR_HIP, "allocating SPARSE_CODE parameters failed");
+      }
+      break;
+    }
     default:
       rc = fail(MJHMC_ERR_UNSUPPORTED, "energy kind not implemented in this build");
   }
@@ -522,6 +613,8 @@ int mjhmc_energy_destroy(mjhmc_energy* e) {
   if (e->dev64) (void)hipFree(e->dev64);
   if (e->dev32) (void)hipFree(e->dev32);
   for (float* q : e->pot)
+    if (q) (void)hipFree(q);
+  for (void* q : e->sic)
     if (q) (void)hipFree(q);
   delete e;
   return 0;
@@ -550,7 +643,10 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
                          const double* Xinit, const double* Vinit, uint64_t seed, int mode, mjhmc_sampler** out) {
   if (!ctx || !e || !out || !Xinit) return fail(MJHMC_ERR_INVALID, "NULL argument");
   if (nparticles < 1) return fail(MJHMC_ERR_INVALID, "nparticles must be >= 1");
-  if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
+  if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
+    return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
+  if ((dtype == MJHMC_BF16) != e->is_sic())
+    return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
   if (mode < MJHMC_MODE_MJHMC || mode > MJHMC_MODE_CTHMC) return fail(MJHMC_ERR_INVALID, "unknown sampler mode");
   if (first_particle_id < 0 || first_particle_id + nparticles > 0xFFFFFFFFLL)
     return fail(MJHMC_ERR_INVALID, "global particle ids must fit 32 bits");
@@ -572,6 +668,12 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs in float32, MJHMC mode (the reference evaluates it in float32)");
     }
     s->sh = Shape{0, 0, kPotDim, kPotDim / 4, 4};
+  } else if (e->is_sic()) {
+    if (mode != MJHMC_MODE_MJHMC) {
+      delete s;
+      return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE runs in MJHMC mode");
+    }
+    s->sh = Shape{0, 0, kSicCoeffs, kSicCoeffs / 8, 2};
   } else {
     rc = pick_shape(s->D, dtype, &s->sh);
   }
@@ -590,17 +692,19 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       if (e->is_pot()) {
         HIPCHK(hipMalloc(&s->Gbuf[i], mb));
         HIPCHK(hipMemsetAsync(s->Gbuf[i], 0, mb, s->stream));
+      }
+      if (e->is_dense()) {
         if (!s->Hwork) {
           HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * sizeof(float)));
           HIPCHK(hipMalloc((void**)&s->cold_list, (s->Npad + 1) * sizeof(int)));
         }
       }
-      HIPCHK(hipMalloc(&s->EX[i], s->Npad * s->sh.esize));
-      HIPCHK(hipMalloc(&s->EV[i], s->Npad * s->sh.esize));
-      HIPCHK(hipMalloc(&s->Hflf[i], s->Npad * s->sh.esize));
-      HIPCHK(hipMemsetAsync(s->EX[i], 0, s->Npad * s->sh.esize, s->stream));
-      HIPCHK(hipMemsetAsync(s->EV[i], 0, s->Npad * s->sh.esize, s->stream));
-      HIPCHK(hipMemsetAsync(s->Hflf[i], 0xFF, s->Npad * s->sh.esize, s->stream));  // all-ones = NaN = cold
+      HIPCHK(hipMalloc(&s->EX[i], s->Npad * ssize(s)));
+      HIPCHK(hipMalloc(&s->EV[i], s->Npad * ssize(s)));
+      HIPCHK(hipMalloc(&s->Hflf[i], s->Npad * ssize(s)));
+      HIPCHK(hipMemsetAsync(s->EX[i], 0, s->Npad * ssize(s), s->stream));
+      HIPCHK(hipMemsetAsync(s->EV[i], 0, s->Npad * ssize(s), s->stream));
+      HIPCHK(hipMemsetAsync(s->Hflf[i], 0xFF, s->Npad * ssize(s), s->stream));  // all-ones = NaN = cold
     }
     HIPCHK(hipMalloc((void**)&s->dwell, s->Npad * sizeof(double)));
     HIPCHK(hipMemsetAsync(s->dwell, 0, s->Npad * sizeof(double), s->stream));
@@ -648,7 +752,7 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
 int mjhmc_checkpoint(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
-  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * s->sh.esize, db = (size_t)s->Npad * sizeof(double);
+  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
   const size_t sizes[6] = {mb, mb, vb, vb, vb, db};
   const void* src[6] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell};
   for (int i = 0; i < 6; ++i) {
@@ -664,7 +768,7 @@ int mjhmc_restore(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   if (!s->ck_valid) return fail(MJHMC_ERR_INVALID, "no checkpoint taken");
   HIPCHK(hipSetDevice(s->ctx->device));
-  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * s->sh.esize, db = (size_t)s->Npad * sizeof(double);
+  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
   const size_t sizes[6] = {mb, mb, vb, vb, vb, db};
   s->Xcur = s->Xbuf[0];
   void* dst[6] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell};
@@ -683,7 +787,7 @@ int mjhmc_advance_tick(mjhmc_sampler* s, int64_t n) {
 int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
-  HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * s->sh.esize, s->stream));
+  HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
   return 0;
 }
 
@@ -820,6 +924,43 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.key = a.key;
         pot_launch_jump(pa, s->en->pot_model(), s->stream);
       }
+    } else if (s->en->is_sic()) {
+      if constexpr (sizeof(T) == 4) {
+        SicJumpArgs sa;
+        sa.X_in = (const __bf16*)xin;
+        sa.V_in = (const __bf16*)s->Vbuf[vi];
+        sa.X_out = (__bf16*)xo;
+        sa.V_out = (__bf16*)s->Vbuf[vi ^ 1];
+        sa.EX_in = a.EX_in;
+        sa.EV_in = a.EV_in;
+        sa.Hflf_in = a.Hflf_in;
+        sa.Hwork = s->Hwork;
+        sa.cold_list = s->cold_list;
+        sa.cold_count = s->cold_list + s->Npad;
+        sa.EX_out = a.EX_out;
+        sa.EV_out = a.EV_out;
+        sa.Hflf_out = a.Hflf_out;
+        sa.dwell = a.dwell;
+        sa.dwell_ring = a.dwell_ring;
+        sa.trans = a.trans;
+        sa.noise = (const __bf16*)a.noise;
+        sa.rexp = a.rexp;
+        sa.ctl = a.ctl;
+        sa.stats = a.stats;
+        sa.N = a.N;
+        sa.Npad = a.Npad;
+        sa.ntiles = a.Npad / 32;
+        sa.first_pid = a.first_pid;
+        sa.L = a.L;
+        sa.iter = a.iter;
+        sa.eps = a.eps;
+        sa.chalf = a.chalf;
+        sa.r_keep = a.r_keep;
+        sa.r_mix = a.r_mix;
+        sa.p_r = a.p_r;
+        sa.key = a.key;
+        sic_launch_jump(sa, s->en->sic_model(), s->stream);
+      }
     } else {
       TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
     }
@@ -931,6 +1072,13 @@ int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
       const void* src = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       if (field == MJHMC_F_DEDX && s->en->is_pot()) {
         src = s->Gbuf[s->vcur];
+      } else if (field == MJHMC_F_DEDX && s->en->is_sic()) {
+        if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, (size_t)s->Npad * kSicCoeffs * sizeof(float)));
+        TRY(run_eval(s, s->Xcur, s->scratch, nullptr, nullptr, nullptr, nullptr));
+        s->download_f32 = true;
+        const int rc = download_cols(s, s->scratch, nullptr, s->N, (double*)host_dst, mat, s->N, 1, 0, true);
+        s->download_f32 = false;
+        return rc;
       } else if (field == MJHMC_F_DEDX) {
         if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, mat_bytes(s)));
         TRY(run_eval(s, s->Xcur, s->scratch, nullptr, nullptr, nullptr, nullptr));
@@ -980,7 +1128,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       TRY(upload_matrix(s, (const double*)host_src, dst));
       TRY(run_eval(s, s->Xcur, s->Gbuf[s->vcur], s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
-      HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * s->sh.esize, s->stream));
+      HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
     }
@@ -1096,7 +1244,9 @@ int mjhmc_sync(mjhmc_sampler* s) {
 
 int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E_out, double* dEdX_out) {
   if (!e || !X || n < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
-  if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
+  if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
+    return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
+  if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE evaluates with BF16 state");
   HIPCHK(hipSetDevice(e->ctx->device));
   // a throw-away sampler-shaped workspace keeps one code path for re-tiling and evaluation
   mjhmc_sampler w;
@@ -1110,6 +1260,8 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   if (e->is_pot()) {
     if (dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T evaluates in float32");
     w.sh = Shape{0, 0, kPotDim, kPotDim / 4, 4};
+  } else if (e->is_sic()) {
+    w.sh = Shape{0, 0, kSicCoeffs, kSicCoeffs / 8, 2};
   } else {
     TRY(pick_shape(w.D, dtype, &w.sh));
   }
@@ -1119,11 +1271,12 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
     const size_t mb = mat_bytes(&w);
     HIPCHK(hipMalloc(&Xd, mb));
     HIPCHK(hipMemsetAsync(Xd, 0, mb, w.stream));
-    if (dEdX_out) HIPCHK(hipMalloc(&Gd, mb));
-    if (E_out) HIPCHK(hipMalloc(&Ed, w.Npad * w.sh.esize));
+    if (dEdX_out) HIPCHK(hipMalloc(&Gd, e->is_sic() ? (size_t)w.Npad * kSicCoeffs * sizeof(float) : mb));
+    if (E_out) HIPCHK(hipMalloc(&Ed, w.Npad * ssize(&w)));
     TRY(upload_matrix(&w, X, Xd));
     TRY(run_eval(&w, Xd, Gd, Ed, nullptr, nullptr, nullptr));
     if (E_out) TRY(read_vec(&w, Ed, E_out, (size_t)n * sizeof(double)));
+    w.download_f32 = e->is_sic();
     if (dEdX_out) TRY(download_cols(&w, Gd, nullptr, n, dEdX_out, (size_t)w.D * n, n, 1, 0, true));
     HIPCHK(hipStreamSynchronize(w.stream));
     return 0;

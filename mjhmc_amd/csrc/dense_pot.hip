@@ -360,39 +360,10 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
 
     // rates, waiting times, first minimum: lanes 0..31 of wave 0, one particle each
     if (w == 0 && h == 0) {
-      const double l_rate = sqrt(exp((double)(H0 - HL)));
-      const double flf_rate = sqrt(exp((double)(H0 - Hflf)));
-      const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
-      const double f_rate = flf_rate - mn;
-      const double r_rate = a.p_r;
-      double eL, eF, eR;
       const uint32_t pid = (uint32_t)(a.first_pid + (alive ? p : 0));
-      if constexpr (REPLAY) {
-        const int64_t pp = alive ? p : 0;
-        eL = a.rexp[pp];
-        eF = a.rexp[a.N + pp];
-        eR = a.rexp[2 * a.N + pp];
-      } else {
-        const u32x4 wq = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
-        const u32x4 qq = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
-        eL = -log(u53(wq.w0, wq.w1));
-        eF = -log(u53(wq.w2, wq.w3));
-        eR = -log(u53(qq.w0, qq.w1));
-      }
-      const bool bad = !(isfinite(l_rate) && isfinite(f_rate) && isfinite(r_rate));
-      const double dL = l_rate == 0.0 ? __builtin_huge_val() : (1.0 / l_rate) * eL;
-      const double dF = f_rate == 0.0 ? __builtin_huge_val() : (1.0 / f_rate) * eF;
-      const double dR = r_rate == 0.0 ? __builtin_huge_val() : (1.0 / r_rate) * eR;
-      int k = 0;
-      double best = dL;
-      if (!(best != best) && (dF < best || dF != dF)) {
-        k = 1;
-        best = dF;
-      }
-      if (!(best != best) && (dR < best || dR != dR)) {
-        k = 2;
-        best = dR;
-      }
+      double best;
+      bool bad;
+      const int k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
       any_bad |= (bad && alive);
       sh.move[c] = k;
       a.dwell[p] = best;

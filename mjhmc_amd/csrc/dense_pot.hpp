@@ -59,6 +59,60 @@ struct PotEvalArgs {
   RngKey key;
 };
 
+// Rates, waiting times and first minimum of ONE particle, evaluated serially by one lane (the dense
+// kernels run it on 32 lanes of one wave, one particle each; ~1e3 instructions against ~1e6 cycles of
+// trajectory).  markov_jump_hmc.py:366-396, utils.py:15-49.  Returns k (0 L, 1 F, 2 R).
+template <bool REPLAY>
+__device__ __forceinline__ int dense_decide(float H0, float HL, float Hflf, double p_r, uint32_t pid, int64_t p,
+                                            int64_t N, const double* rexp, const RngKey& key, double& dwell, bool& bad) {
+  const double l_rate = sqrt(exp((double)(H0 - HL)));
+  const double flf_rate = sqrt(exp((double)(H0 - Hflf)));
+  const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
+  const double f_rate = flf_rate - mn;
+  const double r_rate = p_r;
+  double eL, eF, eR;
+  if constexpr (REPLAY) {
+    eL = rexp[p];
+    eF = rexp[N + p];
+    eR = rexp[2 * N + p];
+  } else {
+    const u32x4 wq = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpLF, key.k0, key.k1);
+    const u32x4 qq = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
+    eL = -log(u53(wq.w0, wq.w1));
+    eF = -log(u53(wq.w2, wq.w3));
+    eR = -log(u53(qq.w0, qq.w1));
+  }
+  bad = !(isfinite(l_rate) && isfinite(f_rate) && isfinite(r_rate));
+  const double dL = l_rate == 0.0 ? __builtin_huge_val() : (1.0 / l_rate) * eL;
+  const double dF = f_rate == 0.0 ? __builtin_huge_val() : (1.0 / f_rate) * eF;
+  const double dR = r_rate == 0.0 ? __builtin_huge_val() : (1.0 / r_rate) * eR;
+  int k = 0;
+  double best = dL;
+  if (!(best != best) && (dF < best || dF != dF)) {
+    k = 1;
+    best = dF;
+  }
+  if (!(best != best) && (dR < best || dR != dR)) {
+    k = 2;
+    best = dR;
+  }
+  dwell = best;
+  return k;
+}
+
+// float32 Box-Muller pair from the same Philox words as normal_pair (the float64 version costs ~4x
+// the instructions; for float32 / bfloat16 state its extra digits are rounded away anyway)
+__device__ __forceinline__ void normal_pair_f32(const RngKey& k, uint32_t pid, uint32_t pair, float& z0, float& z1) {
+  const u32x4 w = philox4x32_10(pid, k.tick_lo, k.tick_hi, pair, k.k0, k.k1);
+  const float u1 = (float)u53(w.w0, w.w1);
+  const float u2 = (float)u53(w.w2, w.w3);
+  const float r = sqrtf(-2.0f * logf(u1 > 0.f ? u1 : 1e-38f));
+  float s, c;
+  sincospif(2.0f * u2, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_eval(const PotEvalArgs& a, const PotModel& mdl, hipStream_t st);
 

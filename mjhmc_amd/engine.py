@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import check, ptr, as_f64
 
 _DTYPES = {'float64': _lib.F64, 'f64': _lib.F64, np.float64: _lib.F64, 'float32': _lib.F32, 'f32': _lib.F32,
-           np.float32: _lib.F32}
+           np.float32: _lib.F32, 'bfloat16': _lib.BF16, 'bf16': _lib.BF16}
 
 _contexts = {}
 
@@ -19,7 +19,7 @@ def dtype_code(dtype):
     try:
         return _DTYPES[dtype]
     except KeyError:
-        raise ValueError('dtype must be float64 or float32, got %r' % (dtype,))
+        raise ValueError('dtype must be float64, float32 or bfloat16, got %r' % (dtype,))
 
 
 class Context(object):

@@ -286,3 +286,46 @@ class ProductOfT(Distribution):
     def __hash__(self):
         return hash((self.ndims, self.nbasis, hash(tuple(self.nu)), hash(tuple(self.weights.ravel())),
                      hash(tuple(self.bias.ravel()))))
+
+
+class SparseImageCode(Distribution):
+    """Posterior over sparse-coding coefficients (mjhmc/misc/tf_distributions.py:204-284):
+    E = mean_p 1/2 |y_p - B a_p|^2 + lambda * sum log(1 + a^2)   (Cauchy; ``cauchy=False``: lambda * sum |a|).
+
+    The reference reads ``distr_data/dump_{n_basis}.pkl`` (basis (256, n_basis) and image patches), which is
+    not part of the reference checkout; pass ``basis`` (img_size, n_coeffs) and ``imgs`` (img_size, >= n_patches)
+    instead.  State rows are patch-major (row p * n_coeffs + c), which is what the reference's reshape yields for
+    one active column.  The device kernel (bf16 state, bf16 MFMA operands, fp32 accumulation) covers
+    n_patches = 1, img_size = 256, n_coeffs = 1024 -- BASELINE.json configs[4]."""
+
+    def __init__(self, n_patches=9, n_batches=10, cauchy=True, n_basis=1024, basis=None, imgs=None, init=None):
+        self.max_n_particles = 50
+        self.lmbda = 0.01
+        if basis is None or imgs is None:
+            raise IOError('distr_data/dump_%d.pkl is not shipped with the reference: pass basis= and imgs=' % n_basis)
+        self.basis = np.asarray(basis, dtype=np.float64)
+        self.imgs = np.asarray(imgs, dtype=np.float64)
+        self.img_size, self.n_coeffs = self.basis.shape
+        assert self.n_coeffs == n_basis
+        self.n_patches = n_patches
+        self.cauchy = cauchy
+        self.patches = self.imgs[:, :n_patches].T            # (n_patches, img_size)
+        self._init = init
+        self.state_dtype = 'bfloat16'
+        self.backend = 'hip-mfma-bf16'
+        super(SparseImageCode, self).__init__(ndims=n_patches * self.n_coeffs, nbatch=n_batches)
+
+    def device_energy(self):
+        params = np.concatenate([[float(self.n_patches), float(self.img_size), float(self.n_coeffs), self.lmbda,
+                                  1.0 if self.cauchy else 0.0], self.basis.ravel(), self.patches.ravel()])
+        return (_lib.E_SPARSE_CODE, params)
+
+    def gen_init_X(self):
+        if self._init is not None:
+            self.Xinit = np.asarray(self._init, dtype=np.float64)
+        else:
+            self.Xinit = 0.1 * np.random.randn(self.ndims, self.nbatch)
+
+    def __hash__(self):
+        return hash((hash(self.imgs.tobytes()), hash(self.basis.tobytes()), hash(self.lmbda), hash(self.n_patches),
+                     self.n_coeffs))

@@ -537,3 +537,80 @@ def test_pot_iterations_vs_oracle(ndims, N, eps, L, beta):
         o.state.shadow_ok[:] = ~np.isnan(hflf)
         o.state.shadow.EX[0, :] = np.nan_to_num(hflf)
         o.state.shadow.EV[0, :] = 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# SparseImageCode: bf16 state / bf16 MFMA operands / fp32 accumulate (parity unpinned -> oracle in float64)
+# ---------------------------------------------------------------------------------------------
+def sic_problem(seed=0):
+    """Synthetic dictionary: column-normalised B (256, 1024), patch y = B a0 + noise."""
+    rs = np.random.RandomState(seed)
+    B = rs.randn(256, 1024)
+    B /= np.linalg.norm(B, axis=0, keepdims=True)
+    a0 = rs.randn(1024) * (rs.rand(1024) < 0.05)
+    y = B.dot(a0) + 0.1 * rs.randn(256)
+    return B, y.reshape(256, 1), a0
+
+
+def to_bf16(a):
+    """round-to-nearest-even float64 -> bfloat16 -> float64 (what the device stores)"""
+    u = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize('cauchy', [True, False])
+def test_sic_energy_and_gradient(cauchy):
+    from mjhmc_amd.misc.distributions import SparseImageCode
+    B, y, a0 = sic_problem()
+    n = 70
+    rs = np.random.RandomState(1)
+    X = to_bf16(a0[:, None] + 0.3 * rs.randn(1024, n))           # representable in the state dtype
+    d = SparseImageCode(n_patches=1, n_batches=n, cauchy=cauchy, n_basis=1024, basis=B, imgs=y, init=X)
+    o = orc.SparseImageCode(to_bf16(B), y.T, lmbda=0.01, cauchy=cauchy)   # the dictionary is an MFMA operand: bf16
+    E, G = d.E(X), d.dEdX(X)
+    Eo, Go = o.E_val(X), o.dEdX_val(X)
+    assert E.shape == (1, n) and G.shape == (1024, n)
+    assert np.allclose(E, Eo, rtol=2e-3), np.abs(E / Eo - 1).max()
+    # gradient: the residual is rounded to bf16 before the second GEMM
+    assert np.abs(G - Go).max() < 2e-2 * np.abs(Go).max()
+
+
+def test_sic_iterations_vs_oracle():
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import SparseImageCode
+    B, y, a0 = sic_problem()
+    N, eps, L, beta, seed = 96, 0.05, 10, 0.2, 5
+    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(2).randn(1024, N))
+    d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y, init=X0)
+    en = orc.SparseImageCode(to_bf16(B), y.T, lmbda=0.01, cauchy=True)
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=seed, resample=False)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(seed, np.arange(N)))
+    V0 = s.state.V
+    assert np.abs(V0 - o.state.V).max() < 2e-2                    # bf16-rounded tick-0 momentum
+    assert np.array_equal(V0, to_bf16(V0))
+    o.state.V[:] = V0
+    o.state.refresh_EV()
+    assert np.allclose(s.state.EX, o.state.EX, rtol=2e-3) and np.allclose(s.state.EV, o.state.EV, rtol=1e-5)
+    agree = []
+    for t in range(5):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        tr, tro = s._dev.read(8), o.last_transition
+        same = tr == tro
+        agree.append(same.mean())
+        moved = same & (tr == 0)
+        # bf16 operands: positions agree to a few bf16 ulps of the trajectory's scale
+        assert np.abs(s.state.X[:, moved] - o.state.X[:, moved]).max() < 3e-2 * max(1.0, np.abs(o.state.X).max()), t
+        assert np.allclose(s.state.EX[0, moved], o.state.EX[0, moved], rtol=2e-2, atol=0.5), t
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        Xd, Vd = s.state.X, s.state.V
+        assert np.array_equal(Xd, to_bf16(Xd)) and np.array_equal(Vd, to_bf16(Vd))
+        hflf = s._dev.read(5)
+        o.state.X[:], o.state.V[:] = Xd, Vd
+        o.state.refresh_EX(); o.state.refresh_EV(); o.state.refresh_grad()
+        o.state.shadow_ok[:] = ~np.isnan(hflf)
+        o.state.shadow.EX[0, :] = np.nan_to_num(hflf)
+        o.state.shadow.EV[0, :] = 0.0
+    assert np.mean(agree) > 0.9, agree
