@@ -36,6 +36,10 @@ WORKLOADS = {
     # reference checkout -> weights from the reference's init_weights recipe)
     'c3': dict(name='C3 ProductOfT ndims=nbasis=512 nparticles=100000/GPU L=20 fp32', kind='pot', D=512, N=100000,
                L=20, eps=0.05, beta=0.1, dtype='float32', params=None),
+    # BASELINE.json configs[4]: 200000 particles over 8 GPUs = 25000 per GPU; synthetic dictionary (the
+    # reference's distr_data/dump_1024.pkl is not in its checkout)
+    'c5': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=25000/GPU L=25 bf16 state / fp32 accumulate',
+               kind='sic', D=1024, N=25000, L=25, eps=0.05, beta=0.1, dtype='bfloat16', params=None),
     # BASELINE.json configs[0] (README shape; plumbing)
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
@@ -52,8 +56,20 @@ def pot_model(D):
     return W + np.eye(D), lognu
 
 
+def sic_model():
+    """column-normalised random dictionary (256, 1024), patch y = B a0 + 0.1 noise, a0 5 % sparse"""
+    rs = np.random.RandomState(0)
+    B = rs.randn(256, 1024)
+    B /= np.linalg.norm(B, axis=0, keepdims=True)
+    a0 = rs.randn(1024) * (rs.rand(1024) < 0.05)
+    y = B.dot(a0) + 0.1 * rs.randn(256)
+    return B, y, a0
+
+
 def initial_state(w, rank):
     rng = np.random.RandomState(1000 + rank)
+    if w['kind'] == 'sic':
+        return sic_model()[2][:, None] + 0.1 * rng.randn(w['D'], w['N'])
     if w['kind'] == 'pot':
         # gen_init_X of ProductOfT (distributions.py:437-445): Student-t draws mapped through inv(W)
         W, lognu = pot_model(w['D'])
@@ -79,9 +95,13 @@ def cpu_baseline(w, seconds_target=15.0):
     n = min(w['N'], 4000 if w['D'] >= 256 else 20000)
     rng = np.random.RandomState(7)
     threads = 1
-    if w['kind'] == 'pot':
-        W, lognu = pot_model(w['D'])
-        en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float32)   # float32 force, float64 state: as the reference
+    if w['kind'] in ('pot', 'sic'):
+        if w['kind'] == 'pot':
+            W, lognu = pot_model(w['D'])
+            en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float32)   # float32 force, float64 state: as the reference
+        else:
+            B, y, _ = sic_model()
+            en = orc.SparseImageCode(B, y.reshape(1, -1), lmbda=0.01, cauchy=True)
         X0 = initial_state(dict(w, N=n), 7)
         try:
             from threadpoolctl import threadpool_info
@@ -134,11 +154,15 @@ def main():
 
     from mjhmc_amd import engine, _lib
     ctx = engine.context(local_rank)
-    kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T}[w['kind']]
+    kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T,
+            'sic': _lib.E_SPARSE_CODE}[w['kind']]
     params = w['params']
     if w['kind'] == 'pot':
         W, lognu = pot_model(w['D'])
         params = np.concatenate([[float(w['D'])], W.ravel(), np.exp(lognu), np.zeros(w['D'])])
+    if w['kind'] == 'sic':
+        B, y, _ = sic_model()
+        params = np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), y])
     en = engine.DeviceEnergy(ctx, kind, w['D'], params)
     X0 = initial_state(w, rank)
     smp = engine.DeviceSampler(en, X0, seed=20261002, first_particle_id=rank * w['N'], dtype=w['dtype'])
@@ -201,14 +225,16 @@ def main():
             traffic = json.load(open(tfile)).get(args.workload)
         n_l = sum(s.l for s in stats)
         n_cold = sum(s.n_cold for s in stats)
-        if w['kind'] == 'pot':
-            # dense energy: the bound is the fp32 matrix pipe.  Algorithmic flops from the exact counters
-            # (SURVEY.md 8d): dEdX_evals * 4*D*K + E_evals * 2*D*K
-            DK = float(w['D']) * w['D']
+        if w['kind'] in ('pot', 'sic'):
+            # dense energy: the bound is the matrix pipe (fp32 for ProductOfT, bf16 for SparseImageCode).
+            # Algorithmic flops from the exact counters: dEdX_evals * 4*D*K + E_evals * 2*D*K
+            DK = float(w['D']) * (w['D'] if w['kind'] == 'pot' else 256)
+            peak = 157.3 if w['kind'] == 'pot' else 2500.0
             flops = sum(s.dEdX_evals * 4 * DK + s.E_evals * 2 * DK for s in stats) / len(stats)
             achieved_tf = flops / (kern_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': achieved_tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': achieved_tf / 157.3,
-                    'traffic': None, 'kernel': 'pot_jump_kernel', 'avg_launch_ms': kern_ms,
+            roof = {'bound': 'mfma', 'achieved': achieved_tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved_tf / peak,
+                    'traffic': None, 'kernel': 'pot_jump_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel',
+                    'avg_launch_ms': kern_ms,
                     'launches_timed': tim['n_jump_launches'], 'algorithmic_flops_per_launch': flops}
         else:
             roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -222,7 +248,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed * 1e3 / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64' if esize == 8 else 'f32', 'data': 'synthetic',
+            'dtype': {'float64': 'f64', 'float32': 'f32', 'bfloat16': 'bf16 state / f32 accumulate'}[w['dtype']],
+            'data': 'synthetic',
             'config': {'workload': w['name'], 'ndims': w['D'], 'nparticles_per_gpu': w['N'], 'L': w['L'],
                        'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
                        'particles_x_L_per_s': w['N'] * w['L'] * args.steps * world / elapsed,

@@ -42,6 +42,8 @@ class HMCBase(object):
         self._seed, self._dtype, self._device, self._Vinit = seed, dtype, device, Vinit
         self._comm, self._plan = comm, None      # mjhmc_amd.parallel.Comm: shard particle columns over ranks
         self._pending = np.zeros(6, dtype=np.int64)  # local l, f, r, fl, E, dEdX increments not yet reduced
+        self._acc_evals = np.zeros(2, dtype=np.int64)   # E / dEdX evaluations of the iteration in flight (retries included)
+        self._iter_evals = []                           # per committed iteration: (E, dEdX) evaluations, local
         self._dev = None
         if not isinstance(self, ContinuousTimeHMC):
             if not isinstance(distribution, Distribution):
@@ -109,9 +111,21 @@ class HMCBase(object):
     def _account(self, st):
         self._pending[4] += st.E_evals
         self._pending[5] += st.dEdX_evals
+        self._acc_evals += (st.E_evals, st.dEdX_evals)
 
     def _commit(self, st):
         self._pending[:4] += (st.l, st.f, st.r, st.fl)
+        self._iter_evals.append(self._acc_evals.copy())
+        self._acc_evals[:] = 0
+
+    def eval_trace(self, n_last):
+        """(E_evals, dEdX_evals) per iteration for the last ``n_last`` committed iterations, summed over
+        ranks: the increments of Distribution.E_count / dEdX_count a per-step host loop would observe
+        (mjhmc/misc/autocor.py:246-248)."""
+        tr = np.array(self._iter_evals[-n_last:], dtype=np.int64).reshape(-1, 2)
+        if self._comm is not None:
+            tr = self._comm.allreduce_ints(tr.ravel(), 'sum').reshape(-1, 2)
+        return tr
 
     def _publish(self):
         """Fold this call's integer bookkeeping into the public counters (summed over ranks)."""
