@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -147,7 +148,8 @@ static int pick_shape(int D, int dtype, Shape* out) {
     G = 1;
   } else {
     C = 4;
-    G = pow2ceil((s.CH + 3) / 4);
+    if (const char* force = std::getenv("MJHMC_CHUNKS_PER_LANE")) C = std::atoi(force) == 8 ? 8 : 4;  // perf experiments
+    G = pow2ceil((s.CH + C - 1) / C);
     if (G > 64) {
       C = 8;
       G = pow2ceil((s.CH + 7) / 8);
