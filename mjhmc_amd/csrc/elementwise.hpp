@@ -102,7 +102,9 @@ __device__ __forceinline__ float swap32_sum(float v) {
   return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 
-// sum over the lanes of a group (G = 2^k <= 64, groups aligned); every lane gets the same bits
+// sum over the lanes of a group (G = 2^k <= 64, groups aligned); every lane gets the same bits.
+// (A branch-free form that always runs all six levels and selects zeros was measured: slower, the
+// permlane swaps cost more than the wave-uniform branches they replace.)
 template <typename T>
 __device__ __forceinline__ T group_sum(T v, int G) {
   if (G > 1) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
@@ -120,8 +122,13 @@ __device__ __forceinline__ T group_lane(T v, const LaneMap& m, int r) {
   return __shfl(v, m.lane0 + r);
 }
 
+// value of the group's lane 0.  Groups of <= 4 lanes sit inside one quad: a DPP quad_perm broadcast
+// (VALU, no LDS crossbar round trip); wider groups go through ds_bpermute.
 template <typename T>
 __device__ __forceinline__ T group_bcast0(T v, const LaneMap& m) {
+  if (m.G == 1) return v;
+  if (m.G == 2) return dpp_mov<0xA0>(v);  // quad_perm [0,0,2,2]
+  if (m.G == 4) return dpp_mov<0x00>(v);  // quad_perm [0,0,0,0]
   return __shfl(v, m.lane0);
 }
 
@@ -295,7 +302,7 @@ struct FunnelNealF {
   __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
     T s = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += (dim_of<T, E>(m, e) == 0) ? T(0) : x[e] * x[e];
+    for (int e = 0; e < E; ++e) s += (e == 0 && m.j == 0) ? T(0) : x[e] * x[e];  // only (lane 0, element 0) is dim 0
     Ctx c;
     c.S = group_sum(s, m.G);
     c.x0 = group_bcast0(x[0], m);
@@ -303,8 +310,8 @@ struct FunnelNealF {
     return c;
   }
   template <int E>
-  __device__ __forceinline__ T grad(T xe, int, int d, const Ctx& c, const Local<E>&) const {
-    return (d == 0) ? (c.x0 * inv_s2 - T(0.5) * c.ex * c.S + half_dm1) : xe * c.ex;
+  __device__ __forceinline__ T grad(T xe, int e, int d, const Ctx& c, const Local<E>&) const {
+    return (e == 0 && d == 0) ? (c.x0 * inv_s2 - T(0.5) * c.ex * c.S + half_dm1) : xe * c.ex;
   }
   template <int E>
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
@@ -331,7 +338,7 @@ struct FunnelRefF {
   __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
     T s = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += (dim_of<T, E>(m, e) == 0) ? T(0) : x[e] * x[e];
+    for (int e = 0; e < E; ++e) s += (e == 0 && m.j == 0) ? T(0) : x[e] * x[e];  // only (lane 0, element 0) is dim 0
     Ctx c;
     c.S = group_sum(s, m.G);
     c.x0 = group_bcast0(x[0], m);
@@ -339,8 +346,8 @@ struct FunnelRefF {
     return c;
   }
   template <int E>
-  __device__ __forceinline__ T grad(T xe, int, int d, const Ctx& c, const Local<E>&) const {
-    return (d == 0) ? (T(-2) * dm1 * c.x0 * inv_s2 + c.ex * c.S) : T(-2) * xe * c.ex;
+  __device__ __forceinline__ T grad(T xe, int e, int d, const Ctx& c, const Local<E>&) const {
+    return (e == 0 && d == 0) ? (T(-2) * dm1 * c.x0 * inv_s2 + c.ex * c.S) : T(-2) * xe * c.ex;
   }
   template <int E>
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
