@@ -56,7 +56,8 @@ struct mjhmc_energy {
   void* dev64 = nullptr;
   void* dev32 = nullptr;
   float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
-  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3]}; }
+  int pot_dim = kPotDim;  // rows padded to 128, 256 or 512
+  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim}; }
   bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
   void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32)
   float sic_lambda = 0.f;
@@ -521,8 +522,10 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
       const double* W = params + 1;
       const double* nu = W + (size_t)ndims * K;
       const double* b = nu + K;
-      const size_t M = (size_t)kPotDim * kPotDim;
-      std::vector<float> w1(M, 0.f), w2t(M, 0.f), cb(kPotDim, 0.f), al(kPotDim, 0.f);
+      const int DIM = ndims <= 128 ? 128 : (ndims <= 256 ? 256 : 512);
+      e->pot_dim = DIM;
+      const size_t M = (size_t)DIM * DIM;
+      std::vector<float> w1(M, 0.f), w2t(M, 0.f), cb(DIM, 0.f), al(DIM, 0.f);
       for (int j = 0; j < K; ++j) {
         // parameters are float32 in the reference (theano.shared(np.array(.., dtype='float32')), :398-406)
         const double nuj = (double)(float)nu[j];
@@ -530,12 +533,12 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         al[j] = (float)((nuj + 1.0) / 2.0);
         for (int d = 0; d < ndims; ++d) {
           const double wdj = (double)(float)W[(size_t)d * K + j];
-          w1[(size_t)d * kPotDim + j] = (float)(wdj / nuj);
-          w2t[(size_t)j * kPotDim + d] = (float)(wdj * (nuj + 1.0) / nuj);
+          w1[(size_t)d * DIM + j] = (float)(wdj / nuj);
+          w2t[(size_t)j * DIM + d] = (float)(wdj * (nuj + 1.0) / nuj);
         }
       }
       const void* src[4] = {w1.data(), w2t.data(), cb.data(), al.data()};
-      const size_t bytes[4] = {M * 4, M * 4, (size_t)kPotDim * 4, (size_t)kPotDim * 4};
+      const size_t bytes[4] = {M * 4, M * 4, (size_t)DIM * 4, (size_t)DIM * 4};
       for (int i = 0; i < 4 && !rc; ++i) {
         if (hipMalloc((void**)&e->pot[i], bytes[i]) != hipSuccess ||
             hipMemcpy(e->pot[i], src[i], bytes[i], hipMemcpyHostToDevice) != hipSuccess)
@@ -669,7 +672,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       delete s;
       return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs in float32, MJHMC mode (the reference evaluates it in float32)");
     }
-    s->sh = Shape{0, 0, kPotDim, kPotDim / 4, 4};
+    s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   } else if (e->is_sic()) {
     if (mode != MJHMC_MODE_MJHMC) {
       delete s;
@@ -1261,7 +1264,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   w.dtype = dtype;
   if (e->is_pot()) {
     if (dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T evaluates in float32");
-    w.sh = Shape{0, 0, kPotDim, kPotDim / 4, 4};
+    w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   } else if (e->is_sic()) {
     w.sh = Shape{0, 0, kSicCoeffs, kSicCoeffs / 8, 2};
   } else {

@@ -7,7 +7,7 @@
 
 namespace mjhmc {
 
-constexpr int kPotDim = 512;  // ndims == nbasis, zero padded to 512
+constexpr int kPotDim = 512;  // largest supported ndims == nbasis (rows are zero padded to 128, 256 or 512)
 
 // device-resident model, float32, padded to 512 x 512
 struct PotModel {
@@ -15,6 +15,7 @@ struct PotModel {
   const float* W2T;    // [j][d] = W[d][j] * (nu_j + 1) / nu_j  (second GEMM: dE/dx = W2T^T phi(u))
   const float* cb;     // [j]    = b_j / nu_j
   const float* alpha;  // [j]    = (nu_j + 1) / 2   (0 for padded experts)
+  int dim;             // padded dimension: 128, 256 or 512
 };
 
 struct PotJumpArgs {

@@ -475,7 +475,7 @@ def pot_weights(ndims, seed=2015):
     return w_sp + np.eye(ndims), lognu
 
 
-@pytest.mark.parametrize('ndims,n', [(36, 25), (100, 40), (512, 70)])
+@pytest.mark.parametrize('ndims,n', [(36, 25), (100, 40), (128, 33), (200, 64), (256, 31), (512, 70)])
 def test_pot_energy_and_gradient(ndims, n):
     from mjhmc_amd.misc.distributions import ProductOfT
     W, lognu = pot_weights(ndims)
@@ -490,7 +490,7 @@ def test_pot_energy_and_gradient(ndims, n):
     assert np.allclose(G, Go, rtol=0, atol=3e-5 * np.abs(Go).max())
 
 
-@pytest.mark.parametrize('ndims,N,eps,L,beta', [(36, 50, 0.1, 6, 0.3), (512, 96, 0.05, 8, 0.2)])
+@pytest.mark.parametrize('ndims,N,eps,L,beta', [(36, 50, 0.1, 6, 0.3), (200, 70, 0.08, 6, 0.3), (512, 96, 0.05, 8, 0.2)])
 def test_pot_iterations_vs_oracle(ndims, N, eps, L, beta):
     """Per-iteration parity from identical inputs (float32 device vs float64 oracle): transitions equal
     (a differing particle must be a near tie), state within float32 tolerance."""
