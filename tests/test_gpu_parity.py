@@ -654,3 +654,45 @@ def test_generate_samples_batched_equals_per_step_loop(cls_name):
     s3, e3, g3 = generate_samples(cls, d3, num_grad_steps=100, **kw)
     k = int(np.nonzero(ref_g >= 100)[0][0]) + 1
     assert s3.shape[2] == k and np.array_equal(g3, ref_g[:k]) and bits_equal(s3, ref_s[:, :, :k])
+
+
+# ---------------------------------------------------------------------------------------------
+# edge shapes: a single particle (experiments/spectral.py runs nbatch == 1), slot boundaries, D = 1
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('D,N', [(1, 1), (3, 1), (1, 63), (2, 64), (5, 65), (513, 3), (1024, 2), (40, 129)])
+def test_edge_shapes_match_oracle(D, N):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import TestGaussian
+    X0 = np.random.RandomState(D * 1000 + N).randn(D, N)
+
+    class Fixed(TestGaussian):
+        def init_X(self):
+            self.Xinit = X0
+
+    d = Fixed(ndims=D, nbatch=N, sigma=1.0)
+    s = MarkovJumpHMC(distribution=d, epsilon=0.2, beta=0.4, num_leapfrog_steps=4, seed=123, resample=False)
+    en = orc.IsoGaussian(1.0)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=0.2, beta=0.4, num_leapfrog_steps=4, resample=False,
+                          rng=orc.PhiloxRNG(123, np.arange(N)))
+    for t in range(6):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        assert np.array_equal(s._dev.read(8), o.last_transition), (D, N, t)
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), (D, N, t)
+        assert s.state.H().shape == (1, N)
+    assert (s.l_count, s.f_count, s.r_count) == (o.l_count, o.f_count, o.r_count)
+    assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
+    out = s.sample(3, preserve_order=True)
+    assert out.shape == (D, N, 3)
+
+
+def test_unsupported_shapes_fail_loudly():
+    from mjhmc_amd import _lib
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import TestGaussian, SparseImageCode
+    with pytest.raises(_lib.EngineError):                      # > 1024 float64 dims: no register-resident kernel
+        MarkovJumpHMC(distribution=TestGaussian(ndims=1100, nbatch=4), epsilon=0.1, beta=0.1)
+    B = np.random.RandomState(0).randn(64, 128)
+    d = SparseImageCode(n_patches=1, n_batches=4, n_basis=128, basis=B, imgs=np.zeros((64, 1)))
+    with pytest.raises(_lib.EngineError):                      # only the 256 x 1024 dictionary shape is built
+        MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.1)
