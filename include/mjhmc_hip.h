@@ -185,6 +185,11 @@ int mjhmc_ring_gather(mjhmc_sampler* s, const int64_t* idx, int64_t n, double* h
  * (D, N, n) if stacked==1 (np.stack(axis=-1)). */
 int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* host_out);
 
+/* sum_k (x_k - shift) and sum_k (x_k - shift)^2 over every state element (d < ndims, particle < N) of ring
+ * slots [slot0, slot0 + n): the device half of the reference's online variance estimate
+ * (mjhmc/misc/gen_mj_init.py:76-98), which walks sampler.sample(1).ravel() value by value. */
+int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double* sum, double* sumsq);
+
 /* Device-time of the last mjhmc_iterate call in milliseconds (HIP events on the sampler's
  * stream): total, and the sum over its jump-kernel launches. */
 int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms, int* n_jump_launches);

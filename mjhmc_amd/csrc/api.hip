@@ -231,6 +231,39 @@ __global__ void flags_from_hflf(const T* __restrict__ h, uint8_t* __restrict__ o
   if (i < n) out[i] = (h[i] == h[i]) ? 1 : 0;
 }
 
+// block-reduced shifted moments of the valid elements of `rows` particle rows
+template <typename T>
+__global__ void moments_kernel(const T* __restrict__ src, int64_t nrows_pad_per_slot, int64_t nrows_per_slot, int nslots,
+                               int D, int pitch, double shift, double* out) {
+  double s1 = 0.0, s2 = 0.0;
+  const int64_t per_slot = nrows_per_slot * D;
+  const int64_t total = per_slot * nslots;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t slot = i / per_slot, rem = i - slot * per_slot;
+    const int64_t row = rem / D;
+    const int d = (int)(rem - row * D);
+    const double v = (double)src[(size_t)(slot * nrows_pad_per_slot + row) * pitch + d] - shift;
+    s1 += v;
+    s2 += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  __shared__ double sm[2][16];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][w] = s1;
+    sm[1][w] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sm[threadIdx.x][k];
+    atomicAdd(&out[threadIdx.x], t);
+  }
+}
+
 template <typename T>
 __global__ void narrow_vec(const double* __restrict__ src, T* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -720,6 +753,14 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
     HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
     HIPCHK(hipEventCreate(&s->ev_total[0]));
     HIPCHK(hipEventCreate(&s->ev_total[1]));
+    // everything mjhmc_iterate needs is created here, so a timed call never allocates
+    for (int i = 0; i < 2 * kMaxTimed; ++i) {
+      hipEvent_t ev;
+      HIPCHK(hipEventCreate(&ev));
+      s->ev_k.push_back(ev);
+    }
+    s->stats_cap = 1024;
+    HIPCHK(hipMalloc((void**)&s->stats, (size_t)s->stats_cap * 4 * sizeof(long long)));
     s->Xcur = s->Xbuf[0];
     TRY(upload_matrix(s, Xinit, s->Xcur));
     if (Vinit) {
@@ -1229,6 +1270,32 @@ int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* hos
     for (int k = 0; k < n; ++k)
       TRY(download_cols(s, base + (size_t)k * mb, nullptr, s->N, host_out, total, (int64_t)s->N * n, n, k, k == n - 1));
   }
+  return 0;
+}
+
+int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double* sum, double* sumsq) {
+  if (!s || !sum || !sumsq) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return fail(MJHMC_ERR_INVALID, "slots out of range");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  TRY(ensure_stage(s, 2));
+  HIPCHK(hipMemsetAsync(s->stage, 0, 2 * sizeof(double), s->stream));
+  const char* base = (const char*)s->ring + (size_t)slot0 * mat_bytes(s);
+  const dim3 grid(1024), block(256);
+  if (s->dtype == MJHMC_F64)
+    hipLaunchKernelGGL(moments_kernel<double>, grid, block, 0, s->stream, (const double*)base, s->Npad, s->N, n, s->D,
+                       s->sh.pitch, shift, s->stage);
+  else if (s->dtype == MJHMC_BF16)
+    hipLaunchKernelGGL(moments_kernel<__bf16>, grid, block, 0, s->stream, (const __bf16*)base, s->Npad, s->N, n, s->D,
+                       s->sh.pitch, shift, s->stage);
+  else
+    hipLaunchKernelGGL(moments_kernel<float>, grid, block, 0, s->stream, (const float*)base, s->Npad, s->N, n, s->D,
+                       s->sh.pitch, shift, s->stage);
+  HIPCHK(hipGetLastError());
+  double h[2];
+  HIPCHK(hipMemcpyAsync(h, s->stage, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  *sum = h[0];
+  *sumsq = h[1];
   return 0;
 }
 

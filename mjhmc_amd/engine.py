@@ -168,6 +168,12 @@ class DeviceSampler(object):
         check(self.lib.mjhmc_ring_read(self.handle, int(slot0), int(n), 1 if stacked else 0, ptr(out)))
         return out
 
+    def ring_moments(self, slot0, n, shift=0.0):
+        """(sum (x - shift), sum (x - shift)^2) over all state elements of ring slots [slot0, slot0 + n)."""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        check(self.lib.mjhmc_ring_moments(self.handle, int(slot0), int(n), float(shift), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def last_timing(self):
         t, k, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         check(self.lib.mjhmc_last_timing(self.handle, ctypes.byref(t), ctypes.byref(k), ctypes.byref(n)))

@@ -5,6 +5,8 @@ indices) bit-exact; float64 state and energies within 1e-10 relative (RTOL below
 bit-identical wherever the force is an exact product (sigma = 1 isotropic / diagonal Gaussian),
 because the kernels are built with -ffp-contract=off and follow the reference's operation order.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -696,3 +698,29 @@ def test_unsupported_shapes_fail_loudly():
     d = SparseImageCode(n_patches=1, n_batches=4, n_basis=128, basis=B, imgs=np.zeros((64, 1)))
     with pytest.raises(_lib.EngineError):                      # only the 256 x 1024 dictionary shape is built
         MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.1)
+
+
+# ---------------------------------------------------------------------------------------------
+# fair-initialisation generator (gen_mj_init.py) -- online variance known answer, pickle format
+# ---------------------------------------------------------------------------------------------
+def test_online_variance_known_answer_and_init_cache(tmp_path):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import Gaussian
+    from mjhmc_amd.misc import gen_mj_init as G
+    np.random.seed(2)
+    d = Gaussian(ndims=6, nbatch=50, log_conditioning=1)
+    a = MarkovJumpHMC(distribution=d, epsilon=0.5, beta=0.3, num_leapfrog_steps=4, seed=8, resample=False)
+    var, _ = G.online_variance(a, d, var_steps=300, block=64)
+    d2 = Gaussian(ndims=6, nbatch=50, log_conditioning=1)
+    d2.Xinit = d.Xinit
+    d2.init_X = lambda: None
+    b = MarkovJumpHMC(distribution=d2, epsilon=0.5, beta=0.3, num_leapfrog_steps=4, seed=8, resample=False)
+    vals = b.sample(300, preserve_order=True)                      # the same 300 states
+    assert abs(var - np.var(vals.ravel(), ddof=1)) < 1e-12 * np.var(vals.ravel())
+    # generator end to end at toy step counts; pickle layout of the reference
+    d3 = Gaussian(ndims=4, nbatch=40, log_conditioning=1)
+    path = G.cache_initialization(d3, str(tmp_path), burn_in_steps=400, var_steps=200, seed=3)
+    mj, emc_var, true_var, ctl = G.load_initialization(d3, str(tmp_path))
+    assert mj.shape == (4, 40) and ctl.shape == (4, 40) and np.isfinite(mj).all() and np.isfinite(ctl).all()
+    assert emc_var > 0 and true_var > 0
+    assert os.path.basename(path).startswith('Gaussian_') and G.stable_digest(d3) in path
