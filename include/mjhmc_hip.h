@@ -190,8 +190,9 @@ int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* hos
  * (mjhmc/misc/gen_mj_init.py:76-98), which walks sampler.sample(1).ravel() value by value. */
 int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double* sum, double* sumsq);
 
-/* Device-time of the last mjhmc_iterate call in milliseconds (HIP events on the sampler's
- * stream): total, and the sum over its jump-kernel launches. */
+/* Device time of the last mjhmc_iterate call in milliseconds: ONE HIP-event pair on the sampler's stream
+ * brackets its whole launch sequence (first to last jump kernel); jump_kernel_ms == total_ms and
+ * n_jump_launches is the number of sampling_iteration attempts it covers. */
 int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms, int* n_jump_launches);
 
 /* Stream synchronisation (bench harness). */
