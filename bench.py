@@ -148,8 +148,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # one rank per GPU over RCCL.  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to exercise
+        # this code path with several ranks on a single-GPU box.
+        backend = os.environ.get('MJHMC_BENCH_BACKEND', 'nccl')
+        if os.environ.get('MJHMC_BENCH_ONE_GPU'):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from mjhmc_amd import engine, _lib
@@ -190,7 +198,7 @@ def main():
     tim = smp.last_timing()
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
