@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "philox.hpp"
 
@@ -61,6 +62,7 @@ struct LaneMap {
   int D;      // true ndims
   int CH;     // 16-byte chunks per particle row (pitch / VEC)
   int lane0;  // wave lane index of the group's lane 0
+  bool wpp;   // the whole wavefront is one particle (G == 64, known at compile time in the WPP kernels)
 };
 
 template <typename T, int E>
@@ -117,8 +119,16 @@ __device__ __forceinline__ T group_sum(T v, int G) {
 }
 
 // value held by lane `r` of the caller's group
+__device__ __forceinline__ double readlane_v(double v, int r) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), r), __builtin_amdgcn_readlane(__double2loint(v), r));
+}
+__device__ __forceinline__ float readlane_v(float v, int r) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r));
+}
+
 template <typename T>
 __device__ __forceinline__ T group_lane(T v, const LaneMap& m, int r) {
+  if (m.wpp) return readlane_v(v, r);  // v_readlane: no LDS-crossbar round trip
   return __shfl(v, m.lane0 + r);
 }
 
@@ -713,11 +723,21 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T
       const int row = (role == 0) ? 0 : (role == 1 ? 2 : 1);
       e = a.rexp[(size_t)row * a.N + p];
     } else {
-      const u32x4 w =
-          philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, a.key.k0, a.key.k1);
-      const double uA = u53(w.w0, w.w1);
-      const double uF = group_lane(u53(w.w2, w.w3), m, 0);
-      e = -log(role >= 2 ? uF : uA);
+      if (m.wpp) {
+        // one particle per wave: the counter, key and slot are wave-uniform, so both Philox calls run
+        // on the scalar unit (s_mul_i32 / s_mul_hi_u32) beside the vector work instead of in it
+        const uint32_t spid = __builtin_amdgcn_readfirstlane(pid);
+        const u32x4 w = philox4x32_10(spid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+        const u32x4 q = philox4x32_10(spid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+        const double uL = u53(w.w0, w.w1), uF = u53(w.w2, w.w3), uR = u53(q.w0, q.w1);
+        e = -log(role == 0 ? uL : (role == 1 ? uR : uF));
+      } else {
+        const u32x4 w =
+            philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, a.key.k0, a.key.k1);
+        const double uA = u53(w.w0, w.w1);
+        const double uF = group_lane(u53(w.w2, w.w3), m, 0);
+        e = -log(role >= 2 ? uF : uA);
+      }
     }
     const double rate = (role == 0) ? l_rate : (role == 1 ? r_rate : f_rate);
     bool ignore = false;
@@ -827,26 +847,30 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const LaneMap& m
 // body forces an in-order vmcnt wait that would also drain the prefetch of the next slot.
 // FULLROW = true: every lane's chunks are inside the row (pitch == G * E), no per-chunk predicates.
 // MODE: which sampler family's iteration this is (kModeMJHMC / kModeControl / kModeCT).
-template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW>
+// WPP = true: G == 64 (a whole wavefront per particle) is a compile-time fact: the reduction ladder, the
+// group exchanges (v_readlane) and the Philox calls (scalar unit) specialise on it.
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false>
 __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
-  const int G = 1 << a.logG;
+  const int logG = WPP ? 6 : a.logG;
+  const int G = 1 << logG;
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block, scalar
-  const int ppw = 64 >> a.logG;
-  const int64_t nslots = a.Npad >> (6 - a.logG);  // rows are padded to a multiple of 64 particles
+  const int ppw = 64 >> logG;
+  const int64_t nslots = a.Npad >> (6 - logG);  // rows are padded to a multiple of 64 particles
   const int64_t W = (int64_t)gridDim.x * 4;
   const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
-  const int gi = lane >> a.logG;
+  const int gi = lane >> logG;
   LaneMap m;
   m.j = lane & (G - 1);
   m.G = G;
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = lane & ~(G - 1);
+  m.wpp = WPP;
   constexpr int VEC = VecOf<T>::n;
   const uint32_t lane_off = ((uint32_t)gi * a.pitch + m.j * VEC) * (uint32_t)sizeof(T);
   const uint32_t chunk_stride = (uint32_t)(G * VEC * sizeof(T));
@@ -1089,6 +1113,7 @@ __global__ __launch_bounds__(256) void mjhmc_eval_kernel(const EvalArgs<T> a, co
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
+  m.wpp = false;
   T x[E];
   load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
   const auto lc = en.template local<E>(m);
@@ -1143,21 +1168,21 @@ struct EnergyParams {
 
 // Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
 // (occupancy query, cached per instantiation), never more than there are slots to hand out.
-template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW>
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false>
 inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   static int resident_blocks = 0;
   if (resident_blocks == 0) {
     int dev = 0, per_cu = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW>, 256,
-                                                       0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP>,
+                                                       256, 0);
     resident_blocks = std::max(1, per_cu) * std::max(1, cus);
   }
   const int64_t nslots = a.Npad >> (6 - a.logG);
   const int64_t want = (nslots + 3) / 4;
   const unsigned grid = (unsigned)std::min<int64_t>(want, resident_blocks);
-  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW>), dim3(grid), dim3(256), 0, st, a, en);
+  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP>), dim3(grid), dim3(256), 0, st, a, en);
 }
 
 // Replay needs every recorded stream of the mode; it is a test path and exists only in the
@@ -1168,6 +1193,7 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool replay = a.noise != nullptr;
   if (a.mode == kModeMJHMC) {
     if (replay) launch_jump_r<En, T, E, kModeMJHMC, true, false>(a, en, st);
+    else if (full && a.logG == 6 && !std::getenv("MJHMC_NO_WPP")) launch_jump_r<En, T, E, kModeMJHMC, false, true, true>(a, en, st);
     else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true>(a, en, st);
     else launch_jump_r<En, T, E, kModeMJHMC, false, false>(a, en, st);
   } else if (a.mode == kModeCT) {
