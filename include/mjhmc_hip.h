@@ -190,6 +190,20 @@ int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* hos
  * (mjhmc/misc/gen_mj_init.py:76-98), which walks sampler.sample(1).ravel() value by value. */
 int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double* sum, double* sumsq);
 
+/* Autocorrelation along the time axis of ring slots [slot0, slot0 + n):
+ *   out[k] = sum_{d < ndims, particle < N} sum_t x_t * x_{t+k},   k = 0 .. n-1   (n float64 to the host)
+ * linear == 0: t + k wraps modulo n.  out / out[0] is fft_autocor(samples) of mjhmc/misc/autocor.py:37-49
+ *              (fftn along time, |.|^2, ifftn, mean over dims and particles, normalise by lag 0).
+ * linear != 0: the sum stops at t + k < n.  out[k] / (ndims * N * (n - k)) is the lag product mean
+ *              np.mean(samples[:, :, :-k] * samples[:, :, k:]) of slow_autocorrelation (:177-211) and of the
+ *              brute-force branch of autocorrelation (:52-117).
+ * The sums are returned unnormalised so that ranks holding column shards can add theirs before dividing. */
+int mjhmc_ring_autocor(mjhmc_sampler* s, int slot0, int n, int linear, double* host_out);
+/* The same for a host array laid out like the reference's samples, [n_dims, n_batch, n_samples] C order,
+ * i.e. n_series = n_dims * n_batch contiguous series of n_samples float64 (no sampler needed). */
+int mjhmc_autocor(mjhmc_ctx* ctx, const double* samples, int64_t n_series, int n_samples, int linear,
+                  double* host_out);
+
 /* Device time of the last mjhmc_iterate call in milliseconds: ONE HIP-event pair on the sampler's stream
  * brackets its whole launch sequence (first to last jump kernel); jump_kernel_ms == total_ms and
  * n_jump_launches is the number of sampling_iteration attempts it covers. */

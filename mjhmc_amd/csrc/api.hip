@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mjhmc_hip.h"
+#include "autocor.hpp"
 #include "dense_pot.hpp"
 #include "dense_sic.hpp"
 #include "elementwise.hpp"
@@ -71,7 +72,6 @@ struct Shape {
   int E, logG, pitch, CH, esize;
 };
 
-static const int kMaxTimed = 256;
 
 struct mjhmc_sampler {
   mjhmc_ctx* ctx;
@@ -1280,6 +1280,25 @@ int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double*
   *sum = h[0];
   *sumsq = h[1];
   return 0;
+}
+
+int mjhmc_ring_autocor(mjhmc_sampler* s, int slot0, int n, int linear, double* host_out) {
+  if (!s || !host_out) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return fail(MJHMC_ERR_INVALID, "slots out of range");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const RingView view{(const char*)s->ring + (size_t)slot0 * mat_bytes(s), s->dtype, s->Npad, s->N, s->D, s->sh.pitch};
+  std::string err;
+  const int rc = autocor_from_ring(s->stream, view, n, linear, host_out, err);
+  return rc ? fail(rc, err) : 0;
+}
+
+int mjhmc_autocor(mjhmc_ctx* ctx, const double* samples, int64_t n_series, int n_samples, int linear,
+                  double* host_out) {
+  if (!ctx || !samples || !host_out) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::string err;
+  const int rc = autocor_from_host(nullptr, samples, n_series, n_samples, linear, host_out, err);
+  return rc ? fail(rc, err) : 0;
 }
 
 int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms, int* n_jump_launches) {

@@ -37,6 +37,17 @@ class Context(object):
         check(self.lib.mjhmc_ctx_info(self.handle, name, 256, ctypes.byref(ncu), ctypes.byref(hbm)))
         return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
 
+    def autocor(self, samples, linear=False):
+        """Lag sums ``out[k] = sum_series sum_t x_t x_{t+k}`` of a host array [n_dims, n_batch, n_samples]
+        (circular in time unless ``linear``); see mjhmc_autocor in include/mjhmc_hip.h."""
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+        assert samples.ndim == 3
+        n = samples.shape[2]
+        out = np.empty(n, dtype=np.float64)
+        check(self.lib.mjhmc_autocor(self.handle, ptr(samples), int(samples.shape[0] * samples.shape[1]), int(n),
+                                     1 if linear else 0, ptr(out)))
+        return out
+
 
 def context(device=0):
     """Process-wide context per device index."""
@@ -173,6 +184,12 @@ class DeviceSampler(object):
         a, b = ctypes.c_double(), ctypes.c_double()
         check(self.lib.mjhmc_ring_moments(self.handle, int(slot0), int(n), float(shift), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def ring_autocor(self, slot0, n, linear=False):
+        """Lag sums over time of ring slots [slot0, slot0 + n), summed over all state elements."""
+        out = np.empty(int(n), dtype=np.float64)
+        check(self.lib.mjhmc_ring_autocor(self.handle, int(slot0), int(n), 1 if linear else 0, ptr(out)))
+        return out
 
     def last_timing(self):
         t, k, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()

@@ -57,6 +57,11 @@ class Comm(object):
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t.cpu().numpy()
 
+    def allreduce_f64(self, values):
+        t = self._t(np.asarray(values, dtype=np.float64), self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
     def bcast(self, arr, src=0):
         t = self._t(arr, self.torch.float64)
         self.dist.broadcast(t, src=src, group=self.group)

@@ -210,10 +210,14 @@ class HMCBase(object):
 
     def sample(self, n_samples=1000, preserve_order=False, replay=None):
         """markov_jump_hmc.py:150-173."""
+        self._record(n_samples, replay)
+        return self._stack(n_samples, preserve_order)
+
+    def _record(self, n_samples, replay=None):
+        """Run n_samples iterations, snapshotting X after each into device ring slots [0, n_samples)."""
         self._dev.ring_alloc(n_samples)
         self._run(n_samples, ring_slot0=0, replay=replay)
         self._publish()
-        return self._stack(n_samples, preserve_order)
 
 
 class HMC(HMCBase):
@@ -323,11 +327,12 @@ class ContinuousTimeHMC(HMCBase):
                 raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # infinite dwell time
             self._last_resample_idx = sample_idx
             return self._dev.ring_gather(sample_idx)
-        self._dev.ring_alloc(n_samples)
-        self._run(n_samples, ring_slot0=0, replay=replay)
-        self._publish()
-        self._read_dwell()
+        self._record(n_samples, replay)
         return self._stack(n_samples, preserve_order)
+
+    def _record(self, n_samples, replay=None):
+        super(ContinuousTimeHMC, self)._record(n_samples, replay)
+        self._read_dwell()
 
 
 class MarkovJumpHMC(ContinuousTimeHMC):

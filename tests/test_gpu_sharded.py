@@ -62,6 +62,16 @@ for name, cls, X, kw in (('mjhmc', MarkovJumpHMC, X0, {}), ('mjhmc-stack', Marko
     else:
         s.state.X, s.state.EX                          # collectives are SPMD: mirror rank 0's gathers
     comm.barrier()
+
+# autocorrelation of a sharded run: every rank transforms its own columns, the lag sums are added
+from mjhmc_amd.misc.autocor import calculate_autocorrelation
+akw = dict(epsilon=0.3, beta=0.3, num_leapfrog_steps=5, seed=4242, resample=False)
+ac, e, g = calculate_autocorrelation(MarkovJumpHMC, dist_of(X0), num_steps=12, comm=comm, **akw)
+if comm.rank == 0:
+    ac1, e1, g1 = calculate_autocorrelation(MarkovJumpHMC, dist_of(X0), num_steps=12, **akw)
+    assert ac.shape == (12,) and np.allclose(ac, ac1, rtol=0, atol=1e-12), 'autocor'
+    assert np.array_equal(e, e1) and np.array_equal(g, g1), 'autocor traces'
+comm.barrier()
 dist.destroy_process_group()
 print('rank', sys.argv[1], 'ok')
 '''

@@ -157,3 +157,26 @@ def test_g8_continuous_time_hmc_replay():
             assert bits_equal(arr, g[f][t]), (t, f)
         assert [s.l_count, s.f_count, s.r_count, s.fl_count] == list(g['counts'][t])
         assert [en.E_count, en.dEdX_count] == list(g['evals'][t])
+
+
+def test_autocor_oracle_against_its_definition():
+    """fft_autocor (autocor.py:37-49) is the normalised circular lag sum; slow_autocorrelation (:177-211)
+    the lag-product mean.  The reference module is not importable (py2 prints, mklfft): pin the
+    restatement on the explicit definitions, on a real sample block of the golden G4 run."""
+    from oracle import autocor_oracle as ac
+    g = load("g4_diag_16x64")
+    X = np.stack([g['X'][t] for t in range(g['X'].shape[0])], axis=-1)      # (D, N, T)
+    circ = ac.circular_lag_sums(X)
+    np.testing.assert_allclose(ac.fft_autocor(X), circ / circ[0], rtol=0, atol=1e-12)
+    lin = ac.linear_lag_sums(X)
+    T = X.shape[2]
+    means = lin / (X.shape[0] * X.shape[1] * (T - np.arange(T)))
+    slow, _, _ = ac.slow_autocorrelation(X, None, None, half_window=False)
+    np.testing.assert_allclose(slow, means[:T - 1] / means[0], rtol=1e-13)
+    slow_h, _, _ = ac.slow_autocorrelation(X, None, None, half_window=True)
+    assert slow_h.shape == (T // 2 - 1,)
+    np.testing.assert_allclose(slow_h, means[:T // 2 - 1] / means[0], rtol=1e-13)
+    e = np.arange(T, dtype=float)
+    brute, e2, _ = ac.autocorrelation(X, e, e, half_window=False, brute_force=True)
+    assert brute.shape == (T - 1, 1) and e2.shape == (T - 1,)
+    np.testing.assert_allclose(brute[:, 0], means[:T - 1] / means[0], rtol=1e-13)
