@@ -835,9 +835,182 @@ int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
 
 }  // extern "C"
 
+// per-attempt counters of one mjhmc_iterate call from the device tallies hs[attempt][4]
+static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>& hs, int attempts, int done, bool failed,
+                            mjhmc_iter_stats* per_iter) {
+  if (!per_iter) return;
+  for (int i = 0; i < attempts; ++i) {
+    mjhmc_iter_stats& st = per_iter[i];
+    std::memset(&st, 0, sizeof(st));
+    if (s->mode == MJHMC_MODE_MJHMC) {
+      st.l = hs[4 * i + 0];
+      st.f = hs[4 * i + 1];
+      st.r = hs[4 * i + 2];
+      st.n_cold = hs[4 * i + 3];
+    } else if (s->mode == MJHMC_MODE_CTHMC) {  // clocks FL, F, R (markov_jump_hmc.py:288-290)
+      st.fl = hs[4 * i + 0];
+      st.f = hs[4 * i + 1];
+      st.r = hs[4 * i + 2];
+    } else {  // markov_jump_hmc.py:138-148
+      st.l = hs[4 * i + 0];
+      st.f = hs[4 * i + 1];
+      st.r = hs[4 * i + 2];
+      st.fl = hs[4 * i + 3];
+    }
+    st.E_evals = s->N + st.n_cold;  // L on all (+ FLF on the cold ones)
+    st.dEdX_evals = (int64_t)s->L * (s->N + st.n_cold);
+    st.nonfinite = (failed && i == done) ? 1 : 0;
+    st.L_used = s->L;
+    st.eps_used = s->eps;
+  }
+}
+
+// Elementwise energies, counter RNG, n_iter >= 2: launches of up to kMaxFuse FUSED iterations.  A launch reads
+// the state buffers of one parity and writes the other, so its input survives it: when some particle meets a
+// non-finite rate at iteration f (the reference aborts the WHOLE batch there, markov_jump_hmc.py:376-389) the
+// launch that contains f is run again for the iterations before f and the call returns n_done = f.
+template <typename T>
+static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
+  const size_t mb = mat_bytes(s);
+  const int need = n_iter + kMaxFuse;  // + scratch tallies for the recovery launch
+  if (s->stats_cap < need) {
+    if (s->stats) HIPCHK(hipFree(s->stats));
+    s->stats = nullptr;
+    HIPCHK(hipMalloc((void**)&s->stats, (size_t)need * 4 * sizeof(long long)));
+    s->stats_cap = need;
+  }
+  HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
+  HIPCHK(hipMemsetAsync(s->stats, 0, (size_t)need * 4 * sizeof(long long), s->stream));
+
+  void* xin = s->Xcur;
+  if (ring_slot0 >= 0) {  // the live state sits in a slot about to be overwritten: move it out first
+    const char* lo = (const char*)s->ring + (size_t)ring_slot0 * mb;
+    const char* hi = lo + (size_t)n_iter * mb;
+    if ((const char*)xin >= lo && (const char*)xin < hi) {
+      void* spare = s->Xbuf[0];
+      HIPCHK(hipMemcpyAsync(spare, xin, mb, hipMemcpyDeviceToDevice, s->stream));
+      xin = s->Xcur = spare;
+    }
+  }
+  struct Launch {
+    int i0, K, vi, si;
+    void* xin;
+    void* xout;
+  };
+  auto launch = [&](const Launch& l, long long* stats) -> int {
+    JumpArgs<T> a;
+    a.X_in = (const T*)l.xin;
+    a.V_in = (const T*)s->Vbuf[l.vi];
+    a.X_out = (T*)l.xout;
+    a.V_out = (T*)s->Vbuf[l.vi ^ 1];
+    a.EX_in = (const T*)s->EX[l.si];
+    a.EV_in = (const T*)s->EV[l.si];
+    a.EX_out = (T*)s->EX[l.si ^ 1];
+    a.EV_out = (T*)s->EV[l.si ^ 1];
+    a.Hflf_in = (const T*)s->Hflf[l.si];
+    a.Hflf_out = (T*)s->Hflf[l.si ^ 1];
+    a.dwell = s->dwell;
+    a.trans = s->trans;
+    a.noise = nullptr;
+    a.rexp = nullptr;
+    a.runif = nullptr;
+    a.mode = s->mode;
+    a.ctl = s->ctl;
+    a.stats = (unsigned long long*)stats;
+    a.N = s->N;
+    a.Npad = s->Npad;
+    a.first_pid = s->first_pid;
+    a.D = s->D;
+    a.pitch = s->sh.pitch;
+    a.CH = s->sh.CH;
+    a.logG = s->sh.logG;
+    a.L = s->L;
+    a.iter = l.i0;
+    a.n_fuse = l.K;
+    if (ring_slot0 >= 0) {
+      a.xiter = (T*)((char*)s->ring + (size_t)(ring_slot0 + l.i0) * mb);
+      a.xiter_stride = mb / sizeof(T);
+      a.dwell_ring = s->dwell_ring + (size_t)(ring_slot0 + l.i0) * s->Npad;
+    } else {
+      a.xiter = nullptr;
+      a.xiter_stride = 0;
+      a.dwell_ring = s->dwell_scratch;
+    }
+    a.eps = (T)s->eps;
+    a.chalf = (T)(-s->eps / 2.);
+    a.r_keep = (T)std::sqrt(1. - s->beta);
+    a.r_mix = (T)std::sqrt(s->beta);
+    a.p_r = s->p_r;
+    a.p_flip = s->p_flip;
+    const uint64_t tick = s->tick + (uint64_t)l.i0;
+    a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), (uint32_t)(tick & 0xFFFFFFFFu),
+                   (uint32_t)(tick >> 32)};
+    TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+  };
+  auto out_of = [&](int i0, int K, void* in) -> void* {
+    if (ring_slot0 >= 0) return (char*)s->ring + (size_t)(ring_slot0 + i0 + K - 1) * mb;
+    return (in != s->Xbuf[0]) ? s->Xbuf[0] : s->Xbuf[1];
+  };
+
+  std::vector<Launch> launches;
+  HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
+  for (int i0 = 0; i0 < n_iter; i0 += kMaxFuse) {
+    const int j = (int)launches.size();
+    Launch l;
+    l.i0 = i0;
+    l.K = std::min(kMaxFuse, n_iter - i0);
+    l.vi = (s->vcur + j) & 1;
+    l.si = (s->scur + j) & 1;
+    l.xin = xin;
+    l.xout = out_of(i0, l.K, xin);
+    TRY(launch(l, s->stats + 4 * (size_t)i0));
+    launches.push_back(l);
+    xin = l.xout;
+  }
+  HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  Control hc;
+  std::vector<long long> hs((size_t)n_iter * 4);
+  HIPCHK(hipMemcpyAsync(&hc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(hs.data(), s->stats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+
+  int done = n_iter, attempts = n_iter, committed = (int)launches.size();
+  void* xlive = launches.back().xout;
+  if (hc.failed) {
+    done = 0x7fffffff - hc.inv_iter;
+    attempts = done + 1;
+    committed = done / kMaxFuse;
+    Launch l = launches[(size_t)committed];
+    xlive = l.xin;
+    l.K = done - l.i0;
+    if (l.K > 0) {  // redo the iterations of that launch that precede the failed one (same ticks, same results)
+      l.xout = out_of(l.i0, l.K, l.xin);
+      HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
+      TRY(launch(l, s->stats + 4 * (size_t)n_iter));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      xlive = l.xout;
+      ++committed;
+    }
+  }
+  fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);
+  s->Xcur = xlive;
+  s->vcur = (s->vcur + committed) & 1;
+  s->scur = (s->scur + committed) & 1;
+  s->tick += (uint64_t)attempts;
+  if (n_done) *n_done = done;
+  s->last_jump_launches = attempts;
+  s->timing_pending = true;
+  return 0;
+}
+
 template <typename T>
 static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                      const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
+  if (n_iter >= 2 && !replay_normal && !replay_exp && !replay_unif && !s->en->is_dense() &&
+      !std::getenv("MJHMC_NO_FUSE"))
+    return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);
   if (s->stats_cap < n_iter) {
     if (s->stats) HIPCHK(hipFree(s->stats));
@@ -910,6 +1083,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.logG = s->sh.logG;
     a.L = s->L;
     a.iter = i;
+    a.n_fuse = 0;
+    a.xiter = nullptr;
+    a.xiter_stride = 0;
     a.eps = (T)s->eps;
     a.chalf = (T)(-s->eps / 2.);
     a.r_keep = (T)std::sqrt(1. - s->beta);
@@ -1011,32 +1187,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
 
   const int done = hc.failed ? hc.failed_iter : n_iter;
   const int attempts = hc.failed ? done + 1 : n_iter;
-  if (per_iter) {
-    for (int i = 0; i < attempts; ++i) {
-      mjhmc_iter_stats& st = per_iter[i];
-      std::memset(&st, 0, sizeof(st));
-      if (s->mode == MJHMC_MODE_MJHMC) {
-        st.l = hs[4 * i + 0];
-        st.f = hs[4 * i + 1];
-        st.r = hs[4 * i + 2];
-        st.n_cold = hs[4 * i + 3];
-      } else if (s->mode == MJHMC_MODE_CTHMC) {  // clocks FL, F, R (markov_jump_hmc.py:288-290)
-        st.fl = hs[4 * i + 0];
-        st.f = hs[4 * i + 1];
-        st.r = hs[4 * i + 2];
-      } else {  // markov_jump_hmc.py:138-148
-        st.l = hs[4 * i + 0];
-        st.f = hs[4 * i + 1];
-        st.r = hs[4 * i + 2];
-        st.fl = hs[4 * i + 3];
-      }
-      st.E_evals = s->N + st.n_cold;                          // L on all (+ FLF on the cold ones)
-      st.dEdX_evals = (int64_t)s->L * (s->N + st.n_cold);
-      st.nonfinite = (hc.failed && i == done) ? 1 : 0;
-      st.L_used = s->L;
-      st.eps_used = s->eps;
-    }
-  }
+  fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);
   // commit the finished iterations
   if (done > 0) s->Xcur = xout[done - 1];
   s->vcur = (s->vcur + done) & 1;

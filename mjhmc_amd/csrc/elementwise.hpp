@@ -40,7 +40,11 @@ constexpr int kModeCT = 2;       // ContinuousTimeHMC.sampling_iteration  (marko
 struct Control {
   int failed;       // some attempt hit a non-finite rate
   int failed_iter;  // index (within the current mjhmc_iterate call) of that attempt
+  int inv_iter;     // fused launches: 0x7fffffff - (first failed attempt), combined with atomicMax (0 = none)
 };
+
+// most sampling iterations one fused launch runs per particle (per-iteration tallies live in LDS)
+constexpr int kMaxFuse = 64;
 
 template <typename T>
 struct VecOf;
@@ -396,6 +400,13 @@ struct JumpArgs {
   int D, pitch, CH, logG;
   int L;
   int iter;             // index of this attempt inside the current mjhmc_iterate call
+  // FUSED kernels: n_fuse consecutive sampling iterations per particle in one launch, the state staying in
+  // registers / LDS between them (iteration it uses RNG tick key.tick + it and stats[4 * it ...]).
+  // xiter != nullptr: X after iteration it is also recorded at xiter + it * xiter_stride (ring slots) and
+  // its dwelling times at dwell_ring + it * Npad; X_out is then not written (the last slot is the live state).
+  int n_fuse;
+  T* xiter;
+  size_t xiter_stride;  // elements of T between consecutive ring slots
   int mode;             // kModeMJHMC / kModeControl / kModeCT
   T eps, chalf;         // epsilon and -epsilon/2 (hmc_state.py:88-91)
   T r_keep, r_mix;      // sqrt(1-beta), sqrt(beta) of HMCState.R (hmc_state.py:125-126)
@@ -706,8 +717,8 @@ __device__ __forceinline__ void slot_store(char* base, uint32_t lane_off, uint32
 // the FLF rate, lane 2 on the F clock -- instead of three times in sequence in every lane
 // (2 exp + 2 sqrt + 3 log + 3 div + 2 Philox  ->  1 of each), then exchanged inside the group.
 template <typename T, bool REPLAY>
-__device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T H0, T HL, T Hflf, int64_t p,
-                                       uint32_t pid, int& k, double& dwell, bool& bad) {
+__device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, const LaneMap& m, T H0, T HL, T Hflf,
+                                       int64_t p, uint32_t pid, int& k, double& dwell, bool& bad) {
   const double r_rate = a.p_r;
   double dL, dF, dR, l_rate, f_rate;
   if (m.G >= 4) {
@@ -727,13 +738,13 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T
         // one particle per wave: the counter, key and slot are wave-uniform, so both Philox calls run
         // on the scalar unit (s_mul_i32 / s_mul_hi_u32) beside the vector work instead of in it
         const uint32_t spid = __builtin_amdgcn_readfirstlane(pid);
-        const u32x4 w = philox4x32_10(spid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
-        const u32x4 q = philox4x32_10(spid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+        const u32x4 w = philox4x32_10(spid, key.tick_lo, key.tick_hi, kSlotExpLF, key.k0, key.k1);
+        const u32x4 q = philox4x32_10(spid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
         const double uL = u53(w.w0, w.w1), uF = u53(w.w2, w.w3), uR = u53(q.w0, q.w1);
         e = -log(role == 0 ? uL : (role == 1 ? uR : uF));
       } else {
         const u32x4 w =
-            philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, a.key.k0, a.key.k1);
+            philox4x32_10(pid, key.tick_lo, key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, key.k0, key.k1);
         const double uA = u53(w.w0, w.w1);
         const double uF = group_lane(u53(w.w2, w.w3), m, 0);
         e = -log(role >= 2 ? uF : uA);
@@ -758,9 +769,9 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T
       eF = a.rexp[a.N + p];
       eR = a.rexp[2 * a.N + p];
     } else {
-      const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+      const u32x4 w = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpLF, key.k0, key.k1);
       __builtin_amdgcn_sched_barrier(0);
-      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      const u32x4 q = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
       __builtin_amdgcn_sched_barrier(0);
       eL = -log(u53(w.w0, w.w1));
       __builtin_amdgcn_sched_barrier(0);
@@ -786,8 +797,8 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const LaneMap& m, T
 // ContinuousTimeHMC (markov_jump_hmc.py:251-290): clocks FL (rate sqrt(exp(H0 - H_fl))), F (rate 1),
 // R (rate p_r); min_idx is called with [f, fl, r], so ties go F, FL, R.  Returns k: 0 = FL, 1 = F, 2 = R.
 template <typename T, bool REPLAY>
-__device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const LaneMap& m, T H0, T HL, int64_t p, uint32_t pid,
-                                          int& k, double& dwell, bool& bad) {
+__device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& key, const LaneMap& m, T H0, T HL,
+                                          int64_t p, uint32_t pid, int& k, double& dwell, bool& bad) {
   const double fl_rate = sqrt(exp((double)(H0 - HL)));
   const double r_rate = a.p_r;
   double dFL, dF, dR;
@@ -799,7 +810,7 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const LaneMap& m
       e = a.rexp[(size_t)row * a.N + p];
     } else {
       const u32x4 w =
-          philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, a.key.k0, a.key.k1);
+          philox4x32_10(pid, key.tick_lo, key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, key.k0, key.k1);
       const double uA = u53(w.w0, w.w1);
       const double uF = group_lane(u53(w.w2, w.w3), m, 0);
       e = -log(role >= 2 ? uF : uA);
@@ -817,9 +828,9 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const LaneMap& m
       eF = a.rexp[a.N + p];
       eR = a.rexp[2 * a.N + p];
     } else {
-      const u32x4 w = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpLF, a.key.k0, a.key.k1);
+      const u32x4 w = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpLF, key.k0, key.k1);
       __builtin_amdgcn_sched_barrier(0);
-      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      const u32x4 q = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
       __builtin_amdgcn_sched_barrier(0);
       eFL = -log(u53(w.w0, w.w1));
       __builtin_amdgcn_sched_barrier(0);
@@ -849,8 +860,15 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const LaneMap& m
 // MODE: which sampler family's iteration this is (kModeMJHMC / kModeControl / kModeCT).
 // WPP = true: G == 64 (a whole wavefront per particle) is a compile-time fact: the reduction ladder, the
 // group exchanges (v_readlane) and the Philox calls (scalar unit) specialise on it.
-template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false>
+// FUSED = true: the launch runs a.n_fuse (<= kMaxFuse) consecutive sampling iterations per particle.  The
+// chains are independent, so between iterations nothing has to leave the wave: X, V, EX, EV, H_flf stay in
+// registers / the LDS stash, HBM sees one read and one write of the state per LAUNCH instead of per
+// iteration (plus the ring snapshots when samples are recorded).  Iteration `it` uses RNG tick key.tick + it
+// and tallies into stats[4 * it ..]; the first iteration that meets a non-finite rate is reported through
+// Control::inv_iter and the host re-runs the launch up to that iteration (the input buffers are untouched).
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false, bool FUSED = false>
 __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
+  static_assert(!(FUSED && REPLAY), "recorded random numbers are replayed one iteration per launch");
   if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
@@ -878,6 +896,13 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   const auto lc = en.template local<E>(m);
   unsigned nL = 0, nF = 0, nR = 0, nCold = 0;  // per-lane tallies (group leaders only)
   bool any_bad = false;
+  const int n_it = FUSED ? a.n_fuse : 1;
+  int first_bad = 0x7fffffff;  // FUSED: first iteration of this lane's particles that met a non-finite rate
+  __shared__ unsigned fused_tally[FUSED ? kMaxFuse : 1][4];
+  if constexpr (FUSED) {
+    fused_tally[threadIdx.x >> 2][threadIdx.x & 3] = 0;  // 256 threads == kMaxFuse * 4
+    __syncthreads();
+  }
   using Vec = typename VecOf<T>::type;
   constexpr int C = E / VEC;
   __shared__ Vec stash[4][2][C][64];
@@ -910,14 +935,28 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
       x[e] = nx[e];
       v[e] = nv[e];
     }
-    stash_put<T, E>(stash_x, lane, x);
-    stash_put<T, E>(stash_v, lane, v);
+    if constexpr (!FUSED) {
+      stash_put<T, E>(stash_x, lane, x);
+      stash_put<T, E>(stash_v, lane, v);
+    }
     T EX0 = ns.EX, EV0 = ns.EV, Hcached = ns.Hflf;
     use_here(EX0);
     use_here(EV0);
     use_here(Hcached);
-    const bool warm = Hcached == Hcached;  // cache_active (hmc_state.py:43-44) is carried as "H_flf is not NaN"
     fetch(slot + W < nslots ? slot + W : slot);  // prefetch (unconditional, so waits stay countable): in flight during everything below
+    const uint32_t pid = (uint32_t)(a.first_pid + p);
+    RngKey key = a.key;
+    int k;
+    double dwell = 0.0;
+    T EXn, EVn, Hc;
+    bool tally_cold = false, r_applied = false;
+#pragma unroll 1
+    for (int it = 0; it < n_it; ++it) {
+    if constexpr (FUSED) {
+      stash_put<T, E>(stash_x, lane, x);
+      stash_put<T, E>(stash_v, lane, v);
+    }
+    const bool warm = Hcached == Hcached;  // cache_active (hmc_state.py:43-44) is carried as "H_flf is not NaN"
     const T H0 = EX0 + EV0;  // HMCState.H (hmc_state.py:80-84)
 
     // inverse-L proposal F L F; only H() of it is ever read (markov_jump_hmc.py:360,367)
@@ -939,14 +978,12 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     const T EXL = en.energy(x, m, lc);
     const T HL = EXL + EVL;
 
-    int k;
-    double dwell = 0.0;
     bool bad = false;
-    const uint32_t pid = (uint32_t)(a.first_pid + p);
-    T EXn, EVn, Hc = (T)__builtin_nan("");
-    bool tally_cold = false, r_applied = false;
+    Hc = (T)__builtin_nan("");
+    tally_cold = false;
+    r_applied = false;
     if constexpr (MODE == kModeMJHMC) {
-      decide<T, REPLAY>(a, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
+      decide<T, REPLAY>(a, key, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
       tally_cold = !warm;
       // successor state (markov_jump_hmc.py:399-410)
       if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
@@ -962,14 +999,14 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
         EVn = EV0;
       } else {  // R: refresh the momentum (hmc_state.py:121-129)
         stash_get<T, E>(stash_x, lane, x);
-        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m,
+        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, key, pid, m,
                                     a.r_keep, a.r_mix);
         stash_get<T, E>(stash_v, lane, v);
         EXn = EX0;
         EVn = kinetic<T, E>(v, m);
       }
     } else if constexpr (MODE == kModeCT) {
-      decide_ct<T, REPLAY>(a, m, H0, HL, alive ? p : 0, pid, k, dwell, bad);
+      decide_ct<T, REPLAY>(a, key, m, H0, HL, alive ? p : 0, pid, k, dwell, bad);
       if (k == 0) {  // FL: leap, then flip (markov_jump_hmc.py:258,278)
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = -v[e];
@@ -984,7 +1021,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
         EVn = EV0;
       } else {  // R (:285-286)
         stash_get<T, E>(stash_x, lane, x);
-        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m,
+        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, key, pid, m,
                                     a.r_keep, a.r_mix);
         stash_get<T, E>(stash_v, lane, v);
         EXn = EX0;
@@ -1001,9 +1038,9 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
         uflip = a.runif[a.N + pp];
         ugate = a.runif[2 * a.N];
       } else {
-        const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
-        const u32x4 f = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
-        const u32x4 g = philox4x32_10(0xFFFFFFFFu, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+        const u32x4 q = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
+        const u32x4 f = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotFlip, key.k0, key.k1);
+        const u32x4 g = philox4x32_10(0xFFFFFFFFu, key.tick_lo, key.tick_hi, kSlotFlip, key.k0, key.k1);
         uacc = u53(q.w2, q.w3);
         uflip = u53(f.w0, f.w1);
         ugate = u53(g.w2, g.w3);
@@ -1030,7 +1067,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
       r_applied = gate;
       if (gate) {  // state.R() on the whole batch (:138-141)
         stash_put<T, E>(stash_v, lane, v);
-        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, a.key, pid, m,
+        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, key, pid, m,
                                     a.r_keep, a.r_mix);
         stash_get<T, E>(stash_v, lane, v);
         EVn = kinetic<T, E>(v, m);
@@ -1041,20 +1078,54 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
       tally_cold = (accept && !flip);
     }
     any_bad |= (bad && alive);
+    if constexpr (FUSED) {
+      // bookkeeping of iteration `it`; the successor state becomes the next iteration's pre-move state
+      if (bad && alive) first_bad = min(first_bad, it);
+      const bool lead = alive && m.j == 0;
+      unsigned long long b0, b1, b2;
+      if constexpr (MODE == kModeControl) {
+        b0 = __ballot(lead && k == 3);
+        b1 = __ballot(lead && k == 2);
+        b2 = __ballot(lead && r_applied);
+      } else {
+        b0 = __ballot(lead && k == 0);
+        b1 = __ballot(lead && k == 1);
+        b2 = __ballot(lead && k == 2);
+      }
+      const unsigned long long b3 = __ballot(lead && tally_cold);
+      if (lane == 0) {
+        if (b0) atomicAdd(&fused_tally[it][0], (unsigned)__popcll(b0));
+        if (b1) atomicAdd(&fused_tally[it][1], (unsigned)__popcll(b1));
+        if (b2) atomicAdd(&fused_tally[it][2], (unsigned)__popcll(b2));
+        if (b3) atomicAdd(&fused_tally[it][3], (unsigned)__popcll(b3));
+      }
+      if (a.xiter) {  // sample ring: X and the dwelling times after every iteration
+        slot_store<T, E, FULLROW>((char*)(a.xiter + (size_t)it * a.xiter_stride) + slot * slot_bytes, lane_off,
+                                  chunk_stride, m, x);
+        a.dwell_ring[(size_t)it * a.Npad + p] = dwell;
+      }
+      EX0 = EXn;
+      EV0 = EVn;
+      Hcached = Hc;
+      key.tick_hi += (key.tick_lo == 0xFFFFFFFFu) ? 1u : 0u;
+      key.tick_lo += 1u;
+    }
+    }  // fused iterations
 
     // Stores are unconditional on purpose: rows beyond N are padding (allocated, never read back),
     // and every lane of a group writes the same scalar to the same address.  With no store behind
     // a branch the compiler can COUNT them, so the wait for the prefetched loads at the loop end is
     // vmcnt(#stores) instead of vmcnt(0) -- the wave never sits waiting for HBM write acks.
-    slot_store<T, E, FULLROW>((char*)a.X_out + slot * slot_bytes, lane_off, chunk_stride, m, x);
+    if (!FUSED || !a.xiter)
+      slot_store<T, E, FULLROW>((char*)a.X_out + slot * slot_bytes, lane_off, chunk_stride, m, x);
     slot_store<T, E, FULLROW>((char*)a.V_out + slot * slot_bytes, lane_off, chunk_stride, m, v);
     a.EX_out[p] = EXn;
     a.EV_out[p] = EVn;
     a.Hflf_out[p] = Hc;
     a.dwell[p] = dwell;
-    a.dwell_ring[p] = dwell;
+    if constexpr (!FUSED) a.dwell_ring[p] = dwell;
     a.trans[p] = (uint8_t)k;
-    if (alive && m.j == 0) {
+    if (!FUSED && alive && m.j == 0) {
       if constexpr (MODE == kModeControl) {
         nL += (k == 3);
         nF += (k == 2);
@@ -1066,6 +1137,20 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
       }
       nCold += tally_cold ? 1u : 0u;
     }
+  }
+  if constexpr (FUSED) {
+    for (int o = 32; o > 0; o >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, o));
+    if (first_bad != 0x7fffffff && lane == 0) {
+      a.ctl->failed = 1;
+      atomicMax(&a.ctl->inv_iter, 0x7fffffff - (a.iter + first_bad));
+    }
+    __syncthreads();
+    const int it = threadIdx.x >> 2, c = threadIdx.x & 3;
+    if (it < n_it) {
+      const unsigned t = fused_tally[it][c];
+      if (t) atomicAdd(&a.stats[4 * it + c], (unsigned long long)t);
+    }
+    return;
   }
   if (any_bad) {  // draw_from's ValueError (utils.py:43-48): the host rolls this attempt back
     a.ctl->failed = 1;
@@ -1168,21 +1253,21 @@ struct EnergyParams {
 
 // Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
 // (occupancy query, cached per instantiation), never more than there are slots to hand out.
-template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false>
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false, bool FUSED = false>
 inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   static int resident_blocks = 0;
   if (resident_blocks == 0) {
     int dev = 0, per_cu = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP>,
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP, FUSED>,
                                                        256, 0);
     resident_blocks = std::max(1, per_cu) * std::max(1, cus);
   }
   const int64_t nslots = a.Npad >> (6 - a.logG);
   const int64_t want = (nslots + 3) / 4;
   const unsigned grid = (unsigned)std::min<int64_t>(want, resident_blocks);
-  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP>), dim3(grid), dim3(256), 0, st, a, en);
+  hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP, FUSED>), dim3(grid), dim3(256), 0, st, a, en);
 }
 
 // Replay needs every recorded stream of the mode; it is a test path and exists only in the
@@ -1191,6 +1276,18 @@ template <class En, typename T, int E>
 inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool full = a.CH == (E / VecOf<T>::n) << a.logG;
   const bool replay = a.noise != nullptr;
+  if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
+    if (a.mode == kModeMJHMC) {
+      if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, true, true>(a, en, st);
+      else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, false, true>(a, en, st);
+      else launch_jump_r<En, T, E, kModeMJHMC, false, false, false, true>(a, en, st);
+    } else if (a.mode == kModeCT) {
+      launch_jump_r<En, T, E, kModeCT, false, false, false, true>(a, en, st);
+    } else {
+      launch_jump_r<En, T, E, kModeControl, false, false, false, true>(a, en, st);
+    }
+    return;
+  }
   if (a.mode == kModeMJHMC) {
     if (replay) launch_jump_r<En, T, E, kModeMJHMC, true, false>(a, en, st);
     else if (full && a.logG == 6 && !std::getenv("MJHMC_NO_WPP")) launch_jump_r<En, T, E, kModeMJHMC, false, true, true>(a, en, st);

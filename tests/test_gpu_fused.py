@@ -1,0 +1,120 @@
+"""GPU: fused launches (several sampling iterations per kernel launch, state kept on chip between them) are
+an implementation detail: mjhmc_iterate(n) must equal n single-iteration calls bit for bit -- state, energies,
+dwelling times, transitions, the per-iteration counters, the ring snapshots -- for every sampler mode and
+lane mapping, across the 64-iteration launch boundary, and when an iteration in the middle of a launch meets a
+non-finite rate (whole-batch abort, markov_jump_hmc.py:376-389)."""
+import numpy as np
+import pytest
+
+from tests.helpers import bits_equal
+
+pytestmark = pytest.mark.gpu
+FIELDS = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
+
+
+def _pair(kind, D, N, mode, seed=5, params=None, scale=1.0):
+    from mjhmc_amd import engine, _lib
+    rs = np.random.RandomState(D * 7 + N)
+    X0 = rs.randn(D, N) * scale
+    ctx = engine.context(0)
+    en = engine.DeviceEnergy(ctx, getattr(_lib, kind), D, params if params is not None else [1.0])
+    return [engine.DeviceSampler(en, X0, seed=seed, mode=mode) for _ in range(2)], _lib
+
+
+def _same_state(a, b, _lib, fields=FIELDS):
+    for f in fields:
+        fa, fb = a.read(getattr(_lib, 'F_' + f)), b.read(getattr(_lib, 'F_' + f))
+        assert bits_equal(fa, fb), f
+
+
+def _stats_tuple(st):
+    return (st.l, st.f, st.r, st.fl, st.n_cold, st.E_evals, st.dEdX_evals, st.nonfinite, st.L_used)
+
+
+@pytest.mark.parametrize('kind,D,N,mode_name,n_iter', [
+    ('E_ISO_GAUSS', 512, 130, 'MODE_MJHMC', 7),      # wave per particle
+    ('E_ISO_GAUSS', 64, 500, 'MODE_MJHMC', 70),      # crosses the 64-iteration launch boundary
+    ('E_ISO_GAUSS', 40, 129, 'MODE_MJHMC', 5),       # ragged rows (predicated chunks)
+    ('E_ISO_GAUSS', 2, 100, 'MODE_MJHMC', 9),
+    ('E_FUNNEL_NEAL', 32, 300, 'MODE_MJHMC', 6),
+    ('E_ISO_GAUSS', 16, 200, 'MODE_CONTROL', 12),
+    ('E_ISO_GAUSS', 24, 77, 'MODE_CTHMC', 12),
+])
+def test_fused_equals_single_iterations(kind, D, N, mode_name, n_iter):
+    params = [3.0] if kind == 'E_FUNNEL_NEAL' else [1.3]
+    from mjhmc_amd import _lib
+    mode = getattr(_lib, mode_name)
+    (a, b), _lib = _pair(kind, D, N, mode, params=params)
+    for s in (a, b):
+        s.set_hparams(0.2, 6, 0.1, 1.0, 0.5)
+    a.ring_alloc(n_iter)
+    b.ring_alloc(n_iter)
+    stats_a, done_a = a.iterate(n_iter, ring_slot0=0)
+    assert done_a == n_iter
+    stats_b = []
+    for i in range(n_iter):
+        st, d = b.iterate(1, ring_slot0=i)
+        assert d == 1
+        stats_b.append(st[0])
+    _same_state(a, b, _lib)
+    assert [_stats_tuple(s) for s in stats_a[:n_iter]] == [_stats_tuple(s) for s in stats_b]
+    assert bits_equal(a.ring_read(0, n_iter, stacked=True), b.ring_read(0, n_iter, stacked=True))
+    assert bits_equal(a.ring_read_dwell(0, n_iter), b.ring_read_dwell(0, n_iter))
+    # and without a ring, continuing from the live state that now sits in the last ring slot
+    stats_a, done_a = a.iterate(3)
+    for i in range(3):
+        b.iterate(1)
+    assert done_a == 3
+    _same_state(a, b, _lib)
+
+
+@pytest.mark.parametrize('D,N', [(512, 70), (24, 301)])
+def test_fused_failure_in_the_middle_of_a_launch(D, N):
+    """A few columns blow up after some iterations: the fused call must stop exactly where the sequence of
+    single iterations stops, with the same state, counters and RNG position."""
+    from mjhmc_amd import _lib
+    # Far out in the Gaussian the leapfrog energy error (~ eps^2 |x|^2 / 8) reaches several hundred, so now
+    # and then exp(H0 - H1) overflows: scan the initial scale for a first failure after a few good iterations
+    found = None
+    s_thr = np.sqrt(709.0 / (0.011 * D))     # scale at which the MEAN energy error of the L proposal overflows exp
+    for scale in np.linspace(0.6, 1.0, 161) * s_thr:
+        (p, _), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale))
+        p.set_hparams(0.5, 5, 0.1, 1.0, 0.5)
+        k = 0
+        while k < 30:
+            _, d = p.iterate(1)
+            if d == 0:
+                break
+            k += 1
+        if 1 <= k < 30:
+            found = (scale, k)
+            break
+    if found is None:
+        pytest.skip('no initial scale with a late first failure for this shape')
+    scale, k = found
+    eps = 0.5
+    (a, b), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale))
+    for s in (a, b):
+        s.set_hparams(eps, 5, 0.1, 1.0, 0.5)
+        s.ring_alloc(40)
+    stats_a, done_a = a.iterate(40, ring_slot0=0)
+    assert done_a == k
+    stats_b = []
+    for i in range(k + 1):
+        st, d = b.iterate(1, ring_slot0=i)
+        stats_b.append(st[0])
+        assert d == (1 if i < k else 0)
+    # dwelling_times / transitions are only defined once the retry has succeeded (the reference assigns them
+    # after draw_from returned, markov_jump_hmc.py:392-396): compared after the retry below
+    _same_state(a, b, _lib, fields=('X', 'V', 'EX', 'EV', 'HFLF'))
+    assert [_stats_tuple(s) for s in stats_a[:k + 1]] == [_stats_tuple(s) for s in stats_b]
+    assert stats_a[k].nonfinite == 1
+    assert bits_equal(a.ring_read(0, k, stacked=True), b.ring_read(0, k, stacked=True))
+    # both consumed the failed attempt's tick: the retry protocol continues identically
+    for s in (a, b):
+        s.set_hparams(eps * 0.5, 10, 0.1, 1.0, 0.5)
+        s.reset_flf_cache()
+    sa, da = a.iterate(2)
+    for _ in range(2):
+        sb, db = b.iterate(1)
+    _same_state(a, b, _lib)
