@@ -224,13 +224,21 @@ def main():
     if rank == 0:
         esize = 8 if w['dtype'] == 'float64' else 4
         units = w['D'] * w['N'] * w['L'] * args.steps * world
-        kern_ms = tim['jump_kernel_ms'] / max(tim['n_jump_launches'], 1)
-        abytes = algorithmic_bytes_per_particle(w['D'], esize) * w['N']
+        kern_ms = tim['jump_kernel_ms'] / max(tim['n_jump_launches'], 1)        # per sampling iteration
+        abytes = algorithmic_bytes_per_particle(w['D'], esize) * w['N']           # per sampling iteration
         achieved = abytes / (kern_ms * 1e-3) / 1e9
+        # elementwise energies: one launch covers up to 64 fused iterations (state stays on chip in between)
+        fused = w['kind'] not in ('pot', 'sic') and args.steps >= 2 and not os.environ.get('MJHMC_NO_FUSE')
+        n_launch = -(-args.steps // 64) if fused else args.steps
+        it_per_launch = args.steps / float(n_launch)
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(args.workload)
+            # PMC-measured HBM bytes of one launch (tools/reduce_pmc.py); only quoted when it was measured on
+            # launches of the same shape as the ones just timed
+            rec = json.load(open(tfile)).get(args.workload)
+            if isinstance(rec, dict) and abs(rec.get('iterations_per_launch', 0) - it_per_launch) < 1e-9:
+                traffic = rec['bytes_per_launch']
         n_l = sum(s.l for s in stats)
         n_cold = sum(s.n_cold for s in stats)
         if w['kind'] in ('pot', 'sic'):
@@ -245,10 +253,26 @@ def main():
                     'avg_launch_ms': kern_ms,
                     'launches_timed': tim['n_jump_launches'], 'algorithmic_flops_per_launch': flops}
         else:
+            # fp64 vector work actually executed per iteration: 6 flop per element and leapfrog step (two adds,
+            # one multiply-add pair kept as mul + add for bit parity, force, half-kick product), L steps, on
+            # the forward trajectory of every particle and the inverse one of the cold-cache particles, plus
+            # 4 flop per element for the two energy reductions.  Without FMA contraction the vector peak is
+            # half the 78.6 TFLOP/s datasheet figure.
+            vflops = (1.0 + n_cold / float(w['N'] * args.steps)) * (6.0 * w['L'] + 4.0) * w['D'] * w['N']
+            valu_tf = vflops / (kern_ms * 1e-3) / 1e12
             roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                    'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms,
-                    'launches_timed': tim['n_jump_launches'], 'algorithmic_bytes_per_launch': abytes}
+                    'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms * it_per_launch,
+                    'launches_timed': n_launch, 'iterations_per_launch': it_per_launch,
+                    'algorithmic_bytes_per_launch': abytes * it_per_launch,
+                    'note': ('fused launch: the state crosses HBM once per launch, not once per iteration, so the '
+                             'algorithmic rate is not limited by HBM; the limiter is the fp64 vector pipe (see valu)')
+                            if fused else 'one sampling iteration per launch',
+                    'valu': {'achieved': valu_tf, 'peak_no_fma': 39.3, 'unit': 'TFLOP/s', 'frac': valu_tf / 39.3,
+                             'dtype': w['dtype']}}
+            if w['dtype'] != 'float64':
+                roof['valu']['peak_no_fma'] = 78.6
+                roof['valu']['frac'] = valu_tf / 78.6
         out = {
             'metric': 'particle-steps/sec (ndims x nparticles x L)',
             'value': units / elapsed,

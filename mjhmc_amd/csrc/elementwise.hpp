@@ -162,6 +162,9 @@ struct NoLocal {};
 // TestGaussian: E = sum(x^2) / (2 sigma^2), dE/dx = x / sigma^2 (distributions.py:356-362)
 template <typename T>
 struct IsoGaussF {
+  // fused launches (several iterations per launch) pay off when one iteration is HBM-bound: measured 1.03-2.7x
+  // for the Gaussian forces at every row size, 0.93-0.99x for the funnel (exp + reductions: vector-pipe-bound)
+  static constexpr bool kFuse = true;
   T inv_s2;   // 1 / sigma^2
   T two_s2;   // 2 sigma^2
   using Ctx = NoCtx;
@@ -192,6 +195,7 @@ struct IsoGaussF {
 // (distributions.py:268-273)
 template <typename T>
 struct DiagGaussF {
+  static constexpr bool kFuse = true;
   const T* jdiag;  // zero padded to kParamPad elements
   using Ctx = NoCtx;
   template <int E>
@@ -226,6 +230,7 @@ struct DiagGaussF {
 // (distributions.py:295-304), operation order as written there.
 template <typename T>
 struct RoughWellF {
+  static constexpr bool kFuse = false;
   T s1sq;       // scale1^2
   T two_s1sq;   // 2 scale1^2
   T s2;
@@ -262,6 +267,7 @@ struct RoughWellF {
 // MultimodalGaussian as coded (distributions.py:323-335): separation vector = (2*sep, 0, ..., 0).
 template <typename T>
 struct MMGaussF {
+  static constexpr bool kFuse = false;
   T sep0;  // 2 * separation
   struct Ctx {
     T common;  // exp(sum 4 S X) = exp(4 sep0 x_0)
@@ -301,6 +307,7 @@ struct MMGaussF {
 // E = x0^2/(2 s^2) + e^{-x0} sum_k x_k^2 / 2 + (D-1) x0 / 2
 template <typename T>
 struct FunnelNealF {
+  static constexpr bool kFuse = false;
   T inv_s2;      // 1/scale^2
   T half_dm1;    // (D-1)/2
   struct Ctx {
@@ -337,6 +344,7 @@ struct FunnelNealF {
 // Funnel exactly as coded (tf_distributions.py:157-165): E = -(D-1) x0^2/s^2 - e^{-x0} sum_k x_k^2
 template <typename T>
 struct FunnelRefF {
+  static constexpr bool kFuse = false;
   T inv_s2;
   T dm1;  // D-1
   struct Ctx {
@@ -1276,7 +1284,7 @@ template <class En, typename T, int E>
 inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool full = a.CH == (E / VecOf<T>::n) << a.logG;
   const bool replay = a.noise != nullptr;
-  if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
+  if constexpr (En::kFuse) if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
     if (a.mode == kModeMJHMC) {
       if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, true, true>(a, en, st);
       else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, false, true>(a, en, st);
