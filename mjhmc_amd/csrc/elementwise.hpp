@@ -81,13 +81,14 @@ __device__ __forceinline__ int dim_of(const LaneMap& m, int e) {
 // round trips (ds_bpermute), which cost ~100+ cycles of latency per butterfly step.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  // bound_ctrl = true with full row / bank masks: every lane is written, so no zero-initialised destination
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ double swap16_sum(double v) {
   const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
@@ -165,8 +166,11 @@ struct IsoGaussF {
   // fused launches (several iterations per launch) pay off when one iteration is HBM-bound: measured 1.03-2.7x
   // for the Gaussian forces at every row size, 0.93-0.99x for the funnel (exp + reductions: vector-pipe-bound)
   static constexpr bool kFuse = true;
-  T inv_s2;   // 1 / sigma^2
-  T two_s2;   // 2 sigma^2
+  // the force is one multiplication by a constant: the half-kick factor is folded into it,
+  // c * (x * inv_s2) -> x * (c * inv_s2)  (identical bits when sigma is a power of two, e.g. the benchmark's 1)
+  static constexpr bool kLinearIso = true;
+  T inv_s2;      // 1 / sigma^2
+  T inv_two_s2;  // 1 / (2 sigma^2)
   using Ctx = NoCtx;
   template <int E>
   using Local = NoLocal<E>;
@@ -187,7 +191,7 @@ struct IsoGaussF {
     T s = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) s += x[e] * x[e];  // padded x are 0
-    return group_sum(s, m.G) / two_s2;
+    return group_sum(s, m.G) * inv_two_s2;
   }
 };
 
@@ -195,6 +199,7 @@ struct IsoGaussF {
 // (distributions.py:268-273)
 template <typename T>
 struct DiagGaussF {
+  static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = true;
   const T* jdiag;  // zero padded to kParamPad elements
   using Ctx = NoCtx;
@@ -230,6 +235,7 @@ struct DiagGaussF {
 // (distributions.py:295-304), operation order as written there.
 template <typename T>
 struct RoughWellF {
+  static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = false;
   T s1sq;       // scale1^2
   T two_s1sq;   // 2 scale1^2
@@ -267,6 +273,7 @@ struct RoughWellF {
 // MultimodalGaussian as coded (distributions.py:323-335): separation vector = (2*sep, 0, ..., 0).
 template <typename T>
 struct MMGaussF {
+  static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = false;
   T sep0;  // 2 * separation
   struct Ctx {
@@ -307,6 +314,7 @@ struct MMGaussF {
 // E = x0^2/(2 s^2) + e^{-x0} sum_k x_k^2 / 2 + (D-1) x0 / 2
 template <typename T>
 struct FunnelNealF {
+  static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = false;
   T inv_s2;      // 1/scale^2
   T half_dm1;    // (D-1)/2
@@ -344,6 +352,7 @@ struct FunnelNealF {
 // Funnel exactly as coded (tf_distributions.py:157-165): E = -(D-1) x0^2/s^2 - e^{-x0} sum_k x_k^2
 template <typename T>
 struct FunnelRefF {
+  static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = false;
   T inv_s2;
   T dm1;  // D-1
@@ -513,6 +522,13 @@ __device__ __forceinline__ void stash_get(typename VecOf<T>::type (*st)[64], int
   }
 }
 
+// c * dE/dx_d: the half-kick product of hmc_state.py:88,91
+template <class En, typename T, int E, class Ctx, class Lc>
+__device__ __forceinline__ T kick_product(const En& en, T c, T xe, int e, int d, const Ctx& ctx, const Lc& lc) {
+  if constexpr (En::kLinearIso) return xe * (c * en.inv_s2);
+  else return c * en.template grad<E>(xe, e, d, ctx, lc);
+}
+
 // M leapfrog steps, in place (hmc_state.py:86-100).  The half kicks are NOT merged, as in the
 // reference; c*g of the closing kick is reused by the next opening kick (same product).
 template <class En, typename T, int E>
@@ -522,7 +538,7 @@ __device__ __forceinline__ void trajectory(const En& en, const typename En::temp
   {
     const auto ctx = en.prep(x, m);
 #pragma unroll
-    for (int e = 0; e < E; ++e) cg[e] = chalf * en.template grad<E>(x[e], e, dim_of<T, E>(m, e), ctx, lc);
+    for (int e = 0; e < E; ++e) cg[e] = kick_product<En, T, E>(en, chalf, x[e], e, dim_of<T, E>(m, e), ctx, lc);
   }
   for (int s = 0; s < L; ++s) {
 #pragma unroll
@@ -533,7 +549,7 @@ __device__ __forceinline__ void trajectory(const En& en, const typename En::temp
     const auto ctx = en.prep(x, m);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      cg[e] = chalf * en.template grad<E>(x[e], e, dim_of<T, E>(m, e), ctx, lc);
+      cg[e] = kick_product<En, T, E>(en, chalf, x[e], e, dim_of<T, E>(m, e), ctx, lc);
       v[e] = v[e] + cg[e];
     }
   }
