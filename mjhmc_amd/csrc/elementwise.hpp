@@ -626,6 +626,69 @@ __device__ __forceinline__ void refresh_stash(typename VecOf<T>::type (*st)[64],
   }
 }
 
+// Transition rate exp(dH) ** .5 (markov_jump_hmc.py:341-347).  Where exp(dH) is a normal number the rate is
+// evaluated as exp(dH / 2) in one polynomial pass (within 1 ulp of the two-step value).  Where exp(dH)
+// overflows (-> inf -> the non-finite abort), is subnormal (its square root then has the reference's coarse
+// rounding) or is 0, and for NaN, the literal two-step form runs: thresholds and special values are exactly
+// those of the reference expression.
+__device__ __forceinline__ double jump_rate(double dH) {
+  if (!(dH > -708.0 && dH < 709.0)) return sqrt(exp(dH));
+  __builtin_amdgcn_sched_barrier(0);  // keep the chain compact: interleaved with its neighbours it costs ~20 VGPRs
+  const double h = 0.5 * dH;
+  const double n = __builtin_rint(h * __longlong_as_double(0x3ff71547652b82feLL));        // h / ln 2
+  double r = __builtin_fma(n, __longlong_as_double(0xbfe62e42fefa39efLL), h);             // - n ln2 (hi, lo)
+  r = __builtin_fma(n, __longlong_as_double(0xbc7abc9e3b39803fLL), r);
+  double p = r * __longlong_as_double(0x3e5ade156a5dcb37LL) + __longlong_as_double(0x3e928af3fca7ab0cLL);
+  p = __builtin_fma(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3f81111111122322LL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3fa55555555502a1LL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3fc5555555555511LL));
+  p = __builtin_fma(r, p, __longlong_as_double(0x3fe000000000000bLL));
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  const double rate = __builtin_amdgcn_ldexp(p, (int)n);
+  __builtin_amdgcn_sched_barrier(0);
+  return rate;
+}
+
+// -log(u) for u in (0, 1), the unit exponential behind draw_from (utils.py:42): fdlibm's e_log.c scheme
+// (error < 1 ulp) without its special cases -- u53() never returns 0 or 1 and its smallest value 2^-54 is a
+// normal number.  About half the vector instructions and half the dependent-chain length of the library log
+// (which carries double-double intermediates).  (Feeding the coefficients from scalar registers through inline
+// asm saved more instructions but cost ~30 VGPRs and an occupancy step: measured slower.)
+__device__ __forceinline__ double neg_log_unit(double u) {
+  __builtin_amdgcn_sched_barrier(0);
+  double m = __builtin_amdgcn_frexp_mant(u);  // [0.5, 1)
+  int k = __builtin_amdgcn_frexp_exp(u);
+  const bool low = m < __longlong_as_double(0x3fe6a09e667f3bcdLL);  // sqrt(1/2)
+  m = low ? m + m : m;  // [sqrt(1/2), sqrt(2))
+  k = low ? k - 1 : k;
+  const double f = m - 1.0;
+  const double t = 2.0 + f;
+  double rc = __builtin_amdgcn_rcp(t);  // s = f / t: reciprocal, two Newton steps, one residual correction
+  rc = __builtin_fma(__builtin_fma(-t, rc, 1.0), rc, rc);
+  rc = __builtin_fma(__builtin_fma(-t, rc, 1.0), rc, rc);
+  double sq = f * rc;
+  sq = __builtin_fma(__builtin_fma(-t, sq, f), rc, sq);
+  const double z = sq * sq;
+  const double w = z * z;
+  double t1 = w * __longlong_as_double(0x3fc39a09d078c69fLL) + __longlong_as_double(0x3fcc71c51d8e78afLL);  // Lg6, Lg4
+  t1 = w * __builtin_fma(w, t1, __longlong_as_double(0x3fd999999997fa04LL));                                        // Lg2
+  double t2 = w * __longlong_as_double(0x3fc2f112df3e5244LL) + __longlong_as_double(0x3fc7466496cb03deLL);  // Lg7, Lg5
+  t2 = __builtin_fma(w, t2, __longlong_as_double(0x3fd2492494229359LL));                                            // Lg3
+  t2 = z * __builtin_fma(w, t2, __longlong_as_double(0x3fe5555555555593LL));                                        // Lg1
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  const double ln2_hi = __longlong_as_double(0x3fe62e42fee00000LL), ln2_lo = __longlong_as_double(0x3dea39ef35793c76LL);
+  const double e = ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f) - dk * ln2_hi;
+  __builtin_amdgcn_sched_barrier(0);
+  return e;
+}
+
 __device__ __forceinline__ double wait_time(double rate, double e, bool& bad) {
   // utils.py:37-48: rate == 0 -> inf; finite -> exponential(scale=1/rate) == (1/rate)*std_exp; else error
   if (rate == 0.0) return __builtin_huge_val();
@@ -748,7 +811,7 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
   if (m.G >= 4) {
     const int role = m.j;  // 0: L clock, 1: R clock (and the FLF rate), 2..: F clock
     const T dH = H0 - ((role == 1) ? Hflf : HL);
-    const double rate01 = sqrt(exp((double)dH));  // exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347)
+    const double rate01 = jump_rate((double)dH);  // exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347)
     l_rate = group_lane(rate01, m, 0);
     const double flf_rate = group_lane(rate01, m, 1);
     const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
@@ -765,13 +828,13 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
         const u32x4 w = philox4x32_10(spid, key.tick_lo, key.tick_hi, kSlotExpLF, key.k0, key.k1);
         const u32x4 q = philox4x32_10(spid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
         const double uL = u53(w.w0, w.w1), uF = u53(w.w2, w.w3), uR = u53(q.w0, q.w1);
-        e = -log(role == 0 ? uL : (role == 1 ? uR : uF));
+        e = neg_log_unit(role == 0 ? uL : (role == 1 ? uR : uF));
       } else {
         const u32x4 w =
             philox4x32_10(pid, key.tick_lo, key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, key.k0, key.k1);
         const double uA = u53(w.w0, w.w1);
         const double uF = group_lane(u53(w.w2, w.w3), m, 0);
-        e = -log(role >= 2 ? uF : uA);
+        e = neg_log_unit(role >= 2 ? uF : uA);
       }
     }
     const double rate = (role == 0) ? l_rate : (role == 1 ? r_rate : f_rate);
@@ -781,9 +844,9 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
     dR = group_lane(d, m, 1);
     dF = group_lane(d, m, 2);
   } else {
-    l_rate = sqrt(exp((double)(H0 - HL)));
+    l_rate = jump_rate((double)(H0 - HL));
     __builtin_amdgcn_sched_barrier(0);  // keep the independent expansions from being interleaved:
-    const double flf_rate = sqrt(exp((double)(H0 - Hflf)));  // interleaved they cost ~90 extra VGPRs
+    const double flf_rate = jump_rate((double)(H0 - Hflf));  // interleaved they cost ~90 extra VGPRs
     __builtin_amdgcn_sched_barrier(0);
     const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
     f_rate = flf_rate - mn;
@@ -797,11 +860,11 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
       __builtin_amdgcn_sched_barrier(0);
       const u32x4 q = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
       __builtin_amdgcn_sched_barrier(0);
-      eL = -log(u53(w.w0, w.w1));
+      eL = neg_log_unit(u53(w.w0, w.w1));
       __builtin_amdgcn_sched_barrier(0);
-      eF = -log(u53(w.w2, w.w3));
+      eF = neg_log_unit(u53(w.w2, w.w3));
       __builtin_amdgcn_sched_barrier(0);
-      eR = -log(u53(q.w0, q.w1));
+      eR = neg_log_unit(u53(q.w0, q.w1));
       __builtin_amdgcn_sched_barrier(0);
     }
     bool ignore = false;
@@ -823,7 +886,7 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
 template <typename T, bool REPLAY>
 __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& key, const LaneMap& m, T H0, T HL,
                                           int64_t p, uint32_t pid, int& k, double& dwell, bool& bad) {
-  const double fl_rate = sqrt(exp((double)(H0 - HL)));
+  const double fl_rate = jump_rate((double)(H0 - HL));
   const double r_rate = a.p_r;
   double dFL, dF, dR;
   if (m.G >= 4) {
@@ -837,7 +900,7 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
           philox4x32_10(pid, key.tick_lo, key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, key.k0, key.k1);
       const double uA = u53(w.w0, w.w1);
       const double uF = group_lane(u53(w.w2, w.w3), m, 0);
-      e = -log(role >= 2 ? uF : uA);
+      e = neg_log_unit(role >= 2 ? uF : uA);
     }
     const double rate = (role == 0) ? fl_rate : (role == 1 ? r_rate : 1.0);
     bool ignore = false;
@@ -856,11 +919,11 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
       __builtin_amdgcn_sched_barrier(0);
       const u32x4 q = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
       __builtin_amdgcn_sched_barrier(0);
-      eFL = -log(u53(w.w0, w.w1));
+      eFL = neg_log_unit(u53(w.w0, w.w1));
       __builtin_amdgcn_sched_barrier(0);
-      eF = -log(u53(w.w2, w.w3));
+      eF = neg_log_unit(u53(w.w2, w.w3));
       __builtin_amdgcn_sched_barrier(0);
-      eR = -log(u53(q.w0, q.w1));
+      eR = neg_log_unit(u53(q.w0, q.w1));
       __builtin_amdgcn_sched_barrier(0);
     }
     bool ignore = false;

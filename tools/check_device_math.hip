@@ -1,0 +1,71 @@
+// Accuracy check of the hand-written transcendental kernels of the jump kernel against host libm.
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -ffp-contract=off -DMJHMC_JUMP_WAVES=1 -I mjhmc_amd/csrc tools/check_device_math.hip -o /tmp/cdm && /tmp/cdm
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "elementwise.hpp"
+
+__global__ void eval(const double* dH, const double* u, double* rate, double* nl, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    rate[i] = mjhmc::jump_rate(dH[i]);
+    nl[i] = mjhmc::neg_log_unit(u[i]);
+  }
+}
+
+static double ulps(double got, double want) {
+  if (std::isnan(got) && std::isnan(want)) return 0;
+  if (got == want) return 0;
+  if (!std::isfinite(got) || !std::isfinite(want)) return 1e300;
+  long long a, b;
+  std::memcpy(&a, &got, 8);
+  std::memcpy(&b, &want, 8);
+  return (double)std::llabs(a - b);
+}
+
+int main() {
+  std::vector<double> dH, u;
+  for (double x = -760; x <= 720; x += 0.0137) dH.push_back(x);
+  for (double x : {-745.2, -745.13, -745.0, -708.4, -708.0, -707.99, 0.0, 1e-300, -1e-300, 708.99, 709.0, 709.78, 709.79, 710.0,
+                   1e308, -1e308, (double)INFINITY, -(double)INFINITY, (double)NAN})
+    dH.push_back(x);
+  unsigned long long st = 88172645463325252ULL;
+  while (u.size() < dH.size()) {
+    st ^= st << 13;
+    st ^= st >> 7;
+    st ^= st << 17;
+    const double v = ((double)(st >> 11) + 0.5) * 0x1p-53;
+    u.push_back(u.size() % 5 == 0 ? v * 0x1p-30 : (u.size() % 7 == 0 ? 1.0 - v * 0x1p-20 : v));
+  }
+  u[0] = 0x1p-54;
+  u[1] = 1.0 - 0x1p-54;
+  const int n = (int)dH.size();
+  double *d_dH, *d_u, *d_r, *d_l;
+  hipMalloc(&d_dH, n * 8);
+  hipMalloc(&d_u, n * 8);
+  hipMalloc(&d_r, n * 8);
+  hipMalloc(&d_l, n * 8);
+  hipMemcpy(d_dH, dH.data(), n * 8, hipMemcpyHostToDevice);
+  hipMemcpy(d_u, u.data(), n * 8, hipMemcpyHostToDevice);
+  eval<<<(n + 255) / 256, 256>>>(d_dH, d_u, d_r, d_l, n);
+  std::vector<double> r(n), l(n);
+  hipMemcpy(r.data(), d_r, n * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(l.data(), d_l, n * 8, hipMemcpyDeviceToHost);
+  double worst_r = 0, worst_l = 0, worst_special = 0;
+  for (int i = 0; i < n; ++i) {
+    const double want_r = std::sqrt(std::exp(dH[i]));
+    const double e = ulps(r[i], want_r);
+    const bool fast = dH[i] > -708.0 && dH[i] < 709.0;
+    if (fast) worst_r = std::fmax(worst_r, e);
+    else worst_special = std::fmax(worst_special, e);
+    worst_l = std::fmax(worst_l, ulps(l[i], -std::log(u[i])));
+  }
+  std::printf("n=%d  jump_rate: max %.0f ulp on the fast range, %.0f ulp on the literal ranges;  neg_log_unit: max %.0f ulp\n", n,
+              worst_r, worst_special, worst_l);
+  // the literal ranges run the device library's exp and sqrt (subnormal results: a few ulp from glibc's)
+  return (worst_r <= 2 && worst_special <= 16 && worst_l <= 2) ? 0 : 1;
+}
