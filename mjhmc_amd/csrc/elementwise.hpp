@@ -633,7 +633,7 @@ __device__ __forceinline__ void refresh_stash(typename VecOf<T>::type (*st)[64],
 // those of the reference expression.
 __device__ __forceinline__ double jump_rate(double dH) {
   if (!(dH > -708.0 && dH < 709.0)) return sqrt(exp(dH));
-  __builtin_amdgcn_sched_barrier(0);  // keep the chain compact: interleaved with its neighbours it costs ~20 VGPRs
+  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
   const double h = 0.5 * dH;
   const double n = __builtin_rint(h * __longlong_as_double(0x3ff71547652b82feLL));        // h / ln 2
   double r = __builtin_fma(n, __longlong_as_double(0xbfe62e42fefa39efLL), h);             // - n ln2 (hi, lo)
@@ -650,7 +650,7 @@ __device__ __forceinline__ double jump_rate(double dH) {
   p = __builtin_fma(r, p, 1.0);
   p = __builtin_fma(r, p, 1.0);
   const double rate = __builtin_amdgcn_ldexp(p, (int)n);
-  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
   return rate;
 }
 
@@ -660,7 +660,7 @@ __device__ __forceinline__ double jump_rate(double dH) {
 // (which carries double-double intermediates).  (Feeding the coefficients from scalar registers through inline
 // asm saved more instructions but cost ~30 VGPRs and an occupancy step: measured slower.)
 __device__ __forceinline__ double neg_log_unit(double u) {
-  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
   double m = __builtin_amdgcn_frexp_mant(u);  // [0.5, 1)
   int k = __builtin_amdgcn_frexp_exp(u);
   const bool low = m < __longlong_as_double(0x3fe6a09e667f3bcdLL);  // sqrt(1/2)
@@ -685,7 +685,7 @@ __device__ __forceinline__ double neg_log_unit(double u) {
   const double dk = (double)k;
   const double ln2_hi = __longlong_as_double(0x3fe62e42fee00000LL), ln2_lo = __longlong_as_double(0x3dea39ef35793c76LL);
   const double e = ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f) - dk * ln2_hi;
-  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
   return e;
 }
 
@@ -1006,12 +1006,15 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     slot_load<T, E, FULLROW>((const char*)a.X_in + slot * slot_bytes, lane_off, chunk_stride, m, nx);
     slot_load<T, E, FULLROW>((const char*)a.V_in + slot * slot_bytes, lane_off, chunk_stride, m, nv);
   };
-  if (wave < nslots) fetch(wave);
+  // FUSED launches spend tens of microseconds per slot: its loads are issued at the top of the slot instead of
+  // one slot ahead, which frees the second register set (one more wave per SIMD)
+  if (!FUSED && wave < nslots) fetch(wave);
 
 #pragma unroll 1
   for (int64_t slot = wave; slot < nslots; slot += W) {
     const int64_t p = slot * ppw + gi;
     const bool alive = p < a.N;
+    if constexpr (FUSED) fetch(slot);
     // The slot's pre-move state (x0, v0) is parked in this wave's private LDS stripe (lane-linear
     // 16-byte chunks: conflict-free ds_write_b128 / ds_read_b128, no barrier -- every lane reads
     // back only what it wrote).  Registers then hold just the working trajectory and the
@@ -1030,7 +1033,8 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     use_here(EX0);
     use_here(EV0);
     use_here(Hcached);
-    fetch(slot + W < nslots ? slot + W : slot);  // prefetch (unconditional, so waits stay countable): in flight during everything below
+    if constexpr (!FUSED)
+      fetch(slot + W < nslots ? slot + W : slot);  // prefetch (unconditional, so waits stay countable): in flight during everything below
     const uint32_t pid = (uint32_t)(a.first_pid + p);
     RngKey key = a.key;
     int k;
