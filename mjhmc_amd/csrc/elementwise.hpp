@@ -529,28 +529,61 @@ __device__ __forceinline__ T kick_product(const En& en, T c, T xe, int e, int d,
   else return c * en.template grad<E>(xe, e, d, ctx, lc);
 }
 
-// M leapfrog steps, in place (hmc_state.py:86-100).  The half kicks are NOT merged, as in the
-// reference; c*g of the closing kick is reused by the next opening kick (same product).
-template <class En, typename T, int E>
+// v += c * dE/dx_d as one fused multiply-add
+template <class En, typename T, int E, class Ctx, class Lc>
+__device__ __forceinline__ T kick_fma(const En& en, T c, T xe, T ve, int e, int d, const Ctx& ctx, const Lc& lc) {
+  if constexpr (En::kLinearIso) return __builtin_fma(xe, c * en.inv_s2, ve);
+  else return __builtin_fma(c, en.template grad<E>(xe, e, d, ctx, lc), ve);
+}
+
+// M leapfrog steps, in place (hmc_state.py:86-100).
+// EXACT = true (the replay kernels, i.e. the golden-vector path): the reference's literal operation order --
+// half kicks NOT merged, every product rounded before its sum (the library is built with -ffp-contract=off);
+// c*g of the closing kick is reused by the next opening kick (same product).  For forces that are exact
+// products this reproduces NumPy's X and V bit for bit.
+// EXACT = false (counter-RNG kernels): the same integrator with the two half kicks between consecutive steps
+// merged into one (what the reference's compiled variant does, fast/hmc.py:6-98) and every update a single
+// fused multiply-add: 2 + grad instead of 5 + grad vector instructions per element and step.  Differs from the
+// literal order by rounding only (~1e-16 relative per step, inside the 1e-10 parity bar; the tests compare it
+// with the oracle's literal order on the same Philox streams).
+template <class En, typename T, int E, bool EXACT>
 __device__ __forceinline__ void trajectory(const En& en, const typename En::template Local<E>& lc, const LaneMap& m,
                                            T (&x)[E], T (&v)[E], int L, T eps, T chalf) {
-  T cg[E];
-  {
-    const auto ctx = en.prep(x, m);
+  if constexpr (EXACT) {
+    T cg[E];
+    {
+      const auto ctx = en.prep(x, m);
 #pragma unroll
-    for (int e = 0; e < E; ++e) cg[e] = kick_product<En, T, E>(en, chalf, x[e], e, dim_of<T, E>(m, e), ctx, lc);
-  }
-  for (int s = 0; s < L; ++s) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      v[e] = v[e] + cg[e];
-      x[e] = x[e] + eps * v[e];
+      for (int e = 0; e < E; ++e) cg[e] = kick_product<En, T, E>(en, chalf, x[e], e, dim_of<T, E>(m, e), ctx, lc);
     }
-    const auto ctx = en.prep(x, m);
+    for (int s = 0; s < L; ++s) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      cg[e] = kick_product<En, T, E>(en, chalf, x[e], e, dim_of<T, E>(m, e), ctx, lc);
-      v[e] = v[e] + cg[e];
+      for (int e = 0; e < E; ++e) {
+        v[e] = v[e] + cg[e];
+        x[e] = x[e] + eps * v[e];
+      }
+      const auto ctx = en.prep(x, m);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        cg[e] = kick_product<En, T, E>(en, chalf, x[e], e, dim_of<T, E>(m, e), ctx, lc);
+        v[e] = v[e] + cg[e];
+      }
+    }
+  } else {
+    if (L <= 0) return;
+    {
+      const auto ctx = en.prep(x, m);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = kick_fma<En, T, E>(en, chalf, x[e], v[e], e, dim_of<T, E>(m, e), ctx, lc);
+    }
+    const T cfull = chalf + chalf;
+    for (int s = 0; s < L; ++s) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = __builtin_fma(eps, v[e], x[e]);
+      const auto ctx = en.prep(x, m);
+      const T c = (s == L - 1) ? chalf : cfull;  // the closing kick of the trajectory is a half kick
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = kick_fma<En, T, E>(en, c, x[e], v[e], e, dim_of<T, E>(m, e), ctx, lc);
     }
   }
 }
@@ -1055,7 +1088,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     if (MODE == kModeMJHMC && !warm) {
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = -v[e];
-      trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+      trajectory<En, T, E, REPLAY>(en, lc, m, x, v, a.L, a.eps, a.chalf);
       const T ev = kinetic<T, E>(v, m);
       const T ex = en.energy(x, m, lc);
       Hflf = ex + ev;
@@ -1064,7 +1097,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     }
 
     // forward proposal L
-    trajectory<En, T, E>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+    trajectory<En, T, E, REPLAY>(en, lc, m, x, v, a.L, a.eps, a.chalf);
     const T EVL = kinetic<T, E>(v, m);
     const T EXL = en.energy(x, m, lc);
     const T HL = EXL + EVL;
