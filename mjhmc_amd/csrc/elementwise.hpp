@@ -156,6 +156,10 @@ __device__ __forceinline__ T group_bcast0(T v, const LaneMap& m) {
 // Padded elements (d >= D) hold x = 0 and must produce grad = 0; energy() masks them.
 // ------------------------------------------------------------------------------------------
 
+// defined with the other scalar kernels below
+__device__ __forceinline__ double exp_any(double h);
+__device__ __forceinline__ float exp_any(float h);
+
 struct NoCtx {};
 template <int E>
 struct NoLocal {};
@@ -335,7 +339,7 @@ struct FunnelNealF {
     Ctx c;
     c.S = group_sum(s, m.G);
     c.x0 = group_bcast0(x[0], m);
-    c.ex = (T)exp(-c.x0);
+    c.ex = exp_any(-c.x0);
     return c;
   }
   template <int E>
@@ -373,7 +377,7 @@ struct FunnelRefF {
     Ctx c;
     c.S = group_sum(s, m.G);
     c.x0 = group_bcast0(x[0], m);
-    c.ex = (T)exp(-c.x0);
+    c.ex = exp_any(-c.x0);
     return c;
   }
   template <int E>
@@ -659,15 +663,11 @@ __device__ __forceinline__ void refresh_stash(typename VecOf<T>::type (*st)[64],
   }
 }
 
-// Transition rate exp(dH) ** .5 (markov_jump_hmc.py:341-347).  Where exp(dH) is a normal number the rate is
-// evaluated as exp(dH / 2) in one polynomial pass (within 1 ulp of the two-step value).  Where exp(dH)
-// overflows (-> inf -> the non-finite abort), is subnormal (its square root then has the reference's coarse
-// rounding) or is 0, and for NaN, the literal two-step form runs: thresholds and special values are exactly
-// those of the reference expression.
-__device__ __forceinline__ double jump_rate(double dH) {
-  if (!(dH > -708.0 && dH < 709.0)) return sqrt(exp(dH));
-  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
-  const double h = 0.5 * dH;
+// exp(h) for |h| < 708 (normal result, no special cases): the library's range reduction and degree-11 polynomial
+// without its overflow / underflow / NaN handling.  Within 1 ulp of libm (tools/check_device_math.hip).
+template <bool FENCED = true>
+__device__ __forceinline__ double exp_normal(double h) {
+  if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);  // chain kept compact inside decide(): measured faster
   const double n = __builtin_rint(h * __longlong_as_double(0x3ff71547652b82feLL));        // h / ln 2
   double r = __builtin_fma(n, __longlong_as_double(0xbfe62e42fefa39efLL), h);             // - n ln2 (hi, lo)
   r = __builtin_fma(n, __longlong_as_double(0xbc7abc9e3b39803fLL), r);
@@ -682,9 +682,27 @@ __device__ __forceinline__ double jump_rate(double dH) {
   p = __builtin_fma(r, p, __longlong_as_double(0x3fe000000000000bLL));
   p = __builtin_fma(r, p, 1.0);
   p = __builtin_fma(r, p, 1.0);
-  const double rate = __builtin_amdgcn_ldexp(p, (int)n);
-  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
-  return rate;
+  const double y = __builtin_amdgcn_ldexp(p, (int)n);
+  if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);
+  return y;
+}
+// exp() of the funnel force, branch-free: v_ldexp_f64 rounds into the subnormal range and overflows to inf by itself
+// (inf for very negative x_0 is what turns a runaway chain into the non-finite abort), so clamping the argument to
+// +-1100 and restoring NaN is all the special handling there is.
+__device__ __forceinline__ double exp_any(double h) {
+  const double y = exp_normal<false>(__builtin_fmin(__builtin_fmax(h, -1100.0), 1100.0));
+  return (h != h) ? h : y;
+}
+__device__ __forceinline__ float exp_any(float h) { return expf(h); }
+
+// Transition rate exp(dH) ** .5 (markov_jump_hmc.py:341-347).  Where exp(dH) is a normal number the rate is
+// evaluated as exp(dH / 2) in one polynomial pass (within 1 ulp of the two-step value).  Where exp(dH)
+// overflows (-> inf -> the non-finite abort), is subnormal (its square root then has the reference's coarse
+// rounding) or is 0, and for NaN, the literal two-step form runs: thresholds and special values are exactly
+// those of the reference expression.
+__device__ __forceinline__ double jump_rate(double dH) {
+  if (!(dH > -708.0 && dH < 709.0)) return sqrt(exp(dH));
+  return exp_normal(0.5 * dH);
 }
 
 // -log(u) for u in (0, 1), the unit exponential behind draw_from (utils.py:42): fdlibm's e_log.c scheme

@@ -1,4 +1,5 @@
-"""Time the ring-resident autocorrelation against the NumPy restatement (same samples).
+"""Time the ring-resident autocorrelation (the comparison with the NumPy restatement lives in
+tests/test_gpu_autocor.py; the oracle is test infrastructure and is not imported from tools/).
 usage: python tools/autocor_bench.py [D N T]"""
 import sys
 import time
@@ -31,15 +32,7 @@ def main():
     ring_gb = D * N * T * 8 / 1e9
     print('ring %.2f GB  sampling %.3f s  autocor calls %s s  -> %.1f GB/s of ring' %
           (ring_gb, t_run, ['%.3f' % t for t in times], ring_gb / min(times)))
-    if ring_gb <= 4:
-        from oracle import autocor_oracle as aco
-        t0 = time.time()
-        samples = smp._stack(T, True)
-        t_dl = time.time() - t0
-        t0 = time.time()
-        ref = aco.fft_autocor(samples)
-        t_np = time.time() - t0
-        print('download %.2f s  numpy fft_autocor %.2f s  max|diff| %.2e' % (t_dl, t_np, np.abs(sums / sums[0] - ref).max()))
+    assert abs(sums[0]) > 0 and np.isfinite(sums).all()
 
 
 if __name__ == '__main__':
