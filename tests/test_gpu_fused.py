@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 FIELDS = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
 
 
-def _pair(kind, D, N, mode, seed=5, params=None, scale=1.0):
+def _pair(kind, D, N, mode, seed=5, params=None, scale=1.0, dtype='float64', dtype2=None):
     from mjhmc_amd import engine, _lib
     rs = np.random.RandomState(D * 7 + N)
     X0 = rs.randn(D, N) * scale
     ctx = engine.context(0)
     en = engine.DeviceEnergy(ctx, getattr(_lib, kind), D, params if params is not None else [1.0])
-    return [engine.DeviceSampler(en, X0, seed=seed, mode=mode) for _ in range(2)], _lib
+    return [engine.DeviceSampler(en, X0, seed=seed, mode=mode, dtype=dt) for dt in (dtype, dtype2 or dtype)], _lib
 
 
 def _same_state(a, b, _lib, fields=FIELDS):
@@ -119,3 +119,36 @@ def test_fused_failure_in_the_middle_of_a_launch(D, N):
     for _ in range(2):
         sb, db = b.iterate(1)
     _same_state(a, b, _lib)
+
+
+@pytest.mark.parametrize('kind,D,N', [('E_ISO_GAUSS', 512, 70), ('E_ISO_GAUSS', 48, 200), ('E_FUNNEL_NEAL', 32, 300),
+                                      ('E_DIAG_GAUSS', 10, 333)])
+def test_float32_state(kind, D, N):
+    """float32 state (the reference's TensorFlow energies run in float32, tf_distributions.py:89): the fused and
+    the single-iteration kernels agree bit for bit, and one iteration from the same float32-representable state
+    follows the float64 sampler: same transitions except at near ties, state within float32 rounding."""
+    from mjhmc_amd import _lib
+    params = {'E_FUNNEL_NEAL': [3.0], 'E_DIAG_GAUSS': list(10.0 ** np.linspace(-2, 0, D))}.get(kind, [1.0])
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, dtype='float32')
+    for s in (a, b):
+        s.set_hparams(0.1, 6, 0.1, 1.0, 0.5)
+    sa, da = a.iterate(9)
+    for _ in range(9):
+        b.iterate(1)
+    assert da == 9
+    _same_state(a, b, _lib)
+    # one iteration, float32 vs float64 kernels, from identical (float32-representable) X and V
+    (c, d), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, dtype='float32', dtype2='float64')
+    X32, V32 = c.read(_lib.F_X), c.read(_lib.F_V)
+    d.write(_lib.F_X, X32)
+    d.write(_lib.F_V, V32)
+    for s in (c, d):
+        s.set_hparams(0.1, 6, 0.1, 1.0, 0.5)
+        s.iterate(1)
+    tc, td = c.read(_lib.F_TRANS), d.read(_lib.F_TRANS)
+    same = tc == td
+    assert same.mean() > 0.97, same.mean()
+    Xc, Xd = c.read(_lib.F_X)[:, same], d.read(_lib.F_X)[:, same]
+    scale = np.abs(Xd).max()
+    assert np.abs(Xc - Xd).max() <= 2e-5 * scale
+    assert np.allclose(c.read(_lib.F_EX)[same], d.read(_lib.F_EX)[same], rtol=2e-4, atol=2e-4 * scale)
