@@ -449,6 +449,20 @@ struct EvalArgs {
   RngKey key;
 };
 
+// inverse-L pass over a compacted list of cold-cache particles (see mjhmc_flf_kernel)
+template <typename T>
+struct FlfArgs {
+  const T* X;         // [N][pitch] pre-move state
+  const T* V;
+  T* H_out;           // [N]: H() of the inverse-L proposal, written for the listed particles only
+  const int* list;    // particle indices with a cold cache
+  const int* count;   // how many
+  const Control* ctl;
+  int D, pitch, CH, logG;
+  int L;
+  T eps, chalf;
+};
+
 // ------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------
@@ -1323,6 +1337,42 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------
+// Inverse-L proposal (F L F, hmc_state.py:109-119) of the cold-cache particles only, compacted.
+// With several particles per wavefront the jump kernel pays for the second trajectory in every wave that holds
+// at least ONE cold particle (C4, 16 particles per wave, 7 % cold: 69 % of the waves).  This kernel runs the same
+// trajectory code on the cold particles packed densely -- the list comes from cold_list_kernel -- and writes
+// H_flf into the vector the jump kernel then reads as "cache warm".  Same code, same inputs: same bits.
+// ------------------------------------------------------------------------------------------
+template <class En, typename T, int E>
+__global__ __launch_bounds__(256) void mjhmc_flf_kernel(const FlfArgs<T> a, const En en) {
+  if (a.ctl->failed) return;
+  const int n_cold = *a.count;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int G = 1 << a.logG;
+  if ((((int64_t)blockIdx.x * 256) >> a.logG) >= n_cold) return;  // whole block beyond the list
+  const int64_t idx = tid >> a.logG;
+  const bool live = idx < n_cold;
+  const int64_t p = a.list[live ? idx : 0];
+  LaneMap m;
+  m.j = (int)(tid & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
+  m.wpp = false;
+  T x[E], v[E];
+  load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
+  load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
+  const auto lc = en.template local<E>(m);
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = -v[e];
+  trajectory<En, T, E, false>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+  const T ev = kinetic<T, E>(v, m);
+  const T ex = en.energy(x, m, lc);
+  if (live && m.j == 0) a.H_out[p] = ex + ev;
+}
+
+// ------------------------------------------------------------------------------------------
 // evaluation kernel: E(X), dEdX(X), optionally kinetic energy / generated initial momentum
 // (HMCState.__init__, hmc_state.py:24-39; Distribution.E/dEdX, distributions.py:62-81)
 // ------------------------------------------------------------------------------------------
@@ -1445,6 +1495,12 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
 }
 
 template <class En, typename T, int E>
+inline void launch_flf_t(const FlfArgs<T>& a, const En& en, int64_t n_max, hipStream_t st) {
+  const int64_t threads = n_max << a.logG;  // grid for the worst case; blocks beyond the list return at once
+  hipLaunchKernelGGL((mjhmc_flf_kernel<En, T, E>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, en);
+}
+
+template <class En, typename T, int E>
 inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
   const int64_t threads = a.N << a.logG;
   const unsigned grid = (unsigned)((threads + 255) / 256);
@@ -1465,6 +1521,18 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
     else if (E == 16) launch_jump_t<decltype(en), float, 16>(a, en, st);                                  \
     else launch_jump_t<decltype(en), float, 32>(a, en, st);                                               \
   }                                                                                                       \
+  void NAME##_flf_f64(const FlfArgs<double>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) { \
+    const auto en = MAKE64(ep);                                                                           \
+    if (E == 2) launch_flf_t<decltype(en), double, 2>(a, en, n, st);                                      \
+    else if (E == 8) launch_flf_t<decltype(en), double, 8>(a, en, n, st);                                 \
+    else launch_flf_t<decltype(en), double, 16>(a, en, n, st);                                            \
+  }                                                                                                       \
+  void NAME##_flf_f32(const FlfArgs<float>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) { \
+    const auto en = MAKE32(ep);                                                                           \
+    if (E == 4) launch_flf_t<decltype(en), float, 4>(a, en, n, st);                                       \
+    else if (E == 16) launch_flf_t<decltype(en), float, 16>(a, en, n, st);                                \
+    else launch_flf_t<decltype(en), float, 32>(a, en, n, st);                                             \
+  }                                                                                                       \
   void NAME##_eval_f64(const EvalArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {        \
     const auto en = MAKE64(ep);                                                                           \
     if (E == 2) launch_eval_t<decltype(en), double, 2>(a, en, st);                                        \
@@ -1481,6 +1549,8 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
 #define MJHMC_DECLARE_ENERGY_LAUNCHERS(NAME)                                                       \
   void NAME##_jump_f64(const JumpArgs<double>&, const EnergyParams&, int, hipStream_t);           \
   void NAME##_jump_f32(const JumpArgs<float>&, const EnergyParams&, int, hipStream_t);            \
+  void NAME##_flf_f64(const FlfArgs<double>&, const EnergyParams&, int, int64_t, hipStream_t);    \
+  void NAME##_flf_f32(const FlfArgs<float>&, const EnergyParams&, int, int64_t, hipStream_t);     \
   void NAME##_eval_f64(const EvalArgs<double>&, const EnergyParams&, int, hipStream_t);           \
   void NAME##_eval_f32(const EvalArgs<float>&, const EnergyParams&, int, hipStream_t);
 

@@ -152,3 +152,26 @@ def test_float32_state(kind, D, N):
     scale = np.abs(Xd).max()
     assert np.abs(Xc - Xd).max() <= 2e-5 * scale
     assert np.allclose(c.read(_lib.F_EX)[same], d.read(_lib.F_EX)[same], rtol=2e-4, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize('kind,D,N', [('E_FUNNEL_NEAL', 32, 20000), ('E_ISO_GAUSS', 6, 70001), ('E_ROUGH_WELL', 40, 16400)])
+def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
+    """Big batches with several particles per wave run the inverse-L trajectory of the cold-cache particles in a
+    separate compacted pass (cold_list_kernel + mjhmc_flf_kernel); it must be invisible: state, scalars, transitions
+    and the per-iteration counters (the cold tallies now come from the list lengths) equal the in-kernel form."""
+    from mjhmc_amd import _lib
+    params = {'E_FUNNEL_NEAL': [3.0], 'E_ROUGH_WELL': [100.0, 4.0]}.get(kind, [1.0])
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params)
+    for s in (a, b):
+        s.set_hparams(0.05, 7, 0.1, 1.0, 0.5)
+    stats_a, stats_b = [], []
+    for it in range(4):
+        monkeypatch.delenv('MJHMC_NO_COMPACT', raising=False)
+        st, d = a.iterate(1) if it % 2 == 0 else a.iterate(3)
+        stats_a += st
+        monkeypatch.setenv('MJHMC_NO_COMPACT', '1')
+        st, d = b.iterate(1) if it % 2 == 0 else b.iterate(3)
+        stats_b += st
+    _same_state(a, b, _lib)
+    assert [_stats_tuple(s) for s in stats_a] == [_stats_tuple(s) for s in stats_b]
+    assert sum(s.n_cold for s in stats_a) > 0 and stats_a[0].n_cold == N        # first iteration: every cache is cold
