@@ -1,0 +1,134 @@
+"""GPU: BASELINE.json's full sizes (configs 2-4; configs[1] is in test_gpu_parity.py).  The oracle cannot run
+10^5 .. 10^6 particles in seconds, so each test checks size-independent properties on the whole batch (counter
+identities, cache bookkeeping, stored energies == energies re-evaluated from the stored state) and a random
+column subset against the oracle driven by the same Philox streams (the RNG is keyed by global particle id).
+
+Tolerances: float64 elementwise energies 1e-10 relative and bit-exact transitions; the dense energies run in
+float32 / bf16 on the device and are compared with the float64 oracle from identical inputs as in
+test_gpu_parity.py (transitions equal except at near ties)."""
+import numpy as np
+import pytest
+
+import bench
+from oracle import mjhmc_oracle as orc
+from tests.test_gpu_parity import close, to_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_size_c4_funnel():
+    """configs[3]: Neal funnel, ndims=32, nparticles=1000000, L=15, float64 (whole batch on one GPU)."""
+    from mjhmc_amd import engine, _lib
+    w = bench.WORKLOADS['c4']
+    D, N, L, eps, beta = w['D'], w['N'], w['L'], w['eps'], w['beta']
+    X0 = bench.initial_state(w, 0)
+    ctx = engine.context(0)
+    en = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, D, w['params'])
+    s = engine.DeviceSampler(en, X0, seed=11)
+    p_r = -np.log(1 - beta) * 0.5
+    s.set_hparams(eps, L, p_r, 1.0)
+    T = 3
+    stats = []
+    for _ in range(T):                       # single launches: the compacted inverse-L pass runs at this size
+        st, done = s.iterate(1)
+        assert done == 1
+        stats += st
+    n_cold_expected = N
+    for st in stats:
+        assert st.l + st.f + st.r == N and st.nonfinite == 0
+        assert st.n_cold == n_cold_expected
+        assert st.E_evals == N + st.n_cold and st.dEdX_evals == L * (N + st.n_cold)
+        n_cold_expected = N - st.l
+    trans, cache = s.read(_lib.F_TRANS), s.read(_lib.F_CACHE)
+    assert np.array_equal(cache == 1, trans == 0)
+    X, V, EX, EV = s.read(_lib.F_X), s.read(_lib.F_V), s.read(_lib.F_EX), s.read(_lib.F_EV)
+    o_en = orc.FunnelNeal(scale=w['params'][0])
+    cols = np.sort(np.random.RandomState(4).choice(N, size=64, replace=False))
+    assert close(EX[cols], o_en.E_val(X[:, cols])[0]) and close(EV, np.sum(V ** 2, axis=0) / 2.)
+    E_dev, _ = en.eval(X[:, :4096], want_grad=False)
+    assert close(EX[:4096], E_dev)
+    o = orc.MarkovJumpHMC(o_en, X0[:, cols], epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(11, cols))
+    for _ in range(T):
+        o.sampling_iteration()
+    assert np.array_equal(trans[cols], o.last_transition)
+    assert close(X[:, cols], o.state.X) and close(V[:, cols], o.state.V)
+    assert close(EX[cols], o.state.EX[0]) and close(s.read(_lib.F_DWELL)[cols], o.dwelling_times)
+
+
+def _dense_subset_check(s, o, cols, N, state_tol, ex_rtol, ex_atol, min_agree):
+    tr, tro = s._dev.read(8), o.last_transition
+    same = tr[cols] == tro
+    assert same.mean() >= min_agree, same.mean()
+    Xd, Vd = s.state.X[:, cols], s.state.V[:, cols]
+    scale = max(1.0, np.abs(o.state.X).max())
+    assert np.abs(Xd[:, same] - o.state.X[:, same]).max() <= state_tol * scale
+    assert np.allclose(s.state.EX[0, cols][same], o.state.EX[0, same], rtol=ex_rtol, atol=ex_atol)
+    assert s.l_count + s.f_count + s.r_count == N
+
+
+def test_full_size_c3_product_of_t():
+    """configs[2]: ProductOfT, ndims=nbasis=512, nparticles=100000, L=20, float32 on the matrix cores."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import ProductOfT
+    w = bench.WORKLOADS['c3']
+    D, N, L, eps, beta = w['D'], w['N'], w['L'], w['eps'], w['beta']
+    W, lognu = bench.pot_model(D)
+    X0 = bench.initial_state(w, 0)
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0
+    d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W)
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=21, resample=False)
+    cols = np.sort(np.random.RandomState(5).choice(N, size=48, replace=False))
+    o = orc.MarkovJumpHMC(orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64), X0[:, cols], epsilon=eps, beta=beta,
+                          num_leapfrog_steps=L, resample=False, rng=orc.PhiloxRNG(21, cols))
+    V0 = s.state.V                                          # float32-rounded tick-0 momentum: identical inputs
+    assert np.allclose(V0[:, cols], o.state.V, atol=1e-6)
+    o.state.V[:] = V0[:, cols]
+    o.state.refresh_EV()
+    d.E_count = d.dEdX_count = 0
+    s.sampling_iteration()
+    o.sampling_iteration()
+    assert d.E_count == 2 * N and d.dEdX_count == 2 * N * L   # first iteration: every inverse-L cache is cold
+    _dense_subset_check(s, o, cols, N, state_tol=2e-4, ex_rtol=1e-4, ex_atol=1e-3, min_agree=0.95)
+    # stored energies == energies re-evaluated (device, float32) from the stored state
+    Xs = s.state.X[:, :2048]
+    assert np.allclose(s.state.EX[0, :2048], d.E(Xs)[0], rtol=2e-5, atol=1e-3)
+    cache = s.state.cache_active
+    assert np.array_equal(cache, s._dev.read(8) == 0)
+
+
+def test_full_size_c5_sparse_image_code():
+    """configs[4]: SparseImageCode, 1024 coefficients / 256-pixel patch, nparticles=200000 (the whole batch on one
+    GPU; bench.py runs the 25000-per-GPU share), L=25, bf16 state / fp32 accumulate."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import SparseImageCode
+    w = dict(bench.WORKLOADS['c5'], N=200000)
+    N, L, eps, beta = w['N'], w['L'], w['eps'], w['beta']
+    B, y, a0 = bench.sic_model()
+    X0 = to_bf16(bench.initial_state(w, 0))
+    d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y.reshape(256, 1), init=X0)
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=31, resample=False)
+    cols = np.sort(np.random.RandomState(6).choice(N, size=48, replace=False))
+    en = orc.SparseImageCode(to_bf16(B), y.reshape(1, -1), lmbda=0.01, cauchy=True)
+    o = orc.MarkovJumpHMC(en, X0[:, cols], epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(31, cols))
+    V0 = s.state.V[:, cols]
+    assert np.abs(V0 - o.state.V).max() < 2e-2 and np.array_equal(V0, to_bf16(V0))
+    o.state.V[:] = V0
+    o.state.refresh_EV()
+    d.E_count = d.dEdX_count = 0
+    s.sampling_iteration()
+    o.sampling_iteration()
+    assert d.E_count == 2 * N and d.dEdX_count == 2 * N * L
+    tr, tro = s._dev.read(8), o.last_transition
+    same = tr[cols] == tro
+    assert same.mean() >= 0.85, same.mean()
+    moved = same & (tro == 0)
+    Xd = s.state.X[:, cols]
+    assert np.abs(Xd[:, moved] - o.state.X[:, moved]).max() < 3e-2 * max(1.0, np.abs(o.state.X).max())
+    assert np.allclose(s.state.EX[0, cols][moved], o.state.EX[0, moved], rtol=2e-2, atol=0.5)
+    assert s.l_count + s.f_count + s.r_count == N
+    assert np.array_equal(s.state.cache_active, tr == 0)
