@@ -194,7 +194,7 @@ struct IsoGaussF {
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
     T s = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += x[e] * x[e];  // padded x are 0
+    for (int e = 0; e < E; ++e) s = __builtin_fma(x[e], x[e], s);  // padded x are 0; sums are compared at 1e-10, not bitwise
     return group_sum(s, m.G) * inv_two_s2;
   }
 };
@@ -230,7 +230,7 @@ struct DiagGaussF {
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>& lc) const {
     T s = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += x[e] * (lc.j[e] * x[e]);
+    for (int e = 0; e < E; ++e) s = __builtin_fma(x[e], lc.j[e] * x[e], s);
     return group_sum(s, m.G) / T(2);
   }
 };
@@ -610,7 +610,7 @@ template <typename T, int E>
 __device__ __forceinline__ T kinetic(const T (&v)[E], const LaneMap& m) {
   T s = 0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) s += v[e] * v[e];
+  for (int e = 0; e < E; ++e) s = __builtin_fma(v[e], v[e], s);
   return group_sum(s, m.G) / T(2);  // hmc_state.py:50
 }
 
