@@ -276,13 +276,26 @@ __global__ void narrow_vec(const double* __restrict__ src, T* __restrict__ dst, 
   if (i < n) dst[i] = (T)src[i];
 }
 
-// indices of the particles whose inverse-L cache is cold (H_flf is NaN), in arbitrary order.  Each block scans
+// indices of the particles that satisfy a predicate (inverse-L cache cold; moved by R), in arbitrary order.  Each block scans
 // kColdChunk particles, collects its hits in LDS and reserves its stretch of the list with ONE global atomic
 // (a global atomic per wave serialised on the single counter: 178 us for 10^6 particles, this form ~10 us).
 constexpr int kColdChunk = 4096;
 template <typename T>
-__global__ __launch_bounds__(1024) void cold_list_kernel(const T* __restrict__ Hflf, int64_t N, const Control* ctl,
-                                                         int* __restrict__ list, int* __restrict__ count) {
+struct ColdCache {  // H_flf is NaN
+  const T* h;
+  __device__ bool operator()(int64_t p) const {
+    const T v = h[p];
+    return v != v;
+  }
+};
+struct MovedBy {  // trans[p] == k
+  const uint8_t* trans;
+  uint8_t k;
+  __device__ bool operator()(int64_t p) const { return trans[p] == k; }
+};
+template <class Pred>
+__global__ __launch_bounds__(1024) void compact_list_kernel(const Pred pred, int64_t N, const Control* ctl,
+                                                            int* __restrict__ list, int* __restrict__ count) {
   __shared__ int hits[kColdChunk];
   __shared__ int n_hits, base;
   if (ctl->failed) return;
@@ -291,11 +304,7 @@ __global__ __launch_bounds__(1024) void cold_list_kernel(const T* __restrict__ H
   const int lane = threadIdx.x & 63;
   for (int k = 0; k < kColdChunk / 1024; ++k) {
     const int64_t p = (int64_t)blockIdx.x * kColdChunk + k * 1024 + threadIdx.x;
-    bool cold = false;
-    if (p < N) {
-      const T h = Hflf[p];
-      cold = h != h;
-    }
+    const bool cold = p < N && pred(p);
     const unsigned long long mask = __ballot(cold);
     if (mask) {
       int at = 0;
@@ -994,6 +1003,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     a.logG = s->sh.logG;
     a.L = s->L;
     a.iter = l.i0;
+    a.defer_r = 0;
     a.n_fuse = l.K;
     if (ring_slot0 >= 0) {
       a.xiter = (T*)((char*)s->ring + (size_t)(ring_slot0 + l.i0) * mb);
@@ -1105,13 +1115,13 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       HIPCHK(hipMalloc((void**)&s->flf_list, (size_t)s->Npad * sizeof(int)));
       HIPCHK(hipMalloc(&s->Hpre, (size_t)s->Npad * ssize(s)));
     }
-    if (s->flf_cap < n_iter) {
+    if (s->flf_cap < n_iter) {  // [n_iter] cold counts, then [n_iter] R-mover counts
       if (s->flf_counts) HIPCHK(hipFree(s->flf_counts));
       s->flf_counts = nullptr;
-      HIPCHK(hipMalloc((void**)&s->flf_counts, (size_t)n_iter * sizeof(int)));
+      HIPCHK(hipMalloc((void**)&s->flf_counts, (size_t)2 * n_iter * sizeof(int)));
       s->flf_cap = n_iter;
     }
-    HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)n_iter * sizeof(int), s->stream));
+    HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)2 * n_iter * sizeof(int), s->stream));
   }
 
   std::vector<void*> xout(n_iter);
@@ -1171,6 +1181,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.L = s->L;
     a.iter = i;
     a.n_fuse = 0;
+    a.defer_r = 0;
     a.xiter = nullptr;
     a.xiter_stride = 0;
     a.eps = (T)s->eps;
@@ -1261,8 +1272,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       }
     } else {
       if (compact) {
-        hipLaunchKernelGGL(cold_list_kernel<T>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)), dim3(1024), 0, s->stream,
-                           a.Hflf_in, s->N, s->ctl, s->flf_list, s->flf_counts + i);
+        hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)),
+                           dim3(1024), 0, s->stream, ColdCache<T>{a.Hflf_in}, s->N, s->ctl, s->flf_list, s->flf_counts + i);
         HIPCHK(hipMemcpyAsync(s->Hpre, a.Hflf_in, (size_t)s->N * sizeof(T), hipMemcpyDeviceToDevice, s->stream));
         FlfArgs<T> fa;
         fa.X = a.X_in;
@@ -1280,8 +1291,30 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         fa.chalf = a.chalf;
         TRY(dispatch_flf<T>(s->en->ep.kind, fa, s->en->ep, s->sh.E, s->N, s->stream));
         a.Hflf_in = (const T*)s->Hpre;  // every cache reads as warm in the jump kernel
+        a.defer_r = 1;                  // and the momentum refresh of the R-movers follows as a compacted pass
       }
       TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+      if (compact) {
+        int* r_count = s->flf_counts + n_iter + i;
+        hipLaunchKernelGGL(compact_list_kernel<MovedBy>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)), dim3(1024),
+                           0, s->stream, MovedBy{s->trans, 2}, s->N, s->ctl, s->flf_list, r_count);
+        RefreshArgs<T> ra;
+        ra.V_in = a.V_in;
+        ra.V_out = a.V_out;
+        ra.EV_out = a.EV_out;
+        ra.list = s->flf_list;
+        ra.count = r_count;
+        ra.ctl = s->ctl;
+        ra.first_pid = s->first_pid;
+        ra.D = a.D;
+        ra.pitch = a.pitch;
+        ra.CH = a.CH;
+        ra.logG = a.logG;
+        ra.r_keep = a.r_keep;
+        ra.r_mix = a.r_mix;
+        ra.key = a.key;
+        launch_refresh<T>(ra, s->sh.E, s->N, s->stream);
+      }
     }
     HIPCHK(hipGetLastError());
     xin = xo;

@@ -425,6 +425,7 @@ struct JumpArgs {
   // registers / LDS between them (iteration it uses RNG tick key.tick + it and stats[4 * it ...]).
   // xiter != nullptr: X after iteration it is also recorded at xiter + it * xiter_stride (ring slots) and
   // its dwelling times at dwell_ring + it * Npad; X_out is then not written (the last slot is the live state).
+  int defer_r;          // != 0: R-movers keep their old momentum here; mjhmc_refresh_kernel draws the new one
   int n_fuse;
   T* xiter;
   size_t xiter_stride;  // elements of T between consecutive ring slots
@@ -461,6 +462,21 @@ struct FlfArgs {
   int D, pitch, CH, logG;
   int L;
   T eps, chalf;
+};
+
+// momentum refresh of the compacted R-movers (see mjhmc_refresh_kernel)
+template <typename T>
+struct RefreshArgs {
+  const T* V_in;      // [N][pitch] pre-move momentum
+  T* V_out;           // rows of the listed particles are overwritten with the refreshed momentum
+  T* EV_out;          // and their kinetic energy
+  const int* list;
+  const int* count;
+  const Control* ctl;
+  int64_t first_pid;
+  int D, pitch, CH, logG;
+  T r_keep, r_mix;
+  RngKey key;         // the attempt's tick: the same normals the jump kernel would have drawn
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1155,11 +1171,16 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
         EVn = EV0;
       } else {  // R: refresh the momentum (hmc_state.py:121-129)
         stash_get<T, E>(stash_x, lane, x);
-        refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, key, pid, m,
-                                    a.r_keep, a.r_mix);
-        stash_get<T, E>(stash_v, lane, v);
+        if (!REPLAY && a.defer_r) {  // done by mjhmc_refresh_kernel on the compacted R-movers (see there)
+          stash_get<T, E>(stash_v, lane, v);
+          EVn = EV0;
+        } else {
+          refresh_stash<T, E, REPLAY>(stash_v, lane, a.noise + (size_t)(alive ? p : 0) * a.pitch, key, pid, m,
+                                      a.r_keep, a.r_mix);
+          stash_get<T, E>(stash_v, lane, v);
+          EVn = kinetic<T, E>(v, m);
+        }
         EXn = EX0;
-        EVn = kinetic<T, E>(v, m);
       }
     } else if constexpr (MODE == kModeCT) {
       decide_ct<T, REPLAY>(a, key, m, H0, HL, alive ? p : 0, pid, k, dwell, bad);
@@ -1370,6 +1391,56 @@ __global__ __launch_bounds__(256) void mjhmc_flf_kernel(const FlfArgs<T> a, cons
   const T ev = kinetic<T, E>(v, m);
   const T ex = en.energy(x, m, lc);
   if (live && m.j == 0) a.H_out[p] = ex + ev;
+}
+
+// ------------------------------------------------------------------------------------------
+// HMCState.R (hmc_state.py:121-129) for the particles that chose R, compacted.  With 16 particles per wavefront and
+// ~5 % R-movers more than half of the jump kernel's waves would run the Philox + Box-Muller block for one lane
+// group's sake (~1000 vector instructions for 8 elements per lane).  The jump kernel leaves those particles' old
+// momentum in place, trans == 2 marks them, and this kernel draws the same normals (same key, tick, particle id)
+// for the listed particles packed densely.  Same code on the same inputs: same bits.
+// ------------------------------------------------------------------------------------------
+template <typename T, int E>
+__global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T> a) {
+  if (a.ctl->failed) return;
+  const int n = *a.count;
+  if ((((int64_t)blockIdx.x * 256) >> a.logG) >= n) return;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int G = 1 << a.logG;
+  const int64_t idx = tid >> a.logG;
+  const bool live = idx < n;
+  const int64_t p = a.list[live ? idx : 0];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  LaneMap m;
+  m.j = (int)(tid & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = lane & ~(G - 1);
+  m.wpp = false;
+  using Vec = typename VecOf<T>::type;
+  constexpr int C = E / VecOf<T>::n;
+  __shared__ Vec stash[4][C][64];
+  T v[E];
+  load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
+  stash_put<T, E>(stash[wib], lane, v);
+  refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key, (uint32_t)(a.first_pid + p), m, a.r_keep, a.r_mix);
+  stash_get<T, E>(stash[wib], lane, v);
+  const T ev = kinetic<T, E>(v, m);
+  if (live) {
+    store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+    if (m.j == 0) a.EV_out[p] = ev;
+  }
+}
+
+template <typename T>
+inline void launch_refresh(const RefreshArgs<T>& a, int E, int64_t n_max, hipStream_t st) {
+  const int64_t threads = n_max << a.logG;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  constexpr int VEC = VecOf<T>::n;
+  if (E == VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, VEC>), grid, block, 0, st, a);
+  else if (E == 4 * VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 4 * VEC>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 8 * VEC>), grid, block, 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------
