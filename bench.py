@@ -228,7 +228,7 @@ def main():
         abytes = algorithmic_bytes_per_particle(w['D'], esize) * w['N']           # per sampling iteration
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         # elementwise energies: one launch covers up to 64 fused iterations (state stays on chip in between)
-        fused = w['kind'] not in ('pot', 'sic') and args.steps >= 2 and not os.environ.get('MJHMC_NO_FUSE')
+        fused = w['kind'] in ('iso', 'diag') and args.steps >= 2 and not os.environ.get('MJHMC_NO_FUSE')
         n_launch = -(-args.steps // 64) if fused else args.steps
         it_per_launch = args.steps / float(n_launch)
         traffic = None
@@ -261,7 +261,9 @@ def main():
             valu_peak = 78.6 if w['dtype'] == 'float64' else 157.3
             roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                    'kernel': 'mjhmc_jump_kernel', 'avg_launch_ms': kern_ms * it_per_launch,
+                    'kernel': 'mjhmc_jump_kernel' if fused or w['N'] < 16384 or w['D'] * esize >= 2048 else
+                              'mjhmc_jump_kernel + the compacted passes of one iteration (cold list, inverse-L, R list, refresh)',
+                    'avg_launch_ms': kern_ms * it_per_launch,
                     'launches_timed': n_launch, 'iterations_per_launch': it_per_launch,
                     'algorithmic_bytes_per_launch': abytes * it_per_launch,
                     'note': ('fused launch: the state crosses HBM once per launch, not once per iteration, so the '
