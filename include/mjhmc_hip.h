@@ -190,6 +190,14 @@ int mjhmc_ring_read(mjhmc_sampler* s, int slot0, int n, int stacked, double* hos
  * (mjhmc/misc/gen_mj_init.py:76-98), which walks sampler.sample(1).ravel() value by value. */
 int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double* sum, double* sumsq);
 
+/* The leapfrog operator on caller-supplied states: HMCState.leapfrog (n_steps = 1) and HMCState.L
+ * (n_steps = num_leapfrog_steps) of mjhmc/samplers/hmc_state.py:86-100, in the reference's literal operation order
+ * (half kicks not merged, every product rounded before its sum).  X, V and the outputs are (ndims, n) float64 C order
+ * (EX_out / EV_out: n values); EX_out, EV_out, dEdX_out may be NULL.  X_out / V_out may alias X / V.
+ * Elementwise energies only (PRODUCT_OF_T / SPARSE_CODE integrate inside their tile kernels): MJHMC_ERR_UNSUPPORTED. */
+int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V, int64_t n, double eps, int n_steps,
+                   double* X_out, double* V_out, double* EX_out, double* EV_out, double* dEdX_out);
+
 /* Autocorrelation along the time axis of ring slots [slot0, slot0 + n):
  *   out[k] = sum_{d < ndims, particle < N} sum_t x_t * x_{t+k},   k = 0 .. n-1   (n float64 to the host)
  * linear == 0: t + k wraps modulo n.  out / out[0] is fft_autocor(samples) of mjhmc/misc/autocor.py:37-49

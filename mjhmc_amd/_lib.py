@@ -62,6 +62,7 @@ PROTOTYPES = {
     'mjhmc_ring_gather': (ctypes.c_int, [_P, _P, ctypes.c_int64, _P]),
     'mjhmc_ring_read': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     'mjhmc_ring_moments': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_double, _dp, _dp]),
+    'mjhmc_leapfrog': (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int64, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P]),
     'mjhmc_ring_autocor': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     'mjhmc_autocor': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P]),
     'mjhmc_last_timing': (ctypes.c_int, [_P, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),

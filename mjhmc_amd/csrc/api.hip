@@ -353,6 +353,35 @@ int dispatch_jump<float>(int kind, const JumpArgs<float>& a, const EnergyParams&
 }
 
 template <typename T>
+static int dispatch_leap(int kind, const LeapArgs<T>& a, const EnergyParams& ep, int E, hipStream_t st);
+template <>
+int dispatch_leap<double>(int kind, const LeapArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_leap_f64(a, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_leap_f64(a, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_leap_f64(a, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_leap_f64(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_leap_f64(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_leap_f64(a, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "the stand-alone leapfrog operator exists for the elementwise energies");
+  }
+  return 0;
+}
+template <>
+int dispatch_leap<float>(int kind, const LeapArgs<float>& a, const EnergyParams& ep, int E, hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_leap_f32(a, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_leap_f32(a, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_leap_f32(a, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_leap_f32(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_leap_f32(a, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_leap_f32(a, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "the stand-alone leapfrog operator exists for the elementwise energies");
+  }
+  return 0;
+}
+
+template <typename T>
 static int dispatch_flf(int kind, const FlfArgs<T>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st);
 template <>
 int dispatch_flf<double>(int kind, const FlfArgs<double>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) {
@@ -1349,6 +1378,30 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   return 0;
 }
 
+template <typename T>
+static int leap_t(mjhmc_sampler& w, void* Xd, void* Vd, void* Xo, void* Vo, void* Gd, void* EXd, void* EVd, double eps,
+                  int L) {
+  LeapArgs<T> a;
+  a.X = (const T*)Xd;
+  a.V = (const T*)Vd;
+  a.X_out = (T*)Xo;
+  a.V_out = (T*)Vo;
+  a.G = (T*)Gd;
+  a.EX = (T*)EXd;
+  a.EV = (T*)EVd;
+  a.N = w.N;
+  a.D = w.D;
+  a.pitch = w.sh.pitch;
+  a.CH = w.sh.CH;
+  a.logG = w.sh.logG;
+  a.L = L;
+  a.eps = (T)eps;
+  a.chalf = (T)(-eps / 2.);
+  TRY(dispatch_leap<T>(w.en->ep.kind, a, w.en->ep, w.sh.E, w.stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
 int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
@@ -1662,6 +1715,54 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   if (Xd) (void)hipFree(Xd);
   if (Gd) (void)hipFree(Gd);
   if (Ed) (void)hipFree(Ed);
+  if (w.stage) (void)hipFree(w.stage);
+  if (w.stream) (void)hipStreamDestroy(w.stream);
+  return rc;
+}
+
+int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V, int64_t n, double eps, int n_steps,
+                   double* X_out, double* V_out, double* EX_out, double* EV_out, double* dEdX_out) {
+  if (!e || !X || !V || !X_out || !V_out || n < 1 || n_steps < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
+  if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
+  if (e->is_dense())
+    return fail(MJHMC_ERR_UNSUPPORTED, "the stand-alone leapfrog operator exists for the elementwise energies");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  mjhmc_sampler w;
+  w.ctx = e->ctx;
+  w.en = e;
+  w.N = n;
+  w.Npad = (n + 63) / 64 * 64;
+  w.first_pid = 0;
+  w.D = e->ep.ndims;
+  w.dtype = dtype;
+  TRY(pick_shape(w.D, dtype, &w.sh));
+  void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // X, V, X', V', G, EX, EV
+  auto body = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    const size_t mb = mat_bytes(&w), vb = (size_t)w.Npad * ssize(&w);
+    for (int i = 0; i < 5; ++i) {
+      if (i == 4 && !dEdX_out) continue;
+      HIPCHK(hipMalloc(&buf[i], mb));
+      HIPCHK(hipMemsetAsync(buf[i], 0, mb, w.stream));
+    }
+    if (EX_out) HIPCHK(hipMalloc(&buf[5], vb));
+    if (EV_out) HIPCHK(hipMalloc(&buf[6], vb));
+    TRY(upload_matrix(&w, X, buf[0]));
+    TRY(upload_matrix(&w, V, buf[1]));
+    if (dtype == MJHMC_F64) TRY(leap_t<double>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
+    else TRY(leap_t<float>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
+    const size_t total = (size_t)w.D * n;
+    TRY(download_cols(&w, buf[2], nullptr, n, X_out, total, n, 1, 0, true));
+    TRY(download_cols(&w, buf[3], nullptr, n, V_out, total, n, 1, 0, true));
+    if (dEdX_out) TRY(download_cols(&w, buf[4], nullptr, n, dEdX_out, total, n, 1, 0, true));
+    if (EX_out) TRY(read_vec(&w, buf[5], EX_out, (size_t)n * sizeof(double)));
+    if (EV_out) TRY(read_vec(&w, buf[6], EV_out, (size_t)n * sizeof(double)));
+    HIPCHK(hipStreamSynchronize(w.stream));
+    return 0;
+  };
+  const int rc = body();
+  for (void* b : buf)
+    if (b) (void)hipFree(b);
   if (w.stage) (void)hipFree(w.stage);
   if (w.stream) (void)hipStreamDestroy(w.stream);
   return rc;

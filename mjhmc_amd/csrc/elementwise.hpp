@@ -464,6 +464,22 @@ struct FlfArgs {
   T eps, chalf;
 };
 
+// stand-alone leapfrog operator (see mjhmc_leap_kernel)
+template <typename T>
+struct LeapArgs {
+  const T* X;      // [n][pitch]
+  const T* V;
+  T* X_out;        // [n][pitch]
+  T* V_out;
+  T* G;            // dE/dX at the end point, or nullptr
+  T* EX;           // [n] or nullptr
+  T* EV;
+  int64_t N;
+  int D, pitch, CH, logG;
+  int L;
+  T eps, chalf;
+};
+
 // momentum refresh of the compacted R-movers (see mjhmc_refresh_kernel)
 template <typename T>
 struct RefreshArgs {
@@ -1444,6 +1460,59 @@ inline void launch_refresh(const RefreshArgs<T>& a, int E, int64_t n_max, hipStr
 }
 
 // ------------------------------------------------------------------------------------------
+// HMCState.leapfrog / HMCState.L as an operator on caller-supplied states (hmc_state.py:86-100): the reference's
+// literal operation order (the EXACT trajectory), then EV, EX and dE/dX of the end point.
+// ------------------------------------------------------------------------------------------
+template <class En, typename T, int E>
+__global__ __launch_bounds__(256) void mjhmc_leap_kernel(const LeapArgs<T> a, const En en) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int G = 1 << a.logG;
+  const int64_t p_raw = tid >> a.logG;
+  const bool alive = p_raw < a.N;
+  const int64_t p = alive ? p_raw : a.N - 1;
+  LaneMap m;
+  m.j = (int)(tid & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
+  m.wpp = false;
+  T x[E], v[E];
+  load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
+  load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
+  const auto lc = en.template local<E>(m);
+  trajectory<En, T, E, true>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+  if (alive) {
+    store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
+    store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+  }
+  if (a.G) {
+    T g[E];
+    const auto ctx = en.prep(x, m);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int d = dim_of<T, E>(m, e);
+      g[e] = (d < a.D) ? en.template grad<E>(x[e], e, d, ctx, lc) : T(0);
+    }
+    if (alive) store_row<T, E>(a.G + (size_t)p * a.pitch, m, g);
+  }
+  if (a.EX) {
+    const T ex = en.energy(x, m, lc);
+    if (alive && m.j == 0) a.EX[p] = ex;
+  }
+  if (a.EV) {
+    const T ev = kinetic<T, E>(v, m);
+    if (alive && m.j == 0) a.EV[p] = ev;
+  }
+}
+
+template <class En, typename T, int E>
+inline void launch_leap_t(const LeapArgs<T>& a, const En& en, hipStream_t st) {
+  const int64_t threads = a.N << a.logG;
+  hipLaunchKernelGGL((mjhmc_leap_kernel<En, T, E>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, en);
+}
+
+// ------------------------------------------------------------------------------------------
 // evaluation kernel: E(X), dEdX(X), optionally kinetic energy / generated initial momentum
 // (HMCState.__init__, hmc_state.py:24-39; Distribution.E/dEdX, distributions.py:62-81)
 // ------------------------------------------------------------------------------------------
@@ -1592,6 +1661,18 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
     else if (E == 16) launch_jump_t<decltype(en), float, 16>(a, en, st);                                  \
     else launch_jump_t<decltype(en), float, 32>(a, en, st);                                               \
   }                                                                                                       \
+  void NAME##_leap_f64(const LeapArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {        \
+    const auto en = MAKE64(ep);                                                                           \
+    if (E == 2) launch_leap_t<decltype(en), double, 2>(a, en, st);                                        \
+    else if (E == 8) launch_leap_t<decltype(en), double, 8>(a, en, st);                                   \
+    else launch_leap_t<decltype(en), double, 16>(a, en, st);                                              \
+  }                                                                                                       \
+  void NAME##_leap_f32(const LeapArgs<float>& a, const EnergyParams& ep, int E, hipStream_t st) {         \
+    const auto en = MAKE32(ep);                                                                           \
+    if (E == 4) launch_leap_t<decltype(en), float, 4>(a, en, st);                                         \
+    else if (E == 16) launch_leap_t<decltype(en), float, 16>(a, en, st);                                  \
+    else launch_leap_t<decltype(en), float, 32>(a, en, st);                                               \
+  }                                                                                                       \
   void NAME##_flf_f64(const FlfArgs<double>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) { \
     const auto en = MAKE64(ep);                                                                           \
     if (E == 2) launch_flf_t<decltype(en), double, 2>(a, en, n, st);                                      \
@@ -1620,6 +1701,8 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
 #define MJHMC_DECLARE_ENERGY_LAUNCHERS(NAME)                                                       \
   void NAME##_jump_f64(const JumpArgs<double>&, const EnergyParams&, int, hipStream_t);           \
   void NAME##_jump_f32(const JumpArgs<float>&, const EnergyParams&, int, hipStream_t);            \
+  void NAME##_leap_f64(const LeapArgs<double>&, const EnergyParams&, int, hipStream_t);           \
+  void NAME##_leap_f32(const LeapArgs<float>&, const EnergyParams&, int, hipStream_t);            \
   void NAME##_flf_f64(const FlfArgs<double>&, const EnergyParams&, int, int64_t, hipStream_t);    \
   void NAME##_flf_f32(const FlfArgs<float>&, const EnergyParams&, int, int64_t, hipStream_t);     \
   void NAME##_eval_f64(const EvalArgs<double>&, const EnergyParams&, int, hipStream_t);           \

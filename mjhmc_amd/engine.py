@@ -80,6 +80,22 @@ class DeviceEnergy(object):
             check(self.ctx.lib.mjhmc_eval(self.handle, dtype_code(dtype), ptr(X), n, ptr(E), ptr(G)))
         return E, G
 
+    def leapfrog(self, X, V, epsilon, n_steps, want_grad=True, dtype='float64'):
+        """n_steps leapfrog steps from (X, V) in the reference's operation order (hmc_state.py:86-100).
+        Returns (X', V', EX' (n,), EV' (n,), dEdX' or None)."""
+        X = as_f64(X)
+        V = as_f64(V, X.shape)
+        if X.ndim != 2 or X.shape[0] != self.ndims:
+            raise ValueError('X must be (ndims, n)')
+        n = X.shape[1]
+        Xo, Vo = np.empty_like(X), np.empty_like(X)
+        EX, EV = np.empty(n), np.empty(n)
+        G = np.empty_like(X) if want_grad else None
+        if n:
+            check(self.ctx.lib.mjhmc_leapfrog(self.handle, dtype_code(dtype), ptr(X), ptr(V), n, float(epsilon), int(n_steps),
+                                              ptr(Xo), ptr(Vo), ptr(EX), ptr(EV), ptr(G)))
+        return Xo, Vo, EX, EV, G
+
     def __del__(self):
         try:
             if getattr(self, 'handle', None):

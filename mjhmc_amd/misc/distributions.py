@@ -77,6 +77,45 @@ class Distribution(object):
     def gen_init_X(self):
         raise NotImplementedError()
 
+    # -- fair-initialisation cache (distributions.py:104-149, 182-195) ----------------------------
+    @staticmethod
+    def _cache_directory(directory=None):
+        import os
+        return directory or os.environ.get('MJHMC_INIT_CACHE') or os.path.join(
+            os.path.expanduser('~'), '.cache', 'mjhmc_amd', 'initializations')
+
+    def cached_init_X(self, directory=None, **generator_kwargs):
+        """Set ``Xinit`` from the cached burn-in end points of this distribution (MJHMC end points when the
+        distribution serves a continuous-time sampler, ControlHMC's otherwise), generating and caching them first
+        when the cache file does not exist -- the reference's ``init_X`` (distributions.py:96-149).  Unlike the
+        reference this is opt-in: ``init_X`` here never starts a 10^6-step burn-in behind the caller's back.
+        ``generator_kwargs`` (burn_in_steps, var_steps, seed) go to gen_mj_init.generate_initialization."""
+        import os
+        from . import gen_mj_init as G
+        directory = self._cache_directory(directory)
+        name = '{}_{}.pickle'.format(type(self).__name__, G.stable_digest(self))
+        if not os.path.exists(os.path.join(directory, name)):
+            old_nbatch, old_mjhmc = self.nbatch, self.mjhmc
+            self.nbatch = self.max_n_particles or G.MAX_N_PARTICLES
+            self.generation_instance = True
+            try:
+                self.gen_init_X()                                     # start from the biased initialisation
+            except NotImplementedError:
+                self.Xinit = np.random.randn(self.ndims, self.nbatch)    # "completely arbitrary choice" (:137-139)
+            try:
+                G.cache_initialization(self, directory, **generator_kwargs)
+            finally:
+                self.nbatch, self.mjhmc = old_nbatch, old_mjhmc
+                self.generation_instance = False
+        mjhmc_endpt, _, _, control_endpt = G.load_initialization(self, directory)
+        self.Xinit = (mjhmc_endpt if self.mjhmc else control_endpt)[:, :self.nbatch]
+
+    def load_cache(self, directory=None):
+        """(mjhmc_endpt, emc_var_estimate, true_var_estimate, control_endpt) of this distribution's cache file;
+        raises if it does not exist (distributions.py:182-195)."""
+        from . import gen_mj_init as G
+        return G.load_initialization(self, self._cache_directory(directory))
+
     def reset(self):
         self.E_count = 0
         self.dEdX_count = 0

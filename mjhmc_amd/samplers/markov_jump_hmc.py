@@ -104,6 +104,13 @@ class HMCBase(object):
     def dEdX(self, X):
         return self.grad_func(X)
 
+    def leap_prob(self, Z1, Z2):
+        """Metropolis-Hastings probability of transitioning from state Z1 to state Z2 (markov_jump_hmc.py:106-114)."""
+        Ediff = Z1.H() - Z2.H()
+        p_acc = np.ones((1, Ediff.shape[1]))
+        p_acc[Ediff < 0] = np.exp(Ediff[Ediff < 0])
+        return p_acc
+
     def burn_in(self):
         self._run(self.n_burn_in)
         self._publish()

@@ -1,0 +1,122 @@
+"""GPU: the reference's state operators on a host snapshot (HMCState.L / leapfrog / F / FLF / R / update /
+cache bookkeeping, hmc_state.py:46-148) and HMCBase.leap_prob (markov_jump_hmc.py:106-114), against the golden
+trajectories captured from the reference (G3) and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import mjhmc_oracle as orc
+from tests.helpers import load, bits_equal
+from tests.test_gpu_parity import close, product_distribution
+
+pytestmark = pytest.mark.gpu
+
+
+def _sampler(tag, kind, g):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    X0, V0 = g[tag + '_X0'], g[tag + '_V0']
+    eps, L = float(g[tag + '_hp'][0]), int(g[tag + '_hp'][1])
+    fake = dict(kind=kind, par_sigma=1.3, par_scale1=100, par_scale2=4,
+                par_conditioning=10 ** np.linspace(-2, 0, X0.shape[0]))
+    return MarkovJumpHMC(distribution=product_distribution(fake, X0), epsilon=eps, beta=0.3, num_leapfrog_steps=L,
+                         Vinit=V0, seed=3)
+
+
+@pytest.mark.parametrize('tag,kind', [('iso_2x100', 'iso'), ('iso_512x32', 'iso'), ('diag_16x24', 'diag'),
+                                      ('rough_4x16', 'rough')])
+def test_L_and_FLF_against_the_reference_trajectories(tag, kind):
+    g = load('g3_trajectories')
+    s = _sampler(tag, kind, g)
+    d = s.distribution
+    n = g[tag + '_X0'].shape[1]
+    e0, g0 = d.E_count, d.dEdX_count
+    Z = s.state.copy().L()
+    assert (d.E_count - e0, d.dEdX_count - g0) == (n, n * s.num_leapfrog_steps)
+    assert close(Z.X, g[tag + '_L_X']) and close(Z.V, g[tag + '_L_V']) and close(Z.dEdX, g[tag + '_L_g'])
+    assert close(Z.EX[0], g[tag + '_L_EX']) and close(Z.EV[0], g[tag + '_L_EV'])
+    if kind == 'diag':                       # exact products: the literal operation order reproduces NumPy's bits
+        assert bits_equal(Z.X, g[tag + '_L_X']) and bits_equal(Z.V, g[tag + '_L_V'])
+    W = s.state.copy().FLF()
+    assert close(W.X, g[tag + '_FLF_X']) and close(W.V, g[tag + '_FLF_V']) and close(W.dEdX, g[tag + '_FLF_g'])
+    assert close(W.EX[0], g[tag + '_FLF_EX']) and close(W.EV[0], g[tag + '_FLF_EV'])
+    # L then F then L then F is the identity up to rounding (time reversibility of the integrator)
+    back = s.state.copy().L().F().L().F()
+    assert np.allclose(back.X, g[tag + '_X0'], rtol=1e-9, atol=1e-9 * np.abs(g[tag + '_X0']).max()) or kind == 'rough'
+
+
+def test_single_steps_compose_to_L_and_bookkeeping_operators():
+    g = load('g3_trajectories')
+    s = _sampler('diag_16x24', 'diag', g)
+    Z = s.state.copy()
+    for _ in range(s.num_leapfrog_steps):
+        Z.leapfrog()
+    assert bits_equal(Z.X, g['diag_16x24_L_X']) and bits_equal(Z.V, g['diag_16x24_L_V'])
+    assert bits_equal(Z.EX, s.state.EX)                       # leapfrog() leaves the energies alone, like the reference
+    Z.update_EV()
+    Z.update_EX()
+    assert close(Z.EX[0], g['diag_16x24_L_EX']) and close(Z.EV[0], g['diag_16x24_L_EV'])
+    # operators act on active_idx only
+    A = s.state.copy()
+    A.active_idx = np.array([1, 5, 7])
+    A.L()
+    rest = np.setdiff1d(np.arange(A.nbatch), [1, 5, 7])
+    assert bits_equal(A.X[:, rest], g['diag_16x24_X0'][:, rest])
+    assert bits_equal(A.X[:, [1, 5, 7]], g['diag_16x24_L_X'][:, [1, 5, 7]])
+    # F, update, cache bookkeeping
+    B = s.state.copy()
+    assert bits_equal(B.copy().F().V, -B.V)
+    B.update(np.array([0, 2]), Z)
+    assert bits_equal(B.X[:, [0, 2]], Z.X[:, [0, 2]]) and bits_equal(B.X[:, 1], g['diag_16x24_X0'][:, 1])
+    B.cache_flf_state(np.array([3]), Z)
+    assert B.cache_active[3] and not B.cache_active[4]
+    B.clear_flf_cache(np.array([3]))
+    assert not B.cache_active.any()
+    # R: the reference's expression on the process-global NumPy stream
+    C = s.state.copy()
+    np.random.seed(12)
+    C.R()
+    np.random.seed(12)
+    want = s.state.V * np.sqrt(1. - s.beta) + np.random.randn(*C.V.shape) * np.sqrt(s.beta)
+    assert bits_equal(C.V, want) and close(C.EV[0], np.sum(want ** 2, axis=0) / 2.)
+
+
+def test_leap_prob_and_transition_rates():
+    g = load('g3_trajectories')
+    s = _sampler('iso_2x100', 'iso', g)
+    Z1 = s.state.copy()
+    Z2 = s.state.copy().L().F()
+    Ediff = Z1.H() - Z2.H()
+    p = s.leap_prob(Z1, Z2)
+    assert p.shape == (1, 100) and np.all(p[Ediff >= 0] == 1) and np.allclose(p[Ediff < 0], np.exp(Ediff[Ediff < 0]))
+    assert np.allclose(s.transition_rates(Z1, Z2), np.exp(Ediff) ** .5)
+
+
+def test_dense_energies_say_so():
+    from mjhmc_amd._lib import EngineError
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import ProductOfT
+    X0 = np.random.RandomState(0).randn(36, 40)
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0
+    s = MarkovJumpHMC(distribution=Fixed(ndims=36, nbasis=36, nbatch=40), epsilon=0.1, seed=1, resample=False)
+    with pytest.raises(EngineError):
+        s.state.copy().L()
+
+
+def test_cached_init_X_and_load_cache(tmp_path):
+    """Distribution.cached_init_X / load_cache (distributions.py:104-149, 182-195): generate once (toy step counts),
+    then serve the MJHMC end points to continuous-time samplers and ControlHMC's to the others."""
+    from mjhmc_amd.misc.distributions import Gaussian
+    d = Gaussian(ndims=4, nbatch=30, log_conditioning=1)
+    d.max_n_particles = 64
+    with pytest.raises(IOError):
+        d.load_cache(str(tmp_path))
+    d.mjhmc = True
+    d.cached_init_X(str(tmp_path), burn_in_steps=300, var_steps=100, seed=5)
+    mj, emc_var, true_var, ctl = d.load_cache(str(tmp_path))
+    assert mj.shape == (4, 64) and ctl.shape == (4, 64) and emc_var > 0 and true_var > 0
+    assert d.nbatch == 30 and not d.generation_instance and np.array_equal(d.Xinit, mj[:, :30])
+    d.mjhmc = False
+    d.cached_init_X(str(tmp_path))                      # second call only reads the file
+    assert np.array_equal(d.Xinit, ctl[:, :30])
