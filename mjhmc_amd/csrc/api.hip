@@ -155,7 +155,10 @@ static int pick_shape(int D, int dtype, Shape* out) {
     G = 1;
   } else {
     C = 4;
-    if (const char* force = std::getenv("MJHMC_CHUNKS_PER_LANE")) C = std::atoi(force) == 8 ? 8 : 4;  // perf experiments
+    if (const char* force = std::getenv("MJHMC_CHUNKS_PER_LANE")) {  // perf experiments
+      const int f = std::atoi(force);
+      C = f == 8 ? 8 : (f == 1 ? 1 : 4);
+    }
     G = pow2ceil((s.CH + C - 1) / C);
     if (G > 64) {
       C = 8;
