@@ -1118,8 +1118,10 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
 template <typename T>
 static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                      const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
-  // fused launches exist for the energies whose single iteration is HBM-bound (En::kFuse in elementwise.hpp)
-  const bool fusable = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
+  // Fused launches: always for the Gaussian forces (one iteration is HBM-bound), for the other elementwise energies
+  // while the batch is small (launch-/latency-bound) -- big batches of those take the compacted passes below instead.
+  const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
+  const bool fusable = !s->en->is_dense() && (gaussian || s->N < 16384 || s->D <= 4);
   if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !std::getenv("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);

@@ -167,8 +167,10 @@ struct NoLocal {};
 // TestGaussian: E = sum(x^2) / (2 sigma^2), dE/dx = x / sigma^2 (distributions.py:356-362)
 template <typename T>
 struct IsoGaussF {
-  // fused launches (several iterations per launch) pay off when one iteration is HBM-bound: measured 1.03-2.7x
-  // for the Gaussian forces at every row size, 0.93-0.99x for the funnel (exp + reductions: vector-pipe-bound)
+  // fused launches (several iterations per launch) exist for this energy; WHEN they are used is the host's decision
+  // (api.hip, iterate_t): always for the Gaussian forces, whose single iteration is HBM-bound (measured 1.03-2.7x at
+  // every row size), and for the vector-pipe-bound ones only while the batch is small (launch- and latency-bound:
+  // funnel 18.7 -> 12.7 us per iteration at 1000 particles; 0.93-0.99x at 10^6, where the compacted passes win)
   static constexpr bool kFuse = true;
   // the force is one multiplication by a constant: the half-kick factor is folded into it,
   // c * (x * inv_s2) -> x * (c * inv_s2)  (identical bits when sigma is a power of two, e.g. the benchmark's 1)
@@ -240,7 +242,7 @@ struct DiagGaussF {
 template <typename T>
 struct RoughWellF {
   static constexpr bool kLinearIso = false;
-  static constexpr bool kFuse = false;
+  static constexpr bool kFuse = true;
   T s1sq;       // scale1^2
   T two_s1sq;   // 2 scale1^2
   T s2;
@@ -278,7 +280,7 @@ struct RoughWellF {
 template <typename T>
 struct MMGaussF {
   static constexpr bool kLinearIso = false;
-  static constexpr bool kFuse = false;
+  static constexpr bool kFuse = true;
   T sep0;  // 2 * separation
   struct Ctx {
     T common;  // exp(sum 4 S X) = exp(4 sep0 x_0)
@@ -319,7 +321,7 @@ struct MMGaussF {
 template <typename T>
 struct FunnelNealF {
   static constexpr bool kLinearIso = false;
-  static constexpr bool kFuse = false;
+  static constexpr bool kFuse = true;
   T inv_s2;      // 1/scale^2
   T half_dm1;    // (D-1)/2
   struct Ctx {
@@ -357,7 +359,7 @@ struct FunnelNealF {
 template <typename T>
 struct FunnelRefF {
   static constexpr bool kLinearIso = false;
-  static constexpr bool kFuse = false;
+  static constexpr bool kFuse = true;
   T inv_s2;
   T dm1;  // D-1
   struct Ctx {
