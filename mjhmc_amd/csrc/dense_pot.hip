@@ -169,6 +169,42 @@ __device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const PubW
   }
 }
 
+// ndims <= 128 (NB = 1): a wave's rows of BOTH pre-scaled matrices are 2 x 64 floats per lane -- they stay in
+// registers for the whole kernel (the workgroup's 4 x 64 lanes x 128 VGPRs hold W1 and W2T completely), so a
+// leapfrog step issues no global load at all.  This is the size of the reference's own ProductOfT experiments
+// (36 dims, <= 1000 particles): a handful of tiles, one per CU, where nothing else could hide the A-row latency.
+template <int NB>
+struct AReg {};
+template <>
+struct AReg<1> {
+  float w1[4][16];
+  float w2[4][16];
+};
+
+template <int NB>
+__device__ __forceinline__ void areg_load(const PotModel& mdl, int w, int c, int h, AReg<NB>& ar) {
+  if constexpr (NB == 1) {
+    const float* m1 = mdl.W1 + (size_t)(4 * h) * 128 + 32 * w + c;
+    const float* m2 = mdl.W2T + (size_t)(4 * h) * 128 + 32 * w + c;
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) {
+      a_chunk_load<1>(m1, chunk, ar.w1[chunk]);
+      a_chunk_load<1>(m2, chunk, ar.w2[chunk]);
+    }
+  }
+}
+
+template <int NB, bool SECOND>
+__device__ __forceinline__ void gemm_any(const PotModel& mdl, const AReg<NB>& ar, const PubWave<NB>* pub, int w, int c,
+                                         int h, int lane, Tile<NB>& acc) {
+  if constexpr (NB == 1) {
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) chunk_mfma<1>(pub, chunk, lane, SECOND ? ar.w2[chunk] : ar.w1[chunk], acc);
+  } else {
+    gemm_dim<NB>(SECOND ? mdl.W2T : mdl.W1, pub, w, c, h, lane, acc);
+  }
+}
+
 // per-row constant vector in accumulator layout
 template <int NB>
 __device__ __forceinline__ void rowvec_load(const float* vec, int w, int h, Tile<NB>& t) {
@@ -199,13 +235,14 @@ struct Shared {
 // a wave can only reach the next publish of a buffer after every wave has passed the barrier that
 // follows its last read of it).
 template <int NB>
-__device__ __forceinline__ void pot_gradient(const PotModel& mdl, Shared<NB>& sh, int w, int c, int h, int lane,
-                                             const Tile<NB>& x, Tile<NB>& g, bool want_energy, float* energy_out) {
+__device__ __forceinline__ void pot_gradient(const PotModel& mdl, const AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
+                                             int lane, const Tile<NB>& x, Tile<NB>& g, bool want_energy,
+                                             float* energy_out) {
   publish<NB>(sh.pub[0][w], lane, x);
   __syncthreads();
   Tile<NB> u;
   rowvec_load<NB>(mdl.cb, w, h, u);                    // u starts at b_j / nu_j
-  gemm_dim<NB>(mdl.W1, sh.pub[0], w, c, h, lane, u);   // + sum_d W[d][j]/nu_j * x_d
+  gemm_any<NB, false>(mdl, ar, sh.pub[0], w, c, h, lane, u);   // + sum_d W[d][j]/nu_j * x_d
   if (want_energy) {                                   // E = sum_j alpha_j log(1 + u_j^2)  (distributions.py:430-432)
     using V = typename VecN<NB>::type;
     const float* al = mdl.alpha + 32 * NB * w;
@@ -232,7 +269,7 @@ __device__ __forceinline__ void pot_gradient(const PotModel& mdl, Shared<NB>& sh
   for (int r = 0; r < NB; ++r)
 #pragma unroll
     for (int q = 0; q < 16; ++q) g.b[r][q] = 0.f;
-  gemm_dim<NB>(mdl.W2T, sh.pub[1], w, c, h, lane, g);
+  gemm_any<NB, true>(mdl, ar, sh.pub[1], w, c, h, lane, g);
   if (want_energy && energy_out) {
     *energy_out = sh.red[0][0][c] + sh.red[0][1][c] + sh.red[0][2][c] + sh.red[0][3][c];
   }
@@ -257,9 +294,9 @@ __device__ __forceinline__ float pot_kinetic(Shared<NB>& sh, int w, int c, int h
 // L leapfrog steps (hmc_state.py:86-100); g enters as dE/dX at x, leaves as dE/dX at the new x.
 // Returns E(x_new) through *ex (the last gradient evaluation already has u(x_new)).
 template <int NB>
-__device__ __forceinline__ void pot_trajectory(const PotModel& mdl, Shared<NB>& sh, int w, int c, int h, int lane,
-                                               Tile<NB>& x, Tile<NB>& v, Tile<NB>& g, int L, float eps, float chalf,
-                                               float* ex) {
+__device__ __forceinline__ void pot_trajectory(const PotModel& mdl, const AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
+                                               int lane, Tile<NB>& x, Tile<NB>& v, Tile<NB>& g, int L, float eps,
+                                               float chalf, float* ex) {
   for (int s = 0; s < L; ++s) {
 #pragma unroll
     for (int r = 0; r < NB; ++r)
@@ -268,7 +305,7 @@ __device__ __forceinline__ void pot_trajectory(const PotModel& mdl, Shared<NB>& 
         v.b[r][q] = v.b[r][q] + chalf * g.b[r][q];
         x.b[r][q] = x.b[r][q] + eps * v.b[r][q];
       }
-    pot_gradient<NB>(mdl, sh, w, c, h, lane, x, g, s == L - 1, ex);
+    pot_gradient<NB>(mdl, ar, sh, w, c, h, lane, x, g, s == L - 1, ex);
 #pragma unroll
     for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -301,12 +338,14 @@ template <int NB>
 __global__ __launch_bounds__(256, 1) void pot_eval_kernel(const PotEvalArgs a, const PotModel mdl) {
   __shared__ Shared<NB> sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  AReg<NB> ar;
+  areg_load<NB>(mdl, w, c, h, ar);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
     Tile<NB> x, g;
     tile_load<NB>(a.X, p, w, h, x);
     float ex = 0.f;
-    pot_gradient<NB>(mdl, sh, w, c, h, lane, x, g, true, &ex);
+    pot_gradient<NB>(mdl, ar, sh, w, c, h, lane, x, g, true, &ex);
     if (a.G) tile_store<NB>(a.G, p, w, h, g);
     if (a.E && w == 0 && h == 0) a.E[p] = ex;
     if (a.EV) {
@@ -356,6 +395,8 @@ __global__ __launch_bounds__(256, 1) void pot_flf_kernel(const PotJumpArgs a, co
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
+  AReg<NB> ar;
+  areg_load<NB>(mdl, w, c, h, ar);
   for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
     const int slot = tile * kP + c;
     const int64_t p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
@@ -366,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void pot_flf_kernel(const PotJumpArgs a, co
 #pragma unroll
     for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
     float ex = 0.f;
-    pot_trajectory<NB>(mdl, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &ex);
+    pot_trajectory<NB>(mdl, ar, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &ex);
     const float ev = pot_kinetic<NB>(sh, w, c, h, v);
     if (w == 0 && h == 0) a.Hwork[p] = ex + ev;
     __syncthreads();
@@ -383,6 +424,8 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   unsigned nL = 0, nF = 0, nR = 0;
   bool any_bad = false;
+  AReg<NB> ar;
+  areg_load<NB>(mdl, w, c, h, ar);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
     const bool alive = p < a.N;
@@ -395,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
     tile_load<NB>(a.V_in, p, w, h, v);
     tile_load<NB>(a.G_in, p, w, h, g);
     float EXL = 0.f;
-    pot_trajectory<NB>(mdl, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &EXL);
+    pot_trajectory<NB>(mdl, ar, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &EXL);
     const float EVL = pot_kinetic<NB>(sh, w, c, h, v);
     const float HL = EXL + EVL;
 
