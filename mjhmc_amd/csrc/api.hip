@@ -58,7 +58,7 @@ struct mjhmc_energy {
   void* dev32 = nullptr;
   float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
   int pot_dim = kPotDim;  // rows padded to 128, 256 or 512
-  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim}; }
+  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim, ep.ndims}; }
   bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
   void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32)
   float sic_lambda = 0.f;

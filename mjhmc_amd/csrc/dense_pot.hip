@@ -198,8 +198,23 @@ template <int NB, bool SECOND>
 __device__ __forceinline__ void gemm_any(const PotModel& mdl, const AReg<NB>& ar, const PubWave<NB>* pub, int w, int c,
                                          int h, int lane, Tile<NB>& acc) {
   if constexpr (NB == 1) {
+    // k-rows at or beyond ndims (== nbasis) are padding: X, phi(U) and the matrix rows are exactly zero there, so the
+    // row groups of eight that lie entirely in the padding are skipped (36 dims: 20 of 64 MFMAs per GEMM remain)
+    const int kdim = mdl.ndims;
 #pragma unroll
-    for (int chunk = 0; chunk < 4; ++chunk) chunk_mfma<1>(pub, chunk, lane, SECOND ? ar.w2[chunk] : ar.w1[chunk], acc);
+    for (int chunk = 0; chunk < 4; ++chunk) {
+      const float(&a)[16] = SECOND ? ar.w2[chunk] : ar.w1[chunk];
+      const f32x4(*blk)[64] = pub[chunk].v[0];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        if (32 * chunk + 8 * q4 < kdim) {
+          const f32x4 b4 = blk[q4][lane];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+            acc.b[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q4 + qq], b4[qq], acc.b[0], 0, 0, 0);
+        }
+      }
+    }
   } else {
     gemm_dim<NB>(SECOND ? mdl.W2T : mdl.W1, pub, w, c, h, lane, acc);
   }

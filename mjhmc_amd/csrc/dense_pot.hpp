@@ -16,6 +16,7 @@ struct PotModel {
   const float* cb;     // [j]    = b_j / nu_j
   const float* alpha;  // [j]    = (nu_j + 1) / 2   (0 for padded experts)
   int dim;             // padded dimension: 128, 256 or 512
+  int ndims;           // true ndims == nbasis (rows at or beyond it are zero padding)
 };
 
 struct PotJumpArgs {
