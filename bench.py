@@ -202,6 +202,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel), measured after the
+    # timed region so that the classical roofline fraction is in the line too
+    unfused_ms = None
+    if w['kind'] in ('iso', 'diag') and args.steps >= 2 and not os.environ.get('MJHMC_NO_FUSE'):
+        os.environ['MJHMC_NO_FUSE'] = '1'
+        try:
+            smp.iterate(32)
+            smp.iterate(32)
+            t_u = smp.last_timing()
+            unfused_ms = t_u['jump_kernel_ms'] / max(t_u['n_jump_launches'], 1)
+        finally:
+            del os.environ['MJHMC_NO_FUSE']
+
     gather_info = None
     if dist is not None:
         # the one collective of the path: all-gather of sample columns at the end of sample()
@@ -272,6 +285,11 @@ def main():
                     'valu': {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak,
                              'dtype': w['dtype'], 'what': 'trajectory + energy flops only (rates, draws, reductions '
                                                           'and bookkeeping are vector instructions too, not flops)'}}
+            if unfused_ms:
+                roof['one_iteration_per_launch'] = {
+                    'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9, 'unit': 'GB/s',
+                    'frac': abytes / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'what': 'the same kernel with the state crossing HBM every iteration (MJHMC_NO_FUSE=1): HBM-bound'}
         out = {
             'metric': 'particle-steps/sec (ndims x nparticles x L)',
             'value': units / elapsed,
