@@ -174,7 +174,7 @@ int run(hipStream_t st, const ChunkSource& src, int64_t n_series, int T, int lin
   }
   const FftApi* api = fft_api(err);
   if (!api) return MJHMC_ERR_UNSUPPORTED;
-  const int M = linear ? 2 * T : T;  // transform length
+  const int M = (linear || T == 1) ? 2 * T : T;  // transform length (a length-1 series is its own zero-padded case)
   const int nF = M / 2 + 1;
   const size_t per_series = (size_t)M * sizeof(double) + (size_t)nF * sizeof(double2);
   int64_t chunk = (int64_t)(staging_budget() / per_series) / 64 * 64;

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-10
 
 
-@pytest.mark.parametrize('D,N,T', [(3, 50, 37), (2, 100, 64), (1, 1, 5), (5, 33, 1000)])
+@pytest.mark.parametrize('D,N,T', [(3, 50, 37), (2, 100, 64), (1, 1, 5), (5, 33, 1000), (4, 9, 1)])
 def test_host_array_estimators_match_oracle(D, N, T):
     from mjhmc_amd.misc import autocor as ac
     rs = np.random.RandomState(D * 1000 + T)
