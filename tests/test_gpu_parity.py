@@ -684,8 +684,12 @@ def test_edge_shapes_match_oracle(D, N):
         assert s.state.H().shape == (1, N)
     assert (s.l_count, s.f_count, s.r_count) == (o.l_count, o.f_count, o.r_count)
     assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
-    out = s.sample(3, preserve_order=True)
-    assert out.shape == (D, N, 3)
+    out = s.sample(3, preserve_order=True)                  # one fused launch of three iterations
+    for t in range(3):
+        o.sampling_iteration()
+    assert out.shape == (D, N, 3) and close(out[:, :, 2], o.state.X)
+    assert np.array_equal(s._dev.read(8), o.last_transition)
+    assert (s.l_count, s.f_count, s.r_count) == (o.l_count, o.f_count, o.r_count)
 
 
 def test_unsupported_shapes_fail_loudly():
