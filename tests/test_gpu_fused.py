@@ -37,12 +37,16 @@ def _stats_tuple(st):
     ('E_ISO_GAUSS', 40, 129, 'MODE_MJHMC', 5),       # ragged rows (predicated chunks)
     ('E_ISO_GAUSS', 2, 100, 'MODE_MJHMC', 9),
     ('E_DIAG_GAUSS', 32, 300, 'MODE_MJHMC', 6),
-    ('E_FUNNEL_NEAL', 32, 300, 'MODE_MJHMC', 6),      # not fused (vector-pipe-bound): same contract
+    ('E_FUNNEL_NEAL', 32, 300, 'MODE_MJHMC', 6),      # fused while the batch is small
+    ('E_ROUGH_WELL', 4, 48, 'MODE_MJHMC', 8),
+    ('E_MM_GAUSS', 3, 40, 'MODE_MJHMC', 8),
+    ('E_ROUGH_WELL', 40, 200, 'MODE_CONTROL', 6),
     ('E_ISO_GAUSS', 16, 200, 'MODE_CONTROL', 12),
     ('E_ISO_GAUSS', 24, 77, 'MODE_CTHMC', 12),
 ])
 def test_fused_equals_single_iterations(kind, D, N, mode_name, n_iter):
-    params = {'E_FUNNEL_NEAL': [3.0], 'E_DIAG_GAUSS': list(10.0 ** np.linspace(-2, 0, D))}.get(kind, [1.3])
+    params = {'E_FUNNEL_NEAL': [3.0], 'E_FUNNEL_REF': [1.0], 'E_ROUGH_WELL': [100.0, 4.0], 'E_MM_GAUSS': [3.0],
+              'E_DIAG_GAUSS': list(10.0 ** np.linspace(-2, 0, D))}.get(kind, [1.3])
     from mjhmc_amd import _lib
     mode = getattr(_lib, mode_name)
     (a, b), _lib = _pair(kind, D, N, mode, params=params)
