@@ -66,7 +66,8 @@ struct LaneMap {
   int D;      // true ndims
   int CH;     // 16-byte chunks per particle row (pitch / VEC)
   int lane0;  // wave lane index of the group's lane 0
-  bool wpp;   // the whole wavefront is one particle (G == 64, known at compile time in the WPP kernels)
+  int wpp;    // lane mapping known at compile time: 1 = the wavefront is one particle (G == 64), 3 = a quad per particle
+              // (G == 4); 0 = G is a run-time value
 };
 
 template <typename T, int E>
@@ -133,7 +134,15 @@ __device__ __forceinline__ float readlane_v(float v, int r) {
 
 template <typename T>
 __device__ __forceinline__ T group_lane(T v, const LaneMap& m, int r) {
-  if (m.wpp) return readlane_v(v, r);  // v_readlane: no LDS-crossbar round trip
+  if (m.wpp == 1) return readlane_v(v, r);  // v_readlane: no LDS-crossbar round trip
+  if (m.wpp == 3) {                         // lane r of the quad: one DPP quad_perm broadcast
+    switch (r) {
+      case 0: return dpp_mov<0x00>(v);
+      case 1: return dpp_mov<0x55>(v);
+      case 2: return dpp_mov<0xAA>(v);
+      default: return dpp_mov<0xFF>(v);
+    }
+  }
   return __shfl(v, m.lane0 + r);
 }
 
@@ -920,7 +929,7 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
       const int row = (role == 0) ? 0 : (role == 1 ? 2 : 1);
       e = a.rexp[(size_t)row * a.N + p];
     } else {
-      if (m.wpp) {
+      if (m.wpp == 1) {
         // one particle per wave: the counter, key and slot are wave-uniform, so both Philox calls run
         // on the scalar unit (s_mul_i32 / s_mul_hi_u32) beside the vector work instead of in it
         const uint32_t spid = __builtin_amdgcn_readfirstlane(pid);
@@ -1044,22 +1053,24 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
 // body forces an in-order vmcnt wait that would also drain the prefetch of the next slot.
 // FULLROW = true: every lane's chunks are inside the row (pitch == G * E), no per-chunk predicates.
 // MODE: which sampler family's iteration this is (kModeMJHMC / kModeControl / kModeCT).
-// WPP = true: G == 64 (a whole wavefront per particle) is a compile-time fact: the reduction ladder, the
-// group exchanges (v_readlane) and the Philox calls (scalar unit) specialise on it.
+// WPP = 1: G == 64 (a whole wavefront per particle) is a compile-time fact: the reduction ladder, the group
+// exchanges (v_readlane) and the Philox calls (scalar unit) specialise on it.
+// WPP = 3: G == 4 (a quad per particle, e.g. ndims 17..32 in float64): two-level DPP reductions without the run-time
+// ladder, group exchanges as quad_perm broadcasts instead of ds_bpermute (C4 -3 %, isotropic 32 x 10^6 fused -8 %).
 // FUSED = true: the launch runs a.n_fuse (<= kMaxFuse) consecutive sampling iterations per particle.  The
 // chains are independent, so between iterations nothing has to leave the wave: X, V, EX, EV, H_flf stay in
 // registers / the LDS stash, HBM sees one read and one write of the state per LAUNCH instead of per
 // iteration (plus the ring snapshots when samples are recorded).  Iteration `it` uses RNG tick key.tick + it
 // and tallies into stats[4 * it ..]; the first iteration that meets a non-finite rate is reported through
 // Control::inv_iter and the host re-runs the launch up to that iteration (the input buffers are untouched).
-template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false, bool FUSED = false>
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, int WPP = 0, bool FUSED = false>
 __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   static_assert(!(FUSED && REPLAY), "recorded random numbers are replayed one iteration per launch");
   if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
-  const int logG = WPP ? 6 : a.logG;
+  const int logG = WPP == 1 ? 6 : (WPP == 3 ? 2 : a.logG);
   const int G = 1 << logG;
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block, scalar
@@ -1398,7 +1409,7 @@ __global__ __launch_bounds__(256) void mjhmc_flf_kernel(const FlfArgs<T> a, cons
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
-  m.wpp = false;
+  m.wpp = 0;
   T x[E], v[E];
   load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
   load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
@@ -1435,7 +1446,7 @@ __global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T>
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = lane & ~(G - 1);
-  m.wpp = false;
+  m.wpp = 0;
   using Vec = typename VecOf<T>::type;
   constexpr int C = E / VecOf<T>::n;
   __shared__ Vec stash[4][C][64];
@@ -1478,7 +1489,7 @@ __global__ __launch_bounds__(256) void mjhmc_leap_kernel(const LeapArgs<T> a, co
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
-  m.wpp = false;
+  m.wpp = 0;
   T x[E], v[E];
   load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
   load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
@@ -1532,7 +1543,7 @@ __global__ __launch_bounds__(256) void mjhmc_eval_kernel(const EvalArgs<T> a, co
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
-  m.wpp = false;
+  m.wpp = 0;
   T x[E];
   load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
   const auto lc = en.template local<E>(m);
@@ -1587,7 +1598,7 @@ struct EnergyParams {
 
 // Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
 // (occupancy query, cached per instantiation), never more than there are slots to hand out.
-template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, bool WPP = false, bool FUSED = false>
+template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, int WPP = 0, bool FUSED = false>
 inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   static int resident_blocks = 0;
   if (resident_blocks == 0) {
@@ -1612,19 +1623,21 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool replay = a.noise != nullptr;
   if constexpr (En::kFuse) if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
     if (a.mode == kModeMJHMC) {
-      if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, true, true>(a, en, st);
-      else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, false, true>(a, en, st);
-      else launch_jump_r<En, T, E, kModeMJHMC, false, false, false, true>(a, en, st);
+      if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1, true>(a, en, st);
+      else if (full && a.logG == 2 && !std::getenv("MJHMC_NO_QUAD")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3, true>(a, en, st);
+      else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, 0, true>(a, en, st);
+      else launch_jump_r<En, T, E, kModeMJHMC, false, false, 0, true>(a, en, st);
     } else if (a.mode == kModeCT) {
-      launch_jump_r<En, T, E, kModeCT, false, false, false, true>(a, en, st);
+      launch_jump_r<En, T, E, kModeCT, false, false, 0, true>(a, en, st);
     } else {
-      launch_jump_r<En, T, E, kModeControl, false, false, false, true>(a, en, st);
+      launch_jump_r<En, T, E, kModeControl, false, false, 0, true>(a, en, st);
     }
     return;
   }
   if (a.mode == kModeMJHMC) {
     if (replay) launch_jump_r<En, T, E, kModeMJHMC, true, false>(a, en, st);
-    else if (full && a.logG == 6 && !std::getenv("MJHMC_NO_WPP")) launch_jump_r<En, T, E, kModeMJHMC, false, true, true>(a, en, st);
+    else if (full && a.logG == 6 && !std::getenv("MJHMC_NO_WPP")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1>(a, en, st);
+    else if (full && a.logG == 2 && !std::getenv("MJHMC_NO_QUAD")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3>(a, en, st);
     else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true>(a, en, st);
     else launch_jump_r<En, T, E, kModeMJHMC, false, false>(a, en, st);
   } else if (a.mode == kModeCT) {
