@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""Headline benchmark: particle-steps/s (ndims x nparticles x L per sampling_iteration) of the
-MJHMC hot path on MI355X, with the HBM roofline of the jump kernel and the NumPy CPU baseline.
+"""Headline benchmark: particle-steps/s (ndims x nparticles x L per sampling_iteration) of the MJHMC hot path on
+MI355X, each workload with the roofline that bounds its kernel and the NumPy CPU baseline timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c1|all] [--scaling weak|strong]
 
-N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py ...
-(one rank per GPU).  Particle columns are independent chains, so each rank owns its own block of
-columns (global particle ids keep the RNG streams identical to an unsharded run); nothing is
-exchanged inside the timed region -> weak scaling, value = all ranks' particle-steps / max time.
+The ONE JSON line rank 0 prints has BASELINE.json configs[1] (C2) as its top-level workload and all GPU workloads
+(C2..C5 = configs[1..4]) under "workloads", each with ms_per_step, roofline and cpu_baseline.
 
-A "step" is one MarkovJumpHMC.sampling_iteration over all particles.
-Inputs are resident in HBM before the timed region starts.
+A "step" is one MarkovJumpHMC.sampling_iteration over all particles; --steps K is the batch one
+mjhmc_iterate call runs back to back with a single host sync.  The timed region is R such calls (R chosen so that it
+lasts >= 0.5 s: a 3 ms region measures the clock ramp, not the kernel), every call bracketed by barrier + stream sync
+on both sides, MAX over ranks; value = all ranks' particle-steps / the summed time, median and spread over the R
+calls reported next to it.  Inputs are resident in HBM before the timed region starts.
+
+N > 1 is launched as  python -m torch.distributed.run --nproc-per-node N bench.py ...  (one rank per GPU).  Particle
+columns are independent chains: each rank owns a block of columns (global particle ids keep the RNG streams those
+of an unsharded run), nothing is exchanged inside the timed region.  --scaling weak (default): every rank runs the
+full single-GPU workload; --scaling strong: the workload's particle count is the TOTAL, N/world per rank
+(BASELINE.json words C4 and C5 that way: "1 000 000 sharded across 8", "200 000 ... on 8xMI355X").
 """
 import argparse
 import json
@@ -24,26 +31,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth measured in the same guide (memory hierarchy, L2)
+MIN_TIMED_S = 0.5
 
 WORKLOADS = {
     # BASELINE.json configs[1]
-    'c2': dict(name='C2 isotropic Gaussian ndims=512 nparticles=100000/GPU L=10 fp64', kind='iso', D=512, N=100000,
+    'c2': dict(name='C2 isotropic Gaussian ndims=512 nparticles=100000 L=10 fp64', kind='iso', D=512, N=100000,
                L=10, eps=0.05, beta=0.1, dtype='float64', params=[1.0]),
-    # BASELINE.json configs[3] (per-GPU share of 1e6 particles at 8 GPUs is 125000; single GPU runs all 1e6)
-    'c4': dict(name='C4 Neal funnel ndims=32 nparticles=1000000/GPU L=15 fp64', kind='funnel', D=32, N=1000000,
-               L=15, eps=0.05, beta=0.1, dtype='float64', params=[3.0]),
     # BASELINE.json configs[2]: ProductOfT on the matrix cores (distr_data/dump_512.pkl is absent from the
     # reference checkout -> weights from the reference's init_weights recipe)
-    'c3': dict(name='C3 ProductOfT ndims=nbasis=512 nparticles=100000/GPU L=20 fp32', kind='pot', D=512, N=100000,
+    'c3': dict(name='C3 ProductOfT ndims=nbasis=512 nparticles=100000 L=20 fp32 (state and force; the reference '
+                    'keeps a float64 state around its float32 force)', kind='pot', D=512, N=100000,
                L=20, eps=0.05, beta=0.1, dtype='float32', params=None),
-    # BASELINE.json configs[4]: 200000 particles over 8 GPUs = 25000 per GPU; synthetic dictionary (the
-    # reference's distr_data/dump_1024.pkl is not in its checkout)
-    'c5': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=25000/GPU L=25 bf16 state / fp32 accumulate',
-               kind='sic', D=1024, N=25000, L=25, eps=0.05, beta=0.1, dtype='bfloat16', params=None),
+    # BASELINE.json configs[3]
+    'c4': dict(name='C4 Neal funnel ndims=32 nparticles=1000000 L=15 fp64', kind='funnel', D=32, N=1000000,
+               L=15, eps=0.05, beta=0.1, dtype='float64', params=[3.0]),
+    # BASELINE.json configs[4]: all 200000 particles fit one GPU; synthetic dictionary (the reference's
+    # distr_data/dump_1024.pkl is not in its checkout)
+    'c5': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25 bf16 state / fp32 accumulate',
+               kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1, dtype='bfloat16', params=None),
     # BASELINE.json configs[0] (README shape; plumbing)
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
 }
+DTYPE_TAG = {'float64': 'f64', 'float32': 'f32', 'bfloat16': 'bf16 state / f32 accumulate'}
 
 
 def pot_model(D):
@@ -66,16 +77,16 @@ def sic_model():
     return B, y, a0
 
 
-def initial_state(w, rank):
-    rng = np.random.RandomState(1000 + rank)
+def initial_state(w, n, stream):
+    rng = np.random.RandomState(1000 + stream)
     if w['kind'] == 'sic':
-        return sic_model()[2][:, None] + 0.1 * rng.randn(w['D'], w['N'])
+        return (sic_model()[2][:, None] + 0.1 * rng.randn(w['D'], n)).astype(np.float64)
     if w['kind'] == 'pot':
         # gen_init_X of ProductOfT (distributions.py:437-445): Student-t draws mapped through inv(W)
         W, lognu = pot_model(w['D'])
-        Z = np.stack([rng.standard_t(np.float32(np.exp(lognu[i])), size=w['N']) for i in range(w['D'])])
+        Z = np.stack([rng.standard_t(np.float32(np.exp(lognu[i])), size=n) for i in range(w['D'])])
         return np.linalg.solve(W.astype(np.float32).astype(np.float64), Z)
-    X0 = rng.randn(w['D'], w['N'])
+    X0 = rng.randn(w['D'], n)
     if w['kind'] == 'funnel':
         X0[0] *= w['params'][0]
         X0[1:] *= np.exp(X0[0] / 2.)
@@ -83,17 +94,16 @@ def initial_state(w, rank):
 
 
 def algorithmic_bytes_per_particle(D, esize):
-    """One sampling_iteration: read X,V + write X',V' (4*D*s) + per-particle scalars:
-    read EX,EV,H_flf (3s); write EX,EV,H_flf (3s) + dwell (8) + dwell-ring slot (8) + trans (1)."""
+    """One sampling_iteration of an elementwise energy: read X,V + write X',V' (4*D*s) + per-particle
+    scalars: read EX,EV,H_flf (3s); write EX,EV,H_flf (3s) + dwell (8) + dwell-ring slot (8) + trans (1)."""
     return 4 * D * esize + 6 * esize + 17
 
 
-def cpu_baseline(w, seconds_target=15.0):
-    """The NumPy oracle (structurally faithful port of the reference's NumPy path) timed on this
-    host: bounded column sample of the same workload."""
+def cpu_baseline(w, seconds_target):
+    """The NumPy oracle (structurally faithful port of the reference's NumPy path) timed on this host: a bounded
+    column sample of the same workload."""
     from oracle import mjhmc_oracle as orc
     n = min(w['N'], 4000 if w['D'] >= 256 else 20000)
-    rng = np.random.RandomState(7)
     threads = 1
     if w['kind'] in ('pot', 'sic'):
         if w['kind'] == 'pot':
@@ -102,18 +112,14 @@ def cpu_baseline(w, seconds_target=15.0):
         else:
             B, y, _ = sic_model()
             en = orc.SparseImageCode(B, y.reshape(1, -1), lmbda=0.01, cauchy=True)
-        X0 = initial_state(dict(w, N=n), 7)
         try:
             from threadpoolctl import threadpool_info
             threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])   # BLAS threads used by np.dot
         except Exception:
             threads = os.cpu_count()
     else:
-        X0 = rng.randn(w['D'], n)
         en = orc.IsoGaussian(w['params'][0]) if w['kind'] == 'iso' else orc.FunnelNeal(w['params'][0])
-    if w['kind'] == 'funnel':
-        X0[0] *= w['params'][0]
-        X0[1:] *= np.exp(X0[0] / 2.)
+    X0 = initial_state(w, n, 7)
     np.random.seed(11)
     s = orc.MarkovJumpHMC(en, X0, epsilon=w['eps'], beta=w['beta'], num_leapfrog_steps=w['L'], resample=False)
     s.sampling_iteration()                     # warm-up (all-cold first iteration)
@@ -131,37 +137,71 @@ def cpu_baseline(w, seconds_target=15.0):
                        % (w['D'], n, w['N'], w['L'], iters, dt, np.__version__, os.cpu_count()))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=64)     # one fused launch of the elementwise kernels
-    ap.add_argument('--warmup', type=int, default=128)   # the chip needs ~15 ms of work to reach its sustained clocks
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
-    w = WORKLOADS[args.workload]
+def measured_traffic(key, it_per_launch):
+    """PMC-measured HBM bytes of one launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, reduced
+    by tools/reduce_pmc.py into profiles/hbm_traffic.json).  A fused launch moves the state across HBM once whatever
+    its iteration count (that is what fusing means: X, V, EX, EV, H_flf stay on chip between iterations), so its
+    figure is quoted for any number of fused iterations; everything else must match the launch shape."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(key)
+    if not isinstance(rec, dict):
+        return None
+    if rec.get('fused') or abs(rec.get('iterations_per_launch', 0) - it_per_launch) < 1e-9:
+        return rec['bytes_per_launch']
+    return None
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        # one rank per GPU over RCCL.  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to exercise
-        # this code path with several ranks on a single-GPU box.
-        backend = os.environ.get('MJHMC_BENCH_BACKEND', 'nccl')
-        if os.environ.get('MJHMC_BENCH_ONE_GPU'):
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
+class Rig(object):
+    """process-wide plumbing of one bench run"""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.dist = self.torch = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            # one rank per GPU over RCCL.  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to exercise
+            # this code path with several ranks on a single-GPU box.
+            backend = os.environ.get('MJHMC_BENCH_BACKEND', 'nccl')
+            if os.environ.get('MJHMC_BENCH_ONE_GPU'):
+                self.local_rank = 0
+            torch.cuda.set_device(self.local_rank)
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', self.local_rank))
+            else:
+                dist.init_process_group(backend)
+            self.dist, self.torch = dist, torch
+        assert self.world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+        from mjhmc_amd import engine
+        self.ctx = engine.context(self.local_rank)
+
+    def barrier(self, smp):
+        smp.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return list(values)
+        dev = 'cuda' if self.dist.get_backend() == 'nccl' else 'cpu'
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+
+def run_workload(rig, key, steps, warmup, cpu_seconds):
     from mjhmc_amd import engine, _lib
-    ctx = engine.context(local_rank)
+    args, rank, world = rig.args, rig.rank, rig.world
+    w = dict(WORKLOADS[key])
+    n_total = w['N'] if args.scaling == 'strong' else w['N'] * world
+    n_rank = n_total // world
+    first = rank * n_rank
     kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T,
             'sic': _lib.E_SPARSE_CODE}[w['kind']]
     params = w['params']
@@ -171,41 +211,51 @@ def main():
     if w['kind'] == 'sic':
         B, y, _ = sic_model()
         params = np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), y])
-    en = engine.DeviceEnergy(ctx, kind, w['D'], params)
-    X0 = initial_state(w, rank)
-    smp = engine.DeviceSampler(en, X0, seed=20261002, first_particle_id=rank * w['N'], dtype=w['dtype'])
+    en = engine.DeviceEnergy(rig.ctx, kind, w['D'], params)
+    X0 = initial_state(w, n_rank, rank)
+    smp = engine.DeviceSampler(en, X0, seed=20261002, first_particle_id=first, dtype=w['dtype'])
     del X0
     p_r = -np.log(1 - w['beta']) * 0.5
     smp.set_hparams(w['eps'], w['L'], p_r, 1.0)
 
-    def barrier():
-        smp.sync()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    if args.warmup > 0:
-        smp.iterate(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    stats, done = smp.iterate(args.steps)       # K sampling_iterations back to back, one host sync at the end
+    # warm-up: the requested W iterations, then calls of K until the chip has been busy for ~0.2 s (sustained clocks)
+    if warmup > 0:
+        smp.iterate(warmup)
     smp.sync()
-    t1 = time.perf_counter()
-    barrier()
-    assert done == args.steps, 'a non-finite rate interrupted the timed region'
-    elapsed = t1 - t0
-    tim = smp.last_timing()
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t0 = time.perf_counter()
+    calib = []
+    while time.perf_counter() - t0 < 0.2 or len(calib) < 2:
+        tc = time.perf_counter()
+        smp.iterate(steps)
+        smp.sync()
+        calib.append(time.perf_counter() - tc)
+    per_call = rig.max_over_ranks([min(calib)])[0]
+    reps = int(min(max(1, np.ceil(MIN_TIMED_S / per_call)), 4096))
 
-    # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel), measured after the
-    # timed region so that the classical roofline fraction is in the line too
+    call_s, kern_ms, launches = [], 0.0, 0
+    agg = np.zeros(4)                               # l moves, cold caches, E evaluations, dEdX evaluations
+    for _ in range(reps):
+        rig.barrier(smp)
+        tb = time.perf_counter()
+        stats, done = smp.iterate(steps)            # K sampling_iterations back to back, one host sync at the end
+        smp.sync()
+        te = time.perf_counter()
+        rig.barrier(smp)
+        assert done == steps, 'a non-finite rate interrupted the timed region'
+        call_s.append(te - tb)
+        tim = smp.last_timing()                     # HIP events on the sampler's stream around the call's launches
+        kern_ms += tim['jump_kernel_ms']
+        launches += tim['n_jump_launches']
+        agg += [sum(s.l for s in stats), sum(s.n_cold for s in stats), sum(s.E_evals for s in stats),
+                sum(s.dEdX_evals for s in stats)]
+    call_s = rig.max_over_ranks(call_s)
+    elapsed = float(np.sum(call_s))
+    iters = steps * reps
+
+    fused = w['kind'] == 'iso' and steps >= 2 and not os.environ.get('MJHMC_NO_FUSE')
+    # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel), after the timed region
     unfused_ms = None
-    if w['kind'] in ('iso', 'diag') and args.steps >= 2 and not os.environ.get('MJHMC_NO_FUSE'):
+    if fused:
         os.environ['MJHMC_NO_FUSE'] = '1'
         try:
             smp.iterate(32)
@@ -214,107 +264,159 @@ def main():
             unfused_ms = t_u['jump_kernel_ms'] / max(t_u['n_jump_launches'], 1)
         finally:
             del os.environ['MJHMC_NO_FUSE']
+    smp.close()
+    if rank != 0:
+        return None
 
-    gather_info = None
-    if dist is not None:
-        # the one collective of the path: all-gather of sample columns at the end of sample()
-        # (RCCL over xGMI).  Outside the timed region; bounded to 8192 columns per rank.
-        try:
-            from mjhmc_amd.parallel import Comm, ShardPlan, gather_state_columns
-            comm = Comm()
-            smp.ring_alloc(1)
-            smp.iterate(1, ring_slot0=0)
-            ncol = min(8192, w['N'])
-            cols = smp.ring_gather(np.arange(ncol, dtype=np.int64))
-            tg0 = time.perf_counter()
-            full = gather_state_columns(comm, ShardPlan(ncol * world, world), cols)
-            tg1 = time.perf_counter()
-            gather_info = {'ok': bool(full.shape == (w['D'], ncol * world) and np.array_equal(full[:, rank * ncol:(rank + 1) * ncol], cols)),
-                           'backend': comm.backend, 'columns_per_rank': ncol, 'ms': (tg1 - tg0) * 1e3}
-        except Exception as exc:  # the bench line must survive a collective problem
-            gather_info = {'ok': False, 'error': repr(exc)[:300]}
-
-    if rank == 0:
-        esize = 8 if w['dtype'] == 'float64' else 4
-        units = w['D'] * w['N'] * w['L'] * args.steps * world
-        kern_ms = tim['jump_kernel_ms'] / max(tim['n_jump_launches'], 1)        # per sampling iteration
-        abytes = algorithmic_bytes_per_particle(w['D'], esize) * w['N']           # per sampling iteration
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        # elementwise energies: one launch covers up to 64 fused iterations (state stays on chip in between)
-        fused = w['kind'] in ('iso', 'diag') and args.steps >= 2 and not os.environ.get('MJHMC_NO_FUSE')
-        n_launch = -(-args.steps // 64) if fused else args.steps
-        it_per_launch = args.steps / float(n_launch)
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tfile):
-            # PMC-measured HBM bytes of one launch (tools/reduce_pmc.py); only quoted when it was measured on
-            # launches of the same shape as the ones just timed
-            rec = json.load(open(tfile)).get(args.workload)
-            if isinstance(rec, dict) and abs(rec.get('iterations_per_launch', 0) - it_per_launch) < 1e-9:
-                traffic = rec['bytes_per_launch']
-        n_l = sum(s.l for s in stats)
-        n_cold = sum(s.n_cold for s in stats)
-        if w['kind'] in ('pot', 'sic'):
-            # dense energy: the bound is the matrix pipe (fp32 for ProductOfT, bf16 for SparseImageCode).
-            # Algorithmic flops from the exact counters: dEdX_evals * 4*D*K + E_evals * 2*D*K
-            DK = float(w['D']) * (w['D'] if w['kind'] == 'pot' else 256)
-            peak = 157.3 if w['kind'] == 'pot' else 2500.0
-            flops = sum(s.dEdX_evals * 4 * DK + s.E_evals * 2 * DK for s in stats) / len(stats)
-            achieved_tf = flops / (kern_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': achieved_tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved_tf / peak,
-                    'traffic': None, 'kernel': 'pot_jump_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel',
-                    'avg_launch_ms': kern_ms,
-                    'launches_timed': tim['n_jump_launches'], 'algorithmic_flops_per_launch': flops}
-        else:
-            # Vector work executed per iteration: one fused multiply-add per element for the opening half kick,
-            # two per element and leapfrog step (drift, merged kick), on the forward trajectory of every particle
-            # and the inverse one of the cold-cache particles, plus 4 flop per element for the two energy sums.
-            vflops = (1.0 + n_cold / float(w['N'] * args.steps)) * (4.0 * w['L'] + 6.0) * w['D'] * w['N']
-            valu_tf = vflops / (kern_ms * 1e-3) / 1e12
-            valu_peak = 78.6 if w['dtype'] == 'float64' else 157.3
-            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                    'kernel': 'mjhmc_jump_kernel' if fused or w['N'] < 16384 or w['D'] * esize >= 2048 else
-                              'mjhmc_jump_kernel + the compacted passes of one iteration (cold list, inverse-L, R list, refresh)',
-                    'avg_launch_ms': kern_ms * it_per_launch,
-                    'launches_timed': n_launch, 'iterations_per_launch': it_per_launch,
-                    'algorithmic_bytes_per_launch': abytes * it_per_launch,
-                    'note': ('fused launch: the state crosses HBM once per launch, not once per iteration, so the '
-                             'algorithmic rate is not limited by HBM; the limiter is the fp64 vector pipe (see valu)')
-                            if fused else 'one sampling iteration per launch',
-                    'valu': {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak,
-                             'dtype': w['dtype'], 'what': 'trajectory + energy flops only (rates, draws, reductions '
-                                                          'and bookkeeping are vector instructions too, not flops)'}}
+    esize = {'float64': 8, 'float32': 4, 'bfloat16': 2}[w['dtype']]
+    units = float(w['D']) * n_rank * w['L'] * iters * world
+    kern_it_ms = kern_ms / max(launches, 1)                       # device time per sampling iteration (HIP events)
+    n_launch_call = -(-steps // 64) if fused else steps
+    it_per_launch = steps / float(n_launch_call)
+    cold_frac = agg[1] / float(n_rank * iters)
+    if w['kind'] in ('pot', 'sic'):
+        # dense energy: the bound is the matrix pipe (fp32 for ProductOfT, bf16 for SparseImageCode).
+        # Algorithmic flops from the exact counters: dEdX_evals * 4*D*K + E_evals * 2*D*K
+        DK = float(w['D']) * (w['D'] if w['kind'] == 'pot' else 256)
+        peak = 157.3 if w['kind'] == 'pot' else 2500.0
+        flops = (agg[3] * 4 * DK + agg[2] * 2 * DK) / iters
+        tf = flops / (kern_it_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+                'traffic': measured_traffic(key, 1),
+                'kernel': ('pot_jump_kernel + pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel + sic_flf_kernel')
+                          + ' (one sampling iteration = both launches)',
+                'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'algorithmic_flops_per_launch': flops,
+                'hbm': {'algorithmic_bytes_per_launch': 6.0 * w['D'] * esize * n_rank,
+                        'achieved': 6.0 * w['D'] * esize * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s',
+                        'what': 'state rows read and written per iteration; nowhere near the HBM roofline'}}
+        if w['kind'] == 'sic':
+            # every leapfrog step of every 32-particle tile streams both 512 KB fragment orders of the dictionary
+            # from L2 (it cannot stay in a CU): the second bound of this kernel
+            tile_steps = agg[3] / 32.0 / iters
+            l2 = tile_steps * 2 * 512 * 1024 / (kern_it_ms * 1e-3) / 1e9
+            roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS,
+                          'what': 'dictionary bytes streamed from L2 per launch (1 MiB per tile and leapfrog step) / time'}
+    else:
+        abytes = algorithmic_bytes_per_particle(w['D'], esize) * n_rank          # per sampling iteration
+        hbm = {'achieved': abytes / (kern_it_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+               'algorithmic_bytes_per_launch': abytes * it_per_launch}
+        hbm['frac_of_algorithmic'] = hbm['achieved'] / HBM_PEAK_GBS
+        # Vector work executed per iteration: one fused multiply-add per element for the opening half kick, two per
+        # element and leapfrog step (drift, merged kick), on the forward trajectory of every particle and the
+        # inverse one of the cold-cache particles, plus 4 flop per element for the two energy sums.
+        vflops = (1.0 + cold_frac) * (4.0 * w['L'] + 6.0) * w['D'] * n_rank
+        valu_tf = vflops / (kern_it_ms * 1e-3) / 1e12
+        valu_peak = 78.6 if w['dtype'] == 'float64' else 157.3
+        valu = {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak,
+                'what': 'trajectory + energy-sum flops only (rates, draws, reductions and bookkeeping are vector '
+                        'instructions too, not flops)'}
+        traffic = measured_traffic(key, it_per_launch)
+        if fused:
+            # the state crosses HBM once per LAUNCH, not once per iteration: HBM does not bound the launch (the
+            # algorithmic byte rate of SURVEY 8d exceeds the HBM peak); the fp64 vector pipe does
+            roof = dict(valu, bound='fp64_valu', traffic=traffic, kernel='mjhmc_jump_kernel<FUSED>',
+                        avg_launch_ms=kern_it_ms * it_per_launch, launches_timed=launches / it_per_launch,
+                        iterations_per_launch=it_per_launch, algorithmic_flops_per_launch=vflops * it_per_launch)
+            hbm['note'] = ('SURVEY 8d byte model / time: not a bound for a fused launch (HBM actually moved: '
+                           'roofline.traffic per launch)')
+            roof['hbm_algorithmic'] = hbm
             if unfused_ms:
                 roof['one_iteration_per_launch'] = {
-                    'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9, 'unit': 'GB/s',
-                    'frac': abytes / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': abytes / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'traffic': measured_traffic(key + '_one_iteration_per_launch', 1),
                     'what': 'the same kernel with the state crossing HBM every iteration (MJHMC_NO_FUSE=1): HBM-bound'}
+        else:
+            roof = {'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': hbm['achieved'] / HBM_PEAK_GBS, 'traffic': traffic,
+                    'kernel': 'mjhmc_jump_kernel' if n_rank < 16384 or w['D'] * esize >= 2048 else
+                              'mjhmc_jump_kernel + the compacted passes of one iteration (cold list, inverse-L, R list, refresh)',
+                    'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'iterations_per_launch': 1.0,
+                    'algorithmic_bytes_per_launch': abytes, 'valu': valu}
+    per_step = np.array(call_s) * 1e3 / steps
+    out = {
+        'value': units / elapsed, 'unit': 'particle-steps/s', 'ms_per_step': elapsed * 1e3 / iters,
+        'ms_per_step_median': float(np.median(per_step)), 'ms_per_step_min': float(per_step.min()),
+        'ms_per_step_max': float(per_step.max()), 'repeats': reps, 'timed_s': elapsed,
+        'dtype': DTYPE_TAG[w['dtype']],
+        'config': {'workload': w['name'], 'ndims': w['D'], 'nparticles_per_gpu': n_rank, 'nparticles_total': n_rank * world,
+                   'L': w['L'], 'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
+                   'particles_x_L_per_s': n_rank * world * w['L'] * iters / elapsed,
+                   'L_move_fraction': agg[0] / float(n_rank * iters), 'cold_fraction': cold_frac},
+        'roofline': roof,
+    }
+    if world == 1 and cpu_seconds > 0:
+        out['cpu_baseline'] = cpu_baseline(w, cpu_seconds)
+        out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+    return out
+
+
+def sample_gather_check(rig):
+    """The one collective of the path: the all-gather of sample columns at the end of sample() (RCCL over xGMI),
+    outside every timed region, on a small sampler."""
+    try:
+        from mjhmc_amd import engine, _lib
+        from mjhmc_amd.parallel import Comm, ShardPlan, gather_state_columns
+        comm = Comm()
+        D, ncol = 32, 8192
+        en = engine.DeviceEnergy(rig.ctx, _lib.E_ISO_GAUSS, D, [1.0])
+        smp = engine.DeviceSampler(en, np.random.RandomState(rig.rank).randn(D, ncol), seed=1, first_particle_id=rig.rank * ncol)
+        smp.set_hparams(0.1, 5, 0.05, 1.0)
+        smp.ring_alloc(1)
+        smp.iterate(1, ring_slot0=0)
+        cols = smp.ring_gather(np.arange(ncol, dtype=np.int64))
+        tg0 = time.perf_counter()
+        full = gather_state_columns(comm, ShardPlan(ncol * rig.world, rig.world), cols)
+        tg1 = time.perf_counter()
+        ok = full.shape == (D, ncol * rig.world) and np.array_equal(full[:, rig.rank * ncol:(rig.rank + 1) * ncol], cols)
+        return {'ok': bool(ok), 'backend': comm.backend, 'columns_per_rank': ncol, 'ms': (tg1 - tg0) * 1e3}
+    except Exception as exc:  # the bench line must survive a collective problem
+        return {'ok': False, 'error': repr(exc)[:300]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=64)     # iterations per mjhmc_iterate call (one fused launch of the elementwise kernels)
+    ap.add_argument('--warmup', type=int, default=64)
+    ap.add_argument('--workload', default='all', choices=sorted(WORKLOADS) + ['all'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    rig = Rig(args)
+    keys = ['c2', 'c3', 'c4', 'c5'] if args.workload == 'all' else [args.workload]
+    head = keys[0]
+    results = {}
+    for key in keys:
+        # the dense workloads run ~10-20 ms per iteration: a batch of K of them is already long
+        steps = args.steps if key in ('c2', 'c4', 'c1') else max(2, min(args.steps, 16))
+        warm = args.warmup if key in ('c2', 'c4', 'c1') else min(args.warmup, 4)
+        cpu_s = 0 if args.no_cpu_baseline else (12.0 if key == head else 6.0)
+        results[key] = run_workload(rig, key, steps, warm, cpu_s)
+        if results[key] is not None:
+            results[key]['steps'] = steps
+            results[key]['warmup'] = warm
+    gather_info = sample_gather_check(rig) if rig.dist is not None else None
+    if rig.rank == 0:
+        h = results[head]
         out = {
             'metric': 'particle-steps/sec (ndims x nparticles x L)',
-            'value': units / elapsed,
-            'unit': 'particle-steps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed * 1e3 / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'float64': 'f64', 'float32': 'f32', 'bfloat16': 'bf16 state / f32 accumulate'}[w['dtype']],
-            'data': 'synthetic',
-            'config': {'workload': w['name'], 'ndims': w['D'], 'nparticles_per_gpu': w['N'], 'L': w['L'],
-                       'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
-                       'particles_x_L_per_s': w['N'] * w['L'] * args.steps * world / elapsed,
-                       'L_move_fraction': n_l / float(w['N'] * args.steps),
-                       'cold_fraction': n_cold / float(w['N'] * args.steps)},
-            'roofline': roof,
+            'value': h['value'], 'unit': h['unit'], 'n_gpus': rig.world, 'steps': h['steps'], 'warmup': h['warmup'],
+            'ms_per_step': h['ms_per_step'], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'dtype': h['dtype'], 'data': 'synthetic', 'config': h['config'], 'roofline': h['roofline'],
+            'timing': {k: h[k] for k in ('ms_per_step_median', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'timed_s')},
         }
+        if 'cpu_baseline' in h:
+            out['cpu_baseline'] = h['cpu_baseline']
         if gather_info is not None:
-            out['config']['sample_gather'] = gather_info
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(w)
-            out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+            out['config'] = dict(out['config'], sample_gather=gather_info)
+        if len(keys) > 1:
+            out['workloads'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world, scaling=args.scaling)
+                                for k, v in results.items()}
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rig.dist is not None:
+        rig.dist.barrier()
+        rig.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

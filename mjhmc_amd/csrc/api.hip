@@ -97,7 +97,7 @@ struct mjhmc_sampler {
   void* Hflf[2] = {nullptr, nullptr};
   double* dwell = nullptr;
   double* dwell_scratch = nullptr;  // dwell_ring target when no ring slot is recorded
-  void* ck[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // checkpoint: X, V, EX, EV, Hflf, dwell
+  void* ck[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // checkpoint: X, V, EX, EV, Hflf, dwell, dEdX (ProductOfT)
   uint64_t ck_tick = 0;
   bool ck_valid = false;
   uint8_t* trans = nullptr;
@@ -776,7 +776,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
-                  s->ck[5]};
+                  s->ck[5],   s->ck[6]};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : s->ev_total)
@@ -904,9 +904,13 @@ int mjhmc_checkpoint(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
   const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
-  const size_t sizes[6] = {mb, mb, vb, vb, vb, db};
-  const void* src[6] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell};
-  for (int i = 0; i < 6; ++i) {
+  // ProductOfT keeps dE/dX of the current state (HMCState.dEdX) and the jump kernel does not recompute it: it is
+  // part of the state a rollback must put back
+  const int nck = s->en->is_pot() ? 7 : 6;
+  const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
+  const void* src[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
+                        s->Gbuf[s->vcur]};
+  for (int i = 0; i < nck; ++i) {
     if (!s->ck[i]) HIPCHK(hipMalloc(&s->ck[i], sizes[i]));
     HIPCHK(hipMemcpyAsync(s->ck[i], src[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
   }
@@ -920,10 +924,12 @@ int mjhmc_restore(mjhmc_sampler* s) {
   if (!s->ck_valid) return fail(MJHMC_ERR_INVALID, "no checkpoint taken");
   HIPCHK(hipSetDevice(s->ctx->device));
   const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
-  const size_t sizes[6] = {mb, mb, vb, vb, vb, db};
+  const int nck = s->en->is_pot() ? 7 : 6;
+  const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
   s->Xcur = s->Xbuf[0];
-  void* dst[6] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell};
-  for (int i = 0; i < 6; ++i) HIPCHK(hipMemcpyAsync(dst[i], s->ck[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
+  void* dst[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
+                  s->Gbuf[s->vcur]};
+  for (int i = 0; i < nck; ++i) HIPCHK(hipMemcpyAsync(dst[i], s->ck[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
   s->tick = s->ck_tick;
   HIPCHK(hipStreamSynchronize(s->stream));
   return 0;

@@ -15,9 +15,11 @@ PARITY STATUS
     TestGaussian/Gaussian/RoughWell/MultimodalGaussian energies) -- checked bit-for-bit
     against golden vectors captured from the imported reference (oracle/capture_golden.py ->
     tests/golden/*.npz, verified by tests/test_oracle_golden.py).
-  * parity unpinned: ProductOfT (Theano), Funnel and SparseImageCode (TensorFlow 0.x) cannot be
-    imported anywhere (neither package is installable here; the reference pins no versions).
-    Their formulas below are restated from the cited lines and checked against autograd only.
+  * parity unpinned by the reference: ProductOfT (Theano), Funnel and SparseImageCode (TensorFlow 0.x)
+    cannot be imported anywhere (neither package is installable here; the reference pins no versions).
+    Their formulas below are restated from the cited lines; the hand-derived gradients are checked
+    against an independent torch restatement of the reference's forward graphs with autograd gradients
+    (oracle/autograd_energies.py, tests/test_oracle_autograd.py, fixtures tests/golden/g2_dense.npz).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 The product (mjhmc_amd) never does.
@@ -325,11 +327,17 @@ class FunnelNeal(Energy):
 class SparseImageCode(Energy):
     """Sparse-coding posterior over coefficients, the per-particle maths tf_distributions.py:241-272
     intends: E = mean_p 1/2 |y_p - B a_p|^2 + lambda * sum log(1+a^2) (Cauchy) or lambda*sum|a|.
-    State rows are patch-major: row p*n_coeffs + c.  PARITY UNPINNED."""
+    State rows are patch-major: row p*n_coeffs + c.  PARITY UNPINNED.
 
-    def __init__(self, basis, patches, lmbda=0.01, cauchy=True):
+    ``operand_rounding`` (a callable, e.g. round-to-bfloat16) restates the mixed-precision form BASELINE.json
+    configs[4] asks for -- "bf16 state / fp32 accumulate": both matrix products take rounded operands (the
+    dictionary, the coefficients entering B a, the residual entering B^T r) and accumulate exactly; everything
+    else (prior, sums of squares, integrator) stays in full precision."""
+
+    def __init__(self, basis, patches, lmbda=0.01, cauchy=True, operand_rounding=None):
         Energy.__init__(self)
-        self.B = np.asarray(basis, dtype=np.float64)            # (img, n_coeffs)
+        self.rnd = operand_rounding or (lambda a: a)
+        self.B = self.rnd(np.asarray(basis, dtype=np.float64))  # (img, n_coeffs)
         self.Y = np.asarray(patches, dtype=np.float64)          # (n_patches, img)
         self.lmbda = lmbda
         self.cauchy = cauchy
@@ -337,7 +345,7 @@ class SparseImageCode(Energy):
     def _resid(self, X):
         P = self.Y.shape[0]
         C = self.B.shape[1]
-        A = X.reshape(P, C, -1)
+        A = self.rnd(X).reshape(P, C, -1)
         recon = np.einsum('ic,pcn->pin', self.B, A)
         return recon - self.Y[:, :, None], A
 
@@ -350,7 +358,7 @@ class SparseImageCode(Energy):
     def dEdX_val(self, X):
         R, _ = self._resid(X)
         P = self.Y.shape[0]
-        g = np.einsum('ic,pin->pcn', self.B, R).reshape(X.shape) / P
+        g = np.einsum('ic,pin->pcn', self.B, self.rnd(R)).reshape(X.shape) / P
         pen = 2 * X / (1 + X ** 2) if self.cauchy else np.sign(X)
         return g + self.lmbda * pen
 
@@ -438,6 +446,10 @@ class Particles(object):
     def L(self):                                                                  # :93-100
         for _ in range(self.owner.num_leapfrog_steps):
             self.leap()
+        rnd = getattr(self.owner, 'state_rounding', None)
+        if rnd is not None:      # reduced-precision STATE (bf16 / float32 configs): the end point is stored rounded
+            self.X[:, self.live] = rnd(self.X[:, self.live])
+            self.V[:, self.live] = rnd(self.V[:, self.live])
         self.refresh_EV()
         self.refresh_EX()
         return self
@@ -457,6 +469,9 @@ class Particles(object):
     def R(self):                                                                  # :121-129
         beta = self.owner.beta
         self.V = self.V * np.sqrt(1. - beta) + self.owner.rng.normals(self.owner.ndims, self.n) * np.sqrt(beta)
+        rnd = getattr(self.owner, 'state_rounding', None)
+        if rnd is not None:
+            self.V = rnd(self.V)
         self.refresh_EV()
         return self
 
@@ -507,8 +522,9 @@ class _SamplerCore(object):
     """Hyper-parameters, counters, E/dEdX plumbing (markov_jump_hmc.py:67-104)."""
 
     def __init__(self, energy, Xinit, epsilon=1e-4, alpha=0.2, beta=None, num_leapfrog_steps=5,
-                 rng=None, V0=None, build_state=True):
+                 rng=None, V0=None, build_state=True, state_rounding=None):
         self.rng = GlobalNumpyRNG() if rng is None else rng
+        self.state_rounding = state_rounding     # None on the reference's float64 path (every golden fixture)
         self.energy = energy
         self.ndims, self.nbatch = Xinit.shape
         self.num_leapfrog_steps = num_leapfrog_steps

@@ -32,3 +32,123 @@ def bits_equal(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     return a.shape == b.shape and bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))))
+
+
+# ---------------------------------------------------------------------------------------------
+# model recipes shared by the dense-energy fixtures (oracle/capture_dense_fixtures.py) and their tests
+# ---------------------------------------------------------------------------------------------
+def ref_init_weights(ndims, nbasis):
+    """init_weights of mjhmc/search/MJHMC_poe_36/mjhmc_objective.py:15-23 (seed 2015), as the reference writes it."""
+    rs = np.random.RandomState(2015)
+    sp_var = rs.rand(ndims, nbasis)
+    w_sp = rs.randn(ndims, nbasis)
+    w_sp[sp_var > 0.05] = 0
+    lognu = np.log(rs.rand(nbasis,) * 2 + 2.1)
+    return w_sp, lognu
+
+
+def sic_problem(seed=0, n_patches=1, img=256, n_coeffs=1024):
+    """Synthetic sparse-coding problem (the reference's distr_data/dump_1024.pkl is not in its
+    checkout): column-normalised dictionary B (img, n_coeffs), patches y_p = B a0_p + 0.1 noise with 5 %-sparse
+    a0_p.  Returns B, imgs (img, n_patches) as the reference's data['data'] is laid out, a0 (n_patches * n_coeffs,)."""
+    rs = np.random.RandomState(seed)
+    B = rs.randn(img, n_coeffs)
+    B /= np.linalg.norm(B, axis=0, keepdims=True)
+    a0 = rs.randn(n_coeffs) * (rs.rand(n_coeffs) < 0.05)
+    y = B.dot(a0) + 0.1 * rs.randn(img)
+    cols, codes = [y], [a0]
+    for _ in range(1, n_patches):
+        a = rs.randn(n_coeffs) * (rs.rand(n_coeffs) < 0.05)
+        cols.append(B.dot(a) + 0.1 * rs.randn(img))
+        codes.append(a)
+    return B, np.stack(cols, axis=1), np.concatenate(codes)
+
+
+def to_bf16(a):
+    """round-to-nearest-even float64 -> bfloat16 -> float64 (what the device stores)"""
+    u = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------
+# reduced-precision kernels (float32 ProductOfT, bf16 SparseImageCode): a transition that differs from the float64
+# oracle must be a NEAR TIE -- the oracle itself changes its mind when the energy differences move by no more than
+# the kernel's energy error -- and everything else must be equal.
+# ---------------------------------------------------------------------------------------------
+def oracle_proposal_energies(o):
+    """(H0, HL, Hflf, unit exponentials (3, N)) the oracle's NEXT MarkovJumpHMC.sampling_iteration will use
+    (markov_jump_hmc.py:356-368); evaluation counters are put back."""
+    en = o.energy
+    counts = (en.E_count, en.dEdX_count)
+    H0 = o.state.H()[0].copy()
+    HL = o.state.clone().L().H()[0].copy()
+    Hflf = o.state.clone().FLF().H()[0].copy()
+    en.E_count, en.dEdX_count = counts
+    exps = np.asarray(o.rng.stream.unit_exponentials(o.rng.tick), dtype=np.float64)
+    return H0, HL, Hflf, exps
+
+
+def _argmin_lfr(dHL, dHflf, p_r, exps):
+    with np.errstate(all='ignore'):
+        l = np.exp(dHL) ** .5
+        flf = np.exp(dHflf) ** .5
+        f = flf - np.minimum(flf, l)
+        r = np.full_like(l, p_r)
+        draws = []
+        for rate, e in ((l, exps[0]), (f, exps[1]), (r, exps[2])):
+            draws.append(np.where(rate == 0, np.inf, (1. / rate) * e))
+    return np.argmin(np.stack(draws), axis=0)
+
+
+def explainable_transitions(H0, HL, Hflf, p_r, exps, delta, device_trans, grid=5):
+    """bool (N,): the device's transition is what the oracle's own decision rule yields for SOME perturbation of the
+    two energy differences H0 - HL and H0 - Hflf by at most ``delta`` (scalar or (N,)) each."""
+    ok = np.zeros(H0.shape[0], dtype=bool)
+    steps = np.linspace(-1.0, 1.0, grid)
+    for a in steps:
+        for b in steps:
+            ok |= _argmin_lfr(H0 - HL + a * delta, H0 - Hflf + b * delta, p_r, exps) == device_trans
+    return ok
+
+
+def resync(s, o, cols=None):
+    """next iteration starts from the device state on both sides (reduced-precision states drift apart otherwise)"""
+    sel = slice(None) if cols is None else cols
+    Xd, Vd = s.state.X[:, sel], s.state.V[:, sel]
+    hflf = s._dev.read(5)[sel]
+    o.state.X[:], o.state.V[:] = Xd, Vd
+    o.state.refresh_EX(); o.state.refresh_EV(); o.state.refresh_grad()
+    o.state.shadow_ok[:] = ~np.isnan(hflf)
+    o.state.shadow.EX[0, :] = np.nan_to_num(hflf)
+    o.state.shadow.EV[0, :] = 0.0
+
+
+def check_iteration(s, o, delta_rel, x_tol, e_rtol, tag='', cols=None):
+    """One MarkovJumpHMC.sampling_iteration on the device sampler ``s`` and on the oracle ``o`` (which may hold only the
+    columns ``cols`` of the batch) from identical inputs.  Every transition must be the oracle's, or be a provable
+    near tie at an energy error of ``delta_rel`` * max|H|; state, energies, cache flags and dwelling times of the
+    agreeing particles are compared.  Returns the number of near ties."""
+    sel = slice(None) if cols is None else cols
+    H0, HL, Hflf, exps = oracle_proposal_energies(o)
+    s.sampling_iteration()
+    o.sampling_iteration()
+    tr, tro = s._dev.read(8)[sel], o.last_transition
+    scale = max(1.0, float(np.abs(H0).max()))
+    ok = explainable_transitions(H0, HL, Hflf, o.p_r, exps, delta_rel * scale, tr)
+    diff = tr != tro
+    assert ok.all(), (tag, 'transitions not explained by an energy error of %g: particles %s' %
+                      (delta_rel * scale, np.nonzero(~ok)[0][:10]))
+    same = ~diff
+    Xd, Vd = s.state.X[:, sel], s.state.V[:, sel]
+    xs = max(1.0, float(np.abs(o.state.X).max()))
+    assert np.abs(Xd[:, same] - o.state.X[:, same]).max() <= x_tol * xs, (tag, 'X')
+    assert np.abs(Vd[:, same] - o.state.V[:, same]).max() <= x_tol * max(1.0, float(np.abs(o.state.V).max())), (tag, 'V')
+    assert np.allclose(s.state.EX[0, sel][same], o.state.EX[0, same], rtol=e_rtol, atol=e_rtol * scale), (tag, 'EX')
+    assert np.allclose(s.state.EV[0, sel][same], o.state.EV[0, same], rtol=e_rtol, atol=e_rtol * scale), (tag, 'EV')
+    assert np.array_equal(s.state.cache_active[sel][same], o.state.shadow_ok[same]), (tag, 'cache flags')
+    keep = same & np.isfinite(o.dwelling_times) & (tr != 1)
+    # dwell = e / sqrt(exp(dH)): an energy error d moves it by d/2 relative (the F clock, flf - min(flf, l), is
+    # ill-conditioned near flf == l and is covered by the transition check instead)
+    assert np.allclose(s.dwelling_times[sel][keep], o.dwelling_times[keep], rtol=max(1e-3, 4 * delta_rel * scale)), (tag, 'dwell')
+    return int(diff.sum())

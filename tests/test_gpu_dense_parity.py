@@ -1,0 +1,177 @@
+"""GPU: the energies the reference builds symbolically (ProductOfT / Funnel / SparseImageCode), through the C ABI,
+against (1) the committed G2 fixtures -- torch restatement of the reference's forward graphs + autograd gradients,
+oracle/capture_dense_fixtures.py -- and (2) the NumPy oracle, from the particle states the reference itself ships
+(initializations/*.pickle -> tests/golden/ref_init_states.npz).
+
+Bars.  Funnel (float64): 1e-10 relative.  ProductOfT (float32 kernel; the reference also evaluates it in float32):
+the spread between the float32 and float64 fixture values times a small factor.  SparseImageCode (bf16 operands,
+float32 accumulation): against the mixed-precision restatement of the oracle (operands rounded to bf16, exact
+accumulation) at float32-accumulation tolerance, against the full-precision fixtures at bf16 tolerance.
+Transitions: equal to the oracle's, except particles that are provably NEAR TIES (tests/helpers.py:
+explainable_transitions) -- no agreement percentages.
+"""
+import numpy as np
+import pytest
+
+from oracle import mjhmc_oracle as orc
+from tests.helpers import load, ref_init_weights, sic_problem, to_bf16, resync as _resync, check_iteration
+
+pytestmark = pytest.mark.gpu
+np.seterr(all='ignore')
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+# ---------------------------------------------------------------------------------------------
+# Funnel: as coded (E_FUNNEL_REF, tf_distributions.py:157-165) and as documented (E_FUNNEL_NEAL)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,scale,literal', [('funnel_lit_s1_10x50', 1.0, True), ('funnel_lit_s3_10x50', 3.0, True),
+                                               ('funnel_neal_s3_10x50', 3.0, False), ('funnel_neal_s3_32x64', 3.0, False)])
+def test_funnel_single_evaluation_matches_autograd_fixture(tag, scale, literal):
+    from mjhmc_amd.misc.distributions import Funnel
+    g = load('g2_dense')
+    X = g[tag + '_X']
+    D, n = X.shape
+    d = Funnel(scale=scale, nbatch=n, ndims=D, literal=literal)
+    E, G = d.E(X), d.dEdX(X)
+    assert E.shape == (1, n) and G.shape == (D, n) and (d.E_count, d.dEdX_count) == (n, n)
+    assert rel(E[0], g[tag + '_E']) < 1e-10
+    assert rel(G, g[tag + '_g']) < 1e-10
+    o = (orc.FunnelLiteral if literal else orc.FunnelNeal)(scale)
+    assert rel(E[0], np.asarray(o.E_val(X)).reshape(-1)) < 1e-10 and rel(G, o.dEdX_val(X)) < 1e-10
+
+
+def test_funnel_literal_leapfrog_step_matches_oracle():
+    """One L() of the as-coded funnel (the chains diverge on it, so one short trajectory is all that is compared)."""
+    from mjhmc_amd.misc.distributions import Funnel
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    g = load('g2_dense')
+    X0 = g['funnel_lit_s1_10x50_X'] * 0.3
+    V0 = np.random.RandomState(1).randn(*X0.shape)
+
+    class Fixed(Funnel):
+        def gen_init_X(self):
+            self.Xinit = X0
+
+    s = MarkovJumpHMC(distribution=Fixed(scale=1.0, nbatch=50, ndims=10, literal=True), epsilon=0.01, beta=0.2,
+                      num_leapfrog_steps=3, Vinit=V0, seed=1)
+    Z = s.state.copy().L()
+    o = orc.MarkovJumpHMC(orc.FunnelLiteral(1.0), X0, epsilon=0.01, beta=0.2, num_leapfrog_steps=3, V0=V0,
+                          rng=orc.ReplayRNG())
+    Zo = o.state.clone().L()
+    assert rel(Z.X, Zo.X) < 1e-10 and rel(Z.V, Zo.V) < 1e-10
+    assert rel(Z.EX, Zo.EX) < 1e-10 and rel(Z.EV, Zo.EV) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------
+# ProductOfT: single evaluations against the autograd fixtures
+# ---------------------------------------------------------------------------------------------
+def _pot(D, n, b=None, X0=None):
+    from mjhmc_amd.misc.distributions import ProductOfT
+    W, lognu = ref_init_weights(D, D)
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0 if X0 is not None else np.zeros((D, n))
+
+    return Fixed(ndims=D, nbasis=D, nbatch=n, lognu=lognu, W=W, b=b), W, lognu
+
+
+@pytest.mark.parametrize('tag,D,n,src', [('pot_36x25', 36, 25, 'g2_dense'), ('pot_512x64', 512, 64, 'g2_dense'),
+                                         ('pot36', 36, 256, 'ref_init_states')])
+def test_pot_single_evaluation_matches_autograd_fixture(tag, D, n, src):
+    g = load(src)
+    X = g[tag + '_X']
+    b = g[tag + '_b'] if tag + '_b' in g else None
+    d, W, lognu = _pot(D, n, b)
+    E, G = d.E(X), d.dEdX(X)
+    assert E.shape == (1, n) and G.shape == (D, n)
+    # float32 kernel against float64 autograd values: a few times the spread the reference's own float32 graph shows
+    if tag + '_E32' in g:
+        spread_E = max(rel(g[tag + '_E32'], g[tag + '_E']), 1e-7)
+        spread_g = max(rel(g[tag + '_g32'], g[tag + '_g']), 1e-7)
+    else:
+        spread_E, spread_g = 1e-6, 4e-6
+    assert rel(E[0], g[tag + '_E']) < 8 * spread_E, (rel(E[0], g[tag + '_E']), spread_E)
+    assert rel(G, g[tag + '_g']) < 8 * spread_g, (rel(G, g[tag + '_g']), spread_g)
+
+
+# ---------------------------------------------------------------------------------------------
+# SparseImageCode: single evaluations
+# ---------------------------------------------------------------------------------------------
+def _sic(P, n, cauchy, X0):
+    from mjhmc_amd.misc.distributions import SparseImageCode
+    B, imgs, a0 = sic_problem(0, n_patches=P)
+    d = SparseImageCode(n_patches=P, n_batches=n, cauchy=cauchy, n_basis=1024, basis=B, imgs=imgs, init=X0)
+    return d, B, imgs
+
+
+def _sic_cases():
+    for P, n, cauchy in ((1, 1, True), (1, 8, True), (1, 8, False), (9, 1, True), (9, 4, True)):
+        yield 'sic_p%d_n%d_%s' % (P, n, 'cauchy' if cauchy else 'laplace'), P, n, cauchy, 'g2_dense'
+    yield 'sic_mj', 1, 10, True, 'ref_init_states'
+    yield 'sic_ctl', 1, 10, True, 'ref_init_states'
+
+
+@pytest.mark.parametrize('tag,P,n,cauchy,src', list(_sic_cases()), ids=[c[0] for c in _sic_cases()])
+def test_sic_single_evaluation(tag, P, n, cauchy, src):
+    g = load(src)
+    X = g[tag + '_X']
+    d, B, imgs = _sic(P, n, cauchy, X)
+    E, G = d.E(X), d.dEdX(X)
+    assert E.shape == (1, n) and G.shape == (P * 1024, n)
+    # (1) mixed-precision restatement: bf16 operands, exact accumulation -> float32-accumulation tolerance
+    o = orc.SparseImageCode(B, imgs[:, :P].T, lmbda=0.01, cauchy=cauchy, operand_rounding=to_bf16)
+    Xb = to_bf16(X)                                   # what the device stores
+    assert rel(E[0], o.E_val(Xb)[0]) < 2e-5, rel(E[0], o.E_val(Xb)[0])
+    assert rel(G, o.dEdX_val(Xb)) < 2e-4, rel(G, o.dEdX_val(Xb))
+    # (2) the full-precision autograd fixture at bf16 tolerance (8 significant bits in every operand)
+    assert rel(E[0], g[tag + '_E']) < 4e-3, rel(E[0], g[tag + '_E'])
+    assert rel(G, g[tag + '_g']) < 2e-2, rel(G, g[tag + '_g'])
+
+
+# ---------------------------------------------------------------------------------------------
+# sampling iterations from the states the reference ships, transitions proven equal up to near ties
+# ---------------------------------------------------------------------------------------------
+def test_pot_iterations_from_the_reference_states():
+    """MJHMC on ProductOfT 36 x 36 with the seed-2015 weights (search/MJHMC_poe_36/mjhmc_objective.py:15-23), started
+    from the burn-in end points the reference ships (initializations/ProductOfT_...pickle[0])."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    X0 = load('ref_init_states')['pot36_X']
+    N = X0.shape[1]
+    d, W, lognu = _pot(36, N, None, X0)
+    en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
+    s = MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.3, num_leapfrog_steps=6, seed=17, resample=False)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=0.1, beta=0.3, num_leapfrog_steps=6, resample=False,
+                          rng=orc.PhiloxRNG(17, np.arange(N)), state_rounding=lambda a: a.astype(np.float32).astype(np.float64))
+    assert np.allclose(s.state.V, o.state.V, atol=1e-6)
+    _resync(s, o)
+    ties = 0
+    for t in range(6):
+        ties += check_iteration(s, o, delta_rel=2e-5, x_tol=2e-5, e_rtol=2e-5, tag='pot36 it %d' % t)
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        _resync(s, o)
+    assert ties <= 0.002 * 6 * N + 2, ties            # near ties are rare by construction
+
+
+def test_sic_iterations_from_the_reference_states():
+    """MJHMC on SparseImageCode (one patch, 1024 coefficients) from the end points the reference ships
+    (initializations/SparseImageCode_...pickle[0] and [3]; the dictionary itself is not in the reference checkout)."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    r = load('ref_init_states')
+    X0 = to_bf16(np.concatenate([r['sic_mj_X'], r['sic_ctl_X']], axis=1))
+    N = X0.shape[1]
+    d, B, imgs = _sic(1, N, True, X0)
+    en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+    eps, L = 0.0625, 8             # a power of two: rounding the scaled residual == scaling the rounded residual
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=0.2, num_leapfrog_steps=L, seed=23, resample=False)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=eps, beta=0.2, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(23, np.arange(N)), state_rounding=to_bf16)
+    _resync(s, o)
+    for t in range(5):
+        check_iteration(s, o, delta_rel=1e-4, x_tol=1.0 / 128, e_rtol=1e-4, tag='sic it %d' % t)
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        _resync(s, o)

@@ -12,6 +12,7 @@ import pytest
 import bench
 from oracle import mjhmc_oracle as orc
 from tests.test_gpu_parity import close, to_bf16
+from tests.helpers import check_iteration, resync
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +22,7 @@ def test_full_size_c4_funnel():
     from mjhmc_amd import engine, _lib
     w = bench.WORKLOADS['c4']
     D, N, L, eps, beta = w['D'], w['N'], w['L'], w['eps'], w['beta']
-    X0 = bench.initial_state(w, 0)
+    X0 = bench.initial_state(w, N, 0)
     ctx = engine.context(0)
     en = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, D, w['params'])
     s = engine.DeviceSampler(en, X0, seed=11)
@@ -56,17 +57,6 @@ def test_full_size_c4_funnel():
     assert close(EX[cols], o.state.EX[0]) and close(s.read(_lib.F_DWELL)[cols], o.dwelling_times)
 
 
-def _dense_subset_check(s, o, cols, N, state_tol, ex_rtol, ex_atol, min_agree):
-    tr, tro = s._dev.read(8), o.last_transition
-    same = tr[cols] == tro
-    assert same.mean() >= min_agree, same.mean()
-    Xd, Vd = s.state.X[:, cols], s.state.V[:, cols]
-    scale = max(1.0, np.abs(o.state.X).max())
-    assert np.abs(Xd[:, same] - o.state.X[:, same]).max() <= state_tol * scale
-    assert np.allclose(s.state.EX[0, cols][same], o.state.EX[0, same], rtol=ex_rtol, atol=ex_atol)
-    assert s.l_count + s.f_count + s.r_count == N
-
-
 def test_full_size_c3_product_of_t():
     """configs[2]: ProductOfT, ndims=nbasis=512, nparticles=100000, L=20, float32 on the matrix cores."""
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
@@ -74,7 +64,7 @@ def test_full_size_c3_product_of_t():
     w = bench.WORKLOADS['c3']
     D, N, L, eps, beta = w['D'], w['N'], w['L'], w['eps'], w['beta']
     W, lognu = bench.pot_model(D)
-    X0 = bench.initial_state(w, 0)
+    X0 = bench.initial_state(w, N, 0)
 
     class Fixed(ProductOfT):
         def init_X(self):
@@ -83,16 +73,14 @@ def test_full_size_c3_product_of_t():
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=21, resample=False)
     cols = np.sort(np.random.RandomState(5).choice(N, size=48, replace=False))
     o = orc.MarkovJumpHMC(orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64), X0[:, cols], epsilon=eps, beta=beta,
-                          num_leapfrog_steps=L, resample=False, rng=orc.PhiloxRNG(21, cols))
-    V0 = s.state.V                                          # float32-rounded tick-0 momentum: identical inputs
-    assert np.allclose(V0[:, cols], o.state.V, atol=1e-6)
-    o.state.V[:] = V0[:, cols]
-    o.state.refresh_EV()
+                          num_leapfrog_steps=L, resample=False, rng=orc.PhiloxRNG(21, cols),
+                          state_rounding=lambda a: a.astype(np.float32).astype(np.float64))
+    assert np.allclose(s.state.V[:, cols], o.state.V, atol=1e-6)
+    resync(s, o, cols)                                      # float32-rounded state on both sides: identical inputs
     d.E_count = d.dEdX_count = 0
-    s.sampling_iteration()
-    o.sampling_iteration()
+    check_iteration(s, o, delta_rel=2e-5, x_tol=2e-5, e_rtol=2e-5, tag='C3', cols=cols)
     assert d.E_count == 2 * N and d.dEdX_count == 2 * N * L   # first iteration: every inverse-L cache is cold
-    _dense_subset_check(s, o, cols, N, state_tol=2e-4, ex_rtol=1e-4, ex_atol=1e-3, min_agree=0.95)
+    assert s.l_count + s.f_count + s.r_count == N
     # stored energies == energies re-evaluated (device, float32) from the stored state
     Xs = s.state.X[:, :2048]
     assert np.allclose(s.state.EX[0, :2048], d.E(Xs)[0], rtol=2e-5, atol=1e-3)
@@ -102,33 +90,25 @@ def test_full_size_c3_product_of_t():
 
 def test_full_size_c5_sparse_image_code():
     """configs[4]: SparseImageCode, 1024 coefficients / 256-pixel patch, nparticles=200000 (the whole batch on one
-    GPU; bench.py runs the 25000-per-GPU share), L=25, bf16 state / fp32 accumulate."""
+    GPU), L=25, bf16 state / fp32 accumulate; epsilon 2^-4 in place of the benchmark's 0.05 so that the
+    mixed-precision restatement of the oracle is exact up to accumulation order (see test_sic_iterations_vs_oracle)."""
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
     from mjhmc_amd.misc.distributions import SparseImageCode
-    w = dict(bench.WORKLOADS['c5'], N=200000)
-    N, L, eps, beta = w['N'], w['L'], w['eps'], w['beta']
+    w = bench.WORKLOADS['c5']
+    N, L, eps, beta = w['N'], w['L'], 0.0625, w['beta']
     B, y, a0 = bench.sic_model()
-    X0 = to_bf16(bench.initial_state(w, 0))
+    X0 = to_bf16(bench.initial_state(w, N, 0))
     d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y.reshape(256, 1), init=X0)
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=31, resample=False)
     cols = np.sort(np.random.RandomState(6).choice(N, size=48, replace=False))
-    en = orc.SparseImageCode(to_bf16(B), y.reshape(1, -1), lmbda=0.01, cauchy=True)
+    en = orc.SparseImageCode(B, y.reshape(1, -1), lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
     o = orc.MarkovJumpHMC(en, X0[:, cols], epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,
-                          rng=orc.PhiloxRNG(31, cols))
+                          rng=orc.PhiloxRNG(31, cols), state_rounding=to_bf16)
     V0 = s.state.V[:, cols]
     assert np.abs(V0 - o.state.V).max() < 2e-2 and np.array_equal(V0, to_bf16(V0))
-    o.state.V[:] = V0
-    o.state.refresh_EV()
+    resync(s, o, cols)
     d.E_count = d.dEdX_count = 0
-    s.sampling_iteration()
-    o.sampling_iteration()
+    check_iteration(s, o, delta_rel=1e-4, x_tol=1.0 / 128, e_rtol=1e-4, tag='C5', cols=cols)
     assert d.E_count == 2 * N and d.dEdX_count == 2 * N * L
-    tr, tro = s._dev.read(8), o.last_transition
-    same = tr[cols] == tro
-    assert same.mean() >= 0.85, same.mean()
-    moved = same & (tro == 0)
-    Xd = s.state.X[:, cols]
-    assert np.abs(Xd[:, moved] - o.state.X[:, moved]).max() < 3e-2 * max(1.0, np.abs(o.state.X).max())
-    assert np.allclose(s.state.EX[0, cols][moved], o.state.EX[0, moved], rtol=2e-2, atol=0.5)
     assert s.l_count + s.f_count + s.r_count == N
-    assert np.array_equal(s.state.cache_active, tr == 0)
+    assert np.array_equal(s.state.cache_active, s._dev.read(8) == 0)

@@ -1,0 +1,116 @@
+"""CPU: the oracle's HAND-DERIVED gradients of the energies the reference builds symbolically (ProductOfT via Theano,
+Funnel / SparseImageCode via TensorFlow -- none importable) against an independent torch restatement of the reference's
+FORWARD graphs with autograd gradients (mirrors T.grad, distributions.py:408, and tf.gradients,
+tf_distributions.py:91), live and through the committed G2 fixtures (oracle/capture_dense_fixtures.py)."""
+import numpy as np
+import pytest
+
+from oracle import mjhmc_oracle as orc
+from oracle import autograd_energies as ag
+from tests.helpers import load, ref_init_weights, sic_problem
+
+TOL = 1e-12
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize('D,n', [(36, 25), (100, 7), (512, 16)])
+def test_product_of_t_gradient_is_autograd(D, n):
+    W, lognu = ref_init_weights(D, D)
+    b = 0.1 * np.random.RandomState(D).randn(D)
+    X = np.random.RandomState(n).randn(D, n) * 1.5
+    o = orc.ProductOfT(W, lognu=lognu, b=b, force_dtype=np.float64)
+    E, g = ag.product_of_t(W, np.exp(lognu), b, X)
+    assert rel(o.E_val(X)[0], E) < TOL and rel(o.dEdX_val(X), g) < TOL
+
+
+@pytest.mark.parametrize('scale', [1.0, 3.0])
+def test_funnel_gradients_are_autograd(scale):
+    X = np.random.RandomState(3).randn(10, 50)
+    X[0] *= 2.0
+    E, g = ag.funnel_literal(scale, X)
+    o = orc.FunnelLiteral(scale)
+    assert rel(o.E_val(X), E) < TOL and rel(o.dEdX_val(X), g) < TOL
+    E, g = ag.funnel_neal(scale, X)
+    o = orc.FunnelNeal(scale)
+    assert rel(o.E_val(X)[0], E) < TOL and rel(o.dEdX_val(X), g) < TOL
+
+
+@pytest.mark.parametrize('P,cauchy', [(1, True), (1, False), (3, True), (9, True)])
+def test_sparse_image_code_gradient_is_autograd(P, cauchy):
+    B, imgs, a0 = sic_problem(1, n_patches=P, img=64, n_coeffs=128)
+    patches = imgs[:, :P].T
+    o = orc.SparseImageCode(B, patches, lmbda=0.01, cauchy=cauchy)
+    # one active column: the reference graph exactly as coded (tf_distributions.py:241-272)
+    x1 = a0[:, None] + 0.3 * np.random.RandomState(2).randn(P * 128, 1)
+    E, g = ag.sparse_image_code_literal(B, patches, 0.01, cauchy, x1)
+    assert rel(o.E_val(x1)[0], E) < TOL and rel(o.dEdX_val(x1), g) < TOL
+    # several columns: the graph column by column == the per-particle maths of the oracle
+    X = a0[:, None] + 0.3 * np.random.RandomState(4).randn(P * 128, 5)
+    E, g = ag.sparse_image_code_per_column(B, patches, 0.01, cauchy, X)
+    assert rel(o.E_val(X)[0], E) < TOL and rel(o.dEdX_val(X), g) < TOL
+
+
+def test_sparse_image_code_reshape_interleaves_beyond_one_column():
+    """for more than one active column the reference's reshape mixes particles and coefficients, so
+    the literal graph differs from the per-particle maths (which is what the engine implements)."""
+    B, imgs, a0 = sic_problem(1, n_patches=2, img=64, n_coeffs=128)
+    X = a0[:, None] + 0.3 * np.random.RandomState(4).randn(256, 3)
+    E_lit, _ = ag.sparse_image_code_literal(B, imgs[:, :2].T, 0.01, True, X)
+    E_col, _ = ag.sparse_image_code_per_column(B, imgs[:, :2].T, 0.01, True, X)
+    assert rel(E_lit, E_col) > 1e-3
+
+
+# ---- the committed fixtures -------------------------------------------------------------------------------------
+def dense_cases():
+    g = load('g2_dense')
+    for D, n in ((36, 25), (512, 64)):
+        tag = 'pot_%dx%d' % (D, n)
+        W, lognu = ref_init_weights(D, D)
+        yield tag, g, orc.ProductOfT(W, lognu=lognu, b=g[tag + '_b'], force_dtype=np.float64)
+    for s in (1, 3):
+        yield 'funnel_lit_s%d_10x50' % s, g, orc.FunnelLiteral(float(s))
+    for tag in ('funnel_neal_s3_10x50', 'funnel_neal_s3_32x64'):
+        yield tag, g, orc.FunnelNeal(3.0)
+    for P, n, cauchy in ((1, 1, True), (1, 8, True), (1, 8, False), (9, 1, True), (9, 4, True)):
+        B, imgs, _ = sic_problem(0, n_patches=P)
+        yield ('sic_p%d_n%d_%s' % (P, n, 'cauchy' if cauchy else 'laplace'), g,
+               orc.SparseImageCode(B, imgs[:, :P].T, lmbda=0.01, cauchy=cauchy))
+    r = load('ref_init_states')
+    W, lognu = ref_init_weights(36, 36)
+    yield 'pot36', r, orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
+    B, imgs, _ = sic_problem(0)
+    for tag in ('sic_mj', 'sic_ctl'):
+        yield tag, r, orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True)
+
+
+@pytest.mark.parametrize('tag,g,o', list(dense_cases()), ids=[c[0] for c in dense_cases()])
+def test_oracle_matches_dense_fixtures(tag, g, o):
+    X = g[tag + '_X']
+    assert rel(np.asarray(o.E_val(X)).reshape(-1), g[tag + '_E']) < TOL
+    assert rel(o.dEdX_val(X), g[tag + '_g']) < TOL
+
+
+def test_recipes_reproduce_the_fixture_models():
+    """The fixtures hold only inputs and outputs of the big models; the matrices come from seeded recipes."""
+    import hashlib
+    g = load('g2_dense')
+
+    def digest(a):
+        return np.frombuffer(hashlib.sha1(np.ascontiguousarray(a, dtype=np.float64).tobytes()).digest()[:8], dtype=np.uint64)[0]
+    assert digest(ref_init_weights(512, 512)[0]) == g['pot_512x64_Wdigest']
+    assert np.array_equal(ref_init_weights(36, 36)[0], g['pot_36x25_W'])
+    assert digest(sic_problem(0)[0]) == g['sic_p1_n8_cauchy_Bdigest']
+    assert digest(sic_problem(0, n_patches=9)[0]) == g['sic_p9_n4_cauchy_Bdigest']
+
+
+def test_float32_graph_is_within_float32_of_the_float64_one():
+    """The reference evaluates ProductOfT in float32 (allow_input_downcast, distributions.py:413-415); the float32
+    fixture values bound what 'float32 tolerance' means for the device kernel's parity bars."""
+    g = load('g2_dense')
+    for tag in ('pot_36x25', 'pot_512x64'):
+        assert rel(g[tag + '_E32'], g[tag + '_E']) < 5e-6
+        assert rel(g[tag + '_g32'], g[tag + '_g']) < 2e-5
