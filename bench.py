@@ -154,45 +154,42 @@ def measured_traffic(key, it_per_launch):
 
 
 class Rig(object):
-    """process-wide plumbing of one bench run"""
+    """process-wide plumbing of one bench run: one rank per GPU; the ranks meet through the library's own RCCL
+    communicator (mjhmc_comm_*, mjhmc_amd/parallel.py: RcclComm) -- barrier, MAX of the elapsed times, and the sample
+    all-gather checked after the timed regions.  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to
+    exercise the multi-rank code path with several ranks on a single-GPU box (RCCL refuses two ranks on one device):
+    they go through the torch.distributed shim instead."""
 
     def __init__(self, args):
         self.args = args
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
-        self.dist = self.torch = None
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            # one rank per GPU over RCCL.  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to exercise
-            # this code path with several ranks on a single-GPU box.
-            backend = os.environ.get('MJHMC_BENCH_BACKEND', 'nccl')
-            if os.environ.get('MJHMC_BENCH_ONE_GPU'):
-                self.local_rank = 0
-            torch.cuda.set_device(self.local_rank)
-            if backend == 'nccl':
-                dist.init_process_group('nccl', device_id=torch.device('cuda', self.local_rank))
-            else:
-                dist.init_process_group(backend)
-            self.dist, self.torch = dist, torch
         assert self.world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+        if os.environ.get('MJHMC_BENCH_ONE_GPU'):
+            self.local_rank = 0
         from mjhmc_amd import engine
         self.ctx = engine.context(self.local_rank)
+        self.comm = None
+        if self.world > 1:
+            if os.environ.get('MJHMC_BENCH_BACKEND', 'rccl') == 'gloo':
+                import torch.distributed as dist
+                from mjhmc_amd.parallel import Comm
+                dist.init_process_group('gloo')
+                self.comm = Comm()
+            else:
+                from mjhmc_amd.parallel import RcclComm
+                self.comm = RcclComm(self.rank, self.world, device=self.local_rank)
 
     def barrier(self, smp):
         smp.sync()
-        if self.dist is not None:
-            self.dist.barrier()
-            self.torch.cuda.synchronize()
+        if self.comm is not None:
+            self.comm.barrier()
 
     def max_over_ranks(self, values):
-        if self.dist is None:
+        if self.comm is None:
             return list(values)
-        dev = 'cuda' if self.dist.get_backend() == 'nccl' else 'cpu'
-        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return [float(v) for v in t.cpu()]
+        return [float(v) for v in self.comm.allreduce_f64(np.asarray(list(values), dtype=np.float64), 'max')]
 
 
 def run_workload(rig, key, steps, warmup, cpu_seconds):
@@ -352,24 +349,32 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
 
 
 def sample_gather_check(rig):
-    """The one collective of the path: the all-gather of sample columns at the end of sample() (RCCL over xGMI),
-    outside every timed region, on a small sampler."""
+    """The one collective of the path: the all-gather of sample columns at the end of sample() (RCCL over xGMI, device
+    ring to device ring), outside every timed region, on a small sampler; every rank checks the whole block."""
     try:
         from mjhmc_amd import engine, _lib
-        from mjhmc_amd.parallel import Comm, ShardPlan, gather_state_columns
-        comm = Comm()
-        D, ncol = 32, 8192
+        from mjhmc_amd.parallel import ShardPlan, assemble_stacked
+        comm = rig.comm
+        D, ncol, n = 32, 8192, 4
+        plan = ShardPlan(ncol * rig.world, rig.world)
         en = engine.DeviceEnergy(rig.ctx, _lib.E_ISO_GAUSS, D, [1.0])
         smp = engine.DeviceSampler(en, np.random.RandomState(rig.rank).randn(D, ncol), seed=1, first_particle_id=rig.rank * ncol)
         smp.set_hparams(0.1, 5, 0.05, 1.0)
-        smp.ring_alloc(1)
-        smp.iterate(1, ring_slot0=0)
-        cols = smp.ring_gather(np.arange(ncol, dtype=np.int64))
+        smp.ring_alloc(n)
+        smp.iterate(n, ring_slot0=0)
+        mine = smp.ring_read(0, n, stacked=False)
+        comm.barrier()
         tg0 = time.perf_counter()
-        full = gather_state_columns(comm, ShardPlan(ncol * rig.world, rig.world), cols)
+        if comm.on_device:
+            full = comm.allgather_ring(smp, 0, n, False, plan.counts)
+        else:
+            full = assemble_stacked(comm, plan, mine, n, False)
         tg1 = time.perf_counter()
-        ok = full.shape == (D, ncol * rig.world) and np.array_equal(full[:, rig.rank * ncol:(rig.rank + 1) * ncol], cols)
-        return {'ok': bool(ok), 'backend': comm.backend, 'columns_per_rank': ncol, 'ms': (tg1 - tg0) * 1e3}
+        cube = full.reshape(D, n, ncol * rig.world)[:, :, rig.rank * ncol:(rig.rank + 1) * ncol]
+        ok = full.shape == (D, n * ncol * rig.world) and np.array_equal(cube.reshape(D, n * ncol), mine)
+        ok_all = int(comm.allreduce_ints([1 if ok else 0], 'min')[0])
+        return {'ok': bool(ok_all), 'backend': comm.backend, 'columns_per_rank': ncol * n, 'ms': (tg1 - tg0) * 1e3,
+                'bytes_per_rank': int(D * ncol * n * 8), 'device_to_device': bool(comm.on_device)}
     except Exception as exc:  # the bench line must survive a collective problem
         return {'ok': False, 'error': repr(exc)[:300]}
 
@@ -396,7 +401,7 @@ def main():
         if results[key] is not None:
             results[key]['steps'] = steps
             results[key]['warmup'] = warm
-    gather_info = sample_gather_check(rig) if rig.dist is not None else None
+    gather_info = sample_gather_check(rig) if rig.comm is not None else None
     if rig.rank == 0:
         h = results[head]
         out = {
@@ -414,9 +419,10 @@ def main():
             out['workloads'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world, scaling=args.scaling)
                                 for k, v in results.items()}
         print(json.dumps(out))
-    if rig.dist is not None:
-        rig.dist.barrier()
-        rig.dist.destroy_process_group()
+    if rig.comm is not None:
+        rig.comm.barrier()
+        if hasattr(rig.comm, 'close'):
+            rig.comm.close()
 
 
 if __name__ == '__main__':

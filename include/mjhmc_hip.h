@@ -26,11 +26,12 @@
 extern "C" {
 #endif
 
-#define MJHMC_ABI_VERSION 1
+#define MJHMC_ABI_VERSION 2
 
 typedef struct mjhmc_ctx mjhmc_ctx;         /* one per process x device                          */
 typedef struct mjhmc_energy mjhmc_energy;   /* an energy model, parameters resident in HBM       */
 typedef struct mjhmc_sampler mjhmc_sampler; /* particle state (HMCState) + jump-process machinery */
+typedef struct mjhmc_comm mjhmc_comm;       /* this rank's end of an RCCL communicator (one process per GPU)     */
 
 typedef enum {
   MJHMC_OK = 0,
@@ -38,7 +39,8 @@ typedef enum {
   MJHMC_ERR_HIP = -2,          /* a HIP runtime call failed                                      */
   MJHMC_ERR_UNSUPPORTED = -3,  /* e.g. ndims too large for the fused register kernel             */
   MJHMC_ERR_NO_DEVICE = -4,
-  MJHMC_ERR_NONFINITE = -5     /* informational: see mjhmc_iterate                               */
+  MJHMC_ERR_NONFINITE = -5,    /* informational: see mjhmc_iterate                               */
+  MJHMC_ERR_COMM = -6          /* librccl could not be loaded, or an RCCL call failed            */
 } mjhmc_status;
 
 /* Energy models.  params are float64; layout per kind:
@@ -161,6 +163,9 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
  * checkpoint: device copy of X, V, EX, EV, H_flf, dwell + the RNG tick.  restore: put it back. */
 int mjhmc_checkpoint(mjhmc_sampler* s);
 int mjhmc_restore(mjhmc_sampler* s);
+/* Undo the last call when it was mjhmc_iterate(1) and committed: the iteration's inputs are the untouched other
+ * halves of the ping-pong buffers, so no copy is taken or restored (the RNG tick stays consumed). */
+int mjhmc_rollback(mjhmc_sampler* s);
 /* skip n RNG ticks (a rank that did not execute a failed attempt must still consume its tick) */
 int mjhmc_advance_tick(mjhmc_sampler* s, int64_t n);
 
@@ -211,6 +216,38 @@ int mjhmc_ring_autocor(mjhmc_sampler* s, int slot0, int n, int linear, double* h
  * i.e. n_series = n_dims * n_batch contiguous series of n_samples float64 (no sampler needed). */
 int mjhmc_autocor(mjhmc_ctx* ctx, const double* samples, int64_t n_series, int n_samples, int linear,
                   double* host_out);
+
+/* ---- several GPUs: one process per GPU, particle COLUMNS sharded over the ranks ------------------
+ * The reference is single-process; its particles are independent chains (mjhmc/samplers/hmc_state.py works column-wise
+ * everywhere), so nothing is exchanged on the data path until sample() returns (markov_jump_hmc.py:150-173,293-338).
+ * The communicator is RCCL (xGMI between the GPUs of a node), loaded with dlopen on first use.  Every rank calls every
+ * collective in the same order.  Pointers are host memory unless stated. */
+#define MJHMC_COMM_ID_BYTES 128
+typedef enum { MJHMC_OP_SUM = 0, MJHMC_OP_MIN = 1, MJHMC_OP_MAX = 2 } mjhmc_reduce_op;
+/* rank 0 draws the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any host channel (file, socket) */
+int mjhmc_comm_unique_id(void* id);
+int mjhmc_comm_create(mjhmc_ctx* ctx, int rank, int world, const void* id, mjhmc_comm** out);
+int mjhmc_comm_destroy(mjhmc_comm* c);
+/* host values, in place: integer bookkeeping (l/f/r counts, E_count / dEdX_count increments: sums), the number of
+ * iterations every rank committed before a non-finite rate (min: the reference retries the WHOLE batch,
+ * markov_jump_hmc.py:376-389), lag sums of the autocorrelation, elapsed times (max) */
+int mjhmc_comm_allreduce_i64(mjhmc_comm* c, int64_t* inout, int64_t n, int op);
+int mjhmc_comm_allreduce_f64(mjhmc_comm* c, double* inout, int64_t n, int op);
+/* e.g. the np.random.random draws of the resampling step (markov_jump_hmc.py:325), drawn on rank 0 */
+int mjhmc_comm_bcast(mjhmc_comm* c, void* inout, size_t nbytes, int root);
+/* recv = rank 0's block, rank 1's block, ... (nbytes_per_rank[r] bytes each; send: this rank's block) */
+int mjhmc_comm_allgatherv(mjhmc_comm* c, const void* send, const int64_t* nbytes_per_rank, void* recv);
+/* THE data-path collective, device to device: ring slots [slot0, slot0 + n) of every rank's sampler are all-gathered
+ * and re-tiled on the receiving GPU; host_out is the sample block of the UNSHARDED run, columns in global particle
+ * order: (D, n * N_total) time-major if stacked == 0 (np.concatenate(axis=1), markov_jump_hmc.py:170-173,336-338),
+ * (D, N_total, n) if stacked != 0 (np.stack(axis=-1)).  particles_per_rank[world]: the column shard sizes. */
+int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n, int stacked,
+                              const int64_t* particles_per_rank, double* host_out);
+/* resampled columns (markov_jump_hmc.py:322-328): every rank gathers the n_local ring columns IT owns (local pool indices
+ * slot * N_local + column, as mjhmc_ring_gather takes them) on the device, the blocks are all-gathered, host_out is
+ * (D, sum columns_per_rank) with rank 0's columns first; the caller puts them in sample order. */
+int mjhmc_comm_allgather_columns(mjhmc_comm* c, mjhmc_sampler* s, const int64_t* local_idx, int64_t n_local,
+                                 const int64_t* columns_per_rank, double* host_out);
 
 /* Device time of the last mjhmc_iterate call in milliseconds: ONE HIP-event pair on the sampler's stream
  * brackets its whole launch sequence (first to last jump kernel); jump_kernel_ms == total_ms and

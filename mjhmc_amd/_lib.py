@@ -18,6 +18,8 @@ F64, F32, BF16 = 0, 1, 2
 MODE_MJHMC, MODE_CONTROL, MODE_CTHMC = 0, 1, 2
 F_X, F_V, F_EX, F_EV, F_DEDX, F_HFLF, F_CACHE, F_DWELL, F_TRANS = range(9)
 ERR_NO_DEVICE = -4
+OP_SUM, OP_MIN, OP_MAX = 0, 1, 2
+COMM_ID_BYTES = 128
 
 
 class IterStats(ctypes.Structure):
@@ -53,6 +55,7 @@ PROTOTYPES = {
                                      ctypes.POINTER(ctypes.c_int)]),
     'mjhmc_checkpoint': (ctypes.c_int, [_P]),
     'mjhmc_restore': (ctypes.c_int, [_P]),
+    'mjhmc_rollback': (ctypes.c_int, [_P]),
     'mjhmc_advance_tick': (ctypes.c_int, [_P, ctypes.c_int64]),
     'mjhmc_reset_flf_cache': (ctypes.c_int, [_P]),
     'mjhmc_read': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_size_t]),
@@ -65,6 +68,15 @@ PROTOTYPES = {
     'mjhmc_leapfrog': (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int64, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P]),
     'mjhmc_ring_autocor': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     'mjhmc_autocor': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P]),
+    'mjhmc_comm_unique_id': (ctypes.c_int, [_P]),
+    'mjhmc_comm_create': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.POINTER(_P)]),
+    'mjhmc_comm_destroy': (ctypes.c_int, [_P]),
+    'mjhmc_comm_allreduce_i64': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int]),
+    'mjhmc_comm_allreduce_f64': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int]),
+    'mjhmc_comm_bcast': (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int]),
+    'mjhmc_comm_allgatherv': (ctypes.c_int, [_P, _P, _P, _P]),
+    'mjhmc_comm_allgather_ring': (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    'mjhmc_comm_allgather_columns': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, _P, _P]),
     'mjhmc_last_timing': (ctypes.c_int, [_P, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     'mjhmc_sync': (ctypes.c_int, [_P]),
 }

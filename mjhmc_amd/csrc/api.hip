@@ -10,124 +10,19 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mjhmc_hip.h"
 #include "autocor.hpp"
-#include "dense_pot.hpp"
-#include "dense_sic.hpp"
-#include "elementwise.hpp"
-
-using namespace mjhmc;
+#include "handles.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const std::string& msg) {
+int mjhmc_fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-
-#define HIPCHK(expr)                                                                                    \
-  do {                                                                                                  \
-    hipError_t e_ = (expr);                                                                             \
-    if (e_ != hipSuccess)                                                                               \
-      return fail(MJHMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ +  \
-                                     ":" + std::to_string(__LINE__) + ")");                             \
-  } while (0)
-
-#define TRY(expr)             \
-  do {                        \
-    int r_ = (expr);          \
-    if (r_ != 0) return r_;   \
-  } while (0)
-
-// ---------------------------------------------------------------------------------------------
-// handles
-// ---------------------------------------------------------------------------------------------
-struct mjhmc_ctx {
-  int device;
-  hipDeviceProp_t prop;
-};
-
-struct mjhmc_energy {
-  mjhmc_ctx* ctx;
-  EnergyParams ep;
-  std::vector<double> params;
-  void* dev64 = nullptr;
-  void* dev32 = nullptr;
-  float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
-  int pot_dim = kPotDim;  // rows padded to 128, 256 or 512
-  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim, ep.ndims}; }
-  bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
-  void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32)
-  float sic_lambda = 0.f;
-  int sic_cauchy = 1;
-  SicModel sic_model() const { return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy}; }
-  bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
-  bool is_dense() const { return is_pot() || is_sic(); }
-};
-
-struct Shape {
-  int E, logG, pitch, CH, esize;
-};
-
-
-struct mjhmc_sampler {
-  mjhmc_ctx* ctx;
-  mjhmc_energy* en;
-  int64_t N, Npad, first_pid;  // Npad: rows allocated (N rounded up to 64; padding rows stay zero)
-  int D, dtype, mode;
-  Shape sh;
-  hipStream_t stream = nullptr;
-  void* Xbuf[2] = {nullptr, nullptr};
-  void* Vbuf[2] = {nullptr, nullptr};
-  void* Xcur = nullptr;
-  void* Gbuf[2] = {nullptr, nullptr};  // dEdX (dense energies keep it, like HMCState.dEdX); follows vcur
-  float* Hwork = nullptr;              // dense energies: per-attempt H_flf work vector
-  int* cold_list = nullptr;            // + compacted cold-particle list (Npad entries, then the counter)
-  // elementwise energies, several particles per wave: inverse-L pass over the compacted cold particles
-  int* flf_list = nullptr;     // [Npad]
-  int* flf_counts = nullptr;   // [flf_cap] one counter per attempt of the current mjhmc_iterate call
-  int flf_cap = 0;
-  void* Hpre = nullptr;        // [Npad] H_flf with the cold entries filled in
-  int vcur = 0, scur = 0;
-  void* EX[2] = {nullptr, nullptr};
-  void* EV[2] = {nullptr, nullptr};
-  void* Hflf[2] = {nullptr, nullptr};
-  double* dwell = nullptr;
-  double* dwell_scratch = nullptr;  // dwell_ring target when no ring slot is recorded
-  void* ck[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // checkpoint: X, V, EX, EV, Hflf, dwell, dEdX (ProductOfT)
-  uint64_t ck_tick = 0;
-  bool ck_valid = false;
-  uint8_t* trans = nullptr;
-  Control* ctl = nullptr;
-  long long* stats = nullptr;  // [stats_cap][4]
-  int stats_cap = 0;
-  void* ring = nullptr;
-  double* dwell_ring = nullptr;
-  int ring_slots = 0;
-  double* stage = nullptr;  // device staging, float64 host layout
-  size_t stage_elems = 0;
-  void* noise = nullptr;    // replay normals, particle-major
-  double* rexp = nullptr;   // [3][N]
-  double* runif = nullptr;  // [2N+1]
-  void* scratch = nullptr;  // [N][pitch] scratch (dEdX reads)
-  bool download_f32 = false;  // bf16 state: the next download_cols source is a float32 matrix (dEdX)
-  double eps = 1e-4, p_r = 0, beta = 1, p_flip = 0.5;
-  int L = 5;
-  uint64_t seed = 0, tick = 1;
-  hipEvent_t ev_total[2] = {nullptr, nullptr};
-  std::vector<hipEvent_t> ev_k;
-  double last_total_ms = 0, last_jump_ms = 0;
-  int last_jump_launches = 0;
-  bool timing_pending = false;
-};
-
-static size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s->sh.esize; }
-// per-particle scalars (EX, EV, H_flf): float64 for float64 state, float32 otherwise (bf16 state included)
-static size_t ssize(const mjhmc_sampler* s) { return s->dtype == MJHMC_F64 ? 8 : 4; }
-static size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_bytes(s); }
+static int fail(int code, const std::string& msg) { return mjhmc_fail(code, msg); }
 
 static int pow2ceil(int v) {
   int p = 1;
@@ -445,7 +340,7 @@ int dispatch_eval<float>(int kind, const EvalArgs<float>& a, const EnergyParams&
 // ---------------------------------------------------------------------------------------------
 // helpers on a sampler
 // ---------------------------------------------------------------------------------------------
-static int ensure_stage(mjhmc_sampler* s, size_t elems) {
+int ensure_stage(mjhmc_sampler* s, size_t elems) {
   if (s->stage_elems >= elems) return 0;
   if (s->stage) HIPCHK(hipFree(s->stage));
   s->stage = nullptr;
@@ -474,8 +369,8 @@ static int upload_matrix(mjhmc_sampler* s, const double* host, void* dst) {
 }
 
 // device particle-major rows -> host float64 with strides (see to_dim_major)
-static int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_idx, int64_t ncols, double* host,
-                         size_t host_elems, int64_t rs, int64_t cs, int64_t off, bool copy_out) {
+int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_idx, int64_t ncols, double* host,
+                  size_t host_elems, int64_t rs, int64_t cs, int64_t off, bool copy_out) {
   dim3 grid((unsigned)((ncols + 31) / 32), (unsigned)((s->D + 31) / 32)), block(32, 8);
   if (s->dtype == MJHMC_F64)
     hipLaunchKernelGGL(to_dim_major<double>, grid, block, 0, s->stream, (const double*)src, dev_idx, s->stage, s->D,
@@ -931,7 +826,21 @@ int mjhmc_restore(mjhmc_sampler* s) {
                   s->Gbuf[s->vcur]};
   for (int i = 0; i < nck; ++i) HIPCHK(hipMemcpyAsync(dst[i], s->ck[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
   s->tick = s->ck_tick;
+  s->undo_valid = false;
   HIPCHK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int mjhmc_rollback(mjhmc_sampler* s) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  if (!s->undo_valid) return fail(MJHMC_ERR_INVALID, "nothing to roll back: the last call was not a committed single iteration");
+  // an iteration reads one buffer parity and writes the other: flipping the parities back IS the pre-move state
+  // (X, V, EX, EV, H_flf and, for ProductOfT, dE/dX); dwell / trans hold the rolled-back attempt's values until
+  // the retry overwrites them.  The RNG tick stays consumed, like the reference's already-drawn numbers.
+  s->Xcur = s->undo_X;
+  s->vcur ^= 1;
+  s->scur ^= 1;
+  s->undo_valid = false;
   return 0;
 }
 
@@ -1111,6 +1020,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     }
   }
   fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);
+  s->undo_valid = false;
   s->Xcur = xlive;
   s->vcur = (s->vcur + committed) & 1;
   s->scur = (s->scur + committed) & 1;
@@ -1375,6 +1285,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   }
   fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);
   // commit the finished iterations
+  s->undo_valid = (n_iter == 1 && done == 1);  // the input buffers of a single iteration survive it: see mjhmc_rollback
+  s->undo_X = s->Xcur;
   if (done > 0) s->Xcur = xout[done - 1];
   s->vcur = (s->vcur + done) & 1;
   s->scur = (s->scur + done) & 1;
@@ -1516,6 +1428,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
     case MJHMC_F_V: {
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
+      s->undo_valid = false;
       TRY(upload_matrix(s, (const double*)host_src, dst));
       TRY(run_eval(s, s->Xcur, s->Gbuf[s->vcur], s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
       HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
@@ -1544,6 +1457,7 @@ int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots) {
   if (!s || n_slots < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(s->ctx->device));
   if (n_slots <= s->ring_slots) return 0;
+  s->undo_valid = false;
   HIPCHK(hipStreamSynchronize(s->stream));
   const size_t mb = mat_bytes(s);
   // the live X may sit in the old ring: park it in a ping-pong buffer before freeing

@@ -1,0 +1,126 @@
+// Handle structs of the C ABI (include/mjhmc_hip.h) and the few helpers api.hip shares with comm.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mjhmc_hip.h"
+#include "dense_pot.hpp"
+#include "dense_sic.hpp"
+#include "elementwise.hpp"
+
+using namespace mjhmc;
+
+int mjhmc_fail(int code, const std::string& msg);  // records the message for mjhmc_last_error(), returns code
+
+#define HIPCHK(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess)                                                                                    \
+      return mjhmc_fail(MJHMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                           ":" + std::to_string(__LINE__) + ")");                            \
+  } while (0)
+
+#define TRY(expr)             \
+  do {                        \
+    int r_ = (expr);          \
+    if (r_ != 0) return r_;   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct mjhmc_ctx {
+  int device;
+  hipDeviceProp_t prop;
+};
+
+struct mjhmc_energy {
+  mjhmc_ctx* ctx;
+  EnergyParams ep;
+  std::vector<double> params;
+  void* dev64 = nullptr;
+  void* dev32 = nullptr;
+  float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
+  int pot_dim = kPotDim;  // rows padded to 128, 256 or 512
+  PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim, ep.ndims}; }
+  bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
+  void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32)
+  float sic_lambda = 0.f;
+  int sic_cauchy = 1;
+  SicModel sic_model() const { return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy}; }
+  bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
+  bool is_dense() const { return is_pot() || is_sic(); }
+};
+
+struct Shape {
+  int E, logG, pitch, CH, esize;
+};
+
+
+struct mjhmc_sampler {
+  mjhmc_ctx* ctx;
+  mjhmc_energy* en;
+  int64_t N, Npad, first_pid;  // Npad: rows allocated (N rounded up to 64; padding rows stay zero)
+  int D, dtype, mode;
+  Shape sh;
+  hipStream_t stream = nullptr;
+  void* Xbuf[2] = {nullptr, nullptr};
+  void* Vbuf[2] = {nullptr, nullptr};
+  void* Xcur = nullptr;
+  void* Gbuf[2] = {nullptr, nullptr};  // dEdX (dense energies keep it, like HMCState.dEdX); follows vcur
+  float* Hwork = nullptr;              // dense energies: per-attempt H_flf work vector
+  int* cold_list = nullptr;            // + compacted cold-particle list (Npad entries, then the counter)
+  // elementwise energies, several particles per wave: inverse-L pass over the compacted cold particles
+  int* flf_list = nullptr;     // [Npad]
+  int* flf_counts = nullptr;   // [flf_cap] one counter per attempt of the current mjhmc_iterate call
+  int flf_cap = 0;
+  void* Hpre = nullptr;        // [Npad] H_flf with the cold entries filled in
+  int vcur = 0, scur = 0;
+  void* EX[2] = {nullptr, nullptr};
+  void* EV[2] = {nullptr, nullptr};
+  void* Hflf[2] = {nullptr, nullptr};
+  double* dwell = nullptr;
+  double* dwell_scratch = nullptr;  // dwell_ring target when no ring slot is recorded
+  void* ck[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // checkpoint: X, V, EX, EV, Hflf, dwell, dEdX (ProductOfT)
+  uint64_t ck_tick = 0;
+  bool ck_valid = false;
+  void* undo_X = nullptr;   // pre-move X of the last single-iteration call (its ping-pong input, still intact)
+  bool undo_valid = false;
+  uint8_t* trans = nullptr;
+  Control* ctl = nullptr;
+  long long* stats = nullptr;  // [stats_cap][4]
+  int stats_cap = 0;
+  void* ring = nullptr;
+  double* dwell_ring = nullptr;
+  int ring_slots = 0;
+  double* stage = nullptr;  // device staging, float64 host layout
+  size_t stage_elems = 0;
+  void* noise = nullptr;    // replay normals, particle-major
+  double* rexp = nullptr;   // [3][N]
+  double* runif = nullptr;  // [2N+1]
+  void* scratch = nullptr;  // [N][pitch] scratch (dEdX reads)
+  bool download_f32 = false;  // bf16 state: the next download_cols source is a float32 matrix (dEdX)
+  double eps = 1e-4, p_r = 0, beta = 1, p_flip = 0.5;
+  int L = 5;
+  uint64_t seed = 0, tick = 1;
+  hipEvent_t ev_total[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_k;
+  double last_total_ms = 0, last_jump_ms = 0;
+  int last_jump_launches = 0;
+  bool timing_pending = false;
+};
+
+inline size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s->sh.esize; }
+// per-particle scalars (EX, EV, H_flf): float64 for float64 state, float32 otherwise (bf16 state included)
+inline size_t ssize(const mjhmc_sampler* s) { return s->dtype == MJHMC_F64 ? 8 : 4; }
+inline size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_bytes(s); }
+
+
+// device staging buffer of at least `elems` float64 (host layout side of every re-tiling)
+int ensure_stage(mjhmc_sampler* s, size_t elems);
+// device particle-major rows -> s->stage in the reference's (ndims, columns) layout: stage[d*rs + k*cs + off] = row(k)[d],
+// row(k) = dev_idx ? dev_idx[k] : k; copy_out: then copy host_elems doubles of the stage to `host` and synchronise
+int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_idx, int64_t ncols, double* host,
+                  size_t host_elems, int64_t rs, int64_t cs, int64_t off, bool copy_out);

@@ -152,6 +152,9 @@ class DeviceSampler(object):
     def restore(self):
         check(self.lib.mjhmc_restore(self.handle))
 
+    def rollback(self):
+        check(self.lib.mjhmc_rollback(self.handle))
+
     def advance_tick(self, n=1):
         check(self.lib.mjhmc_advance_tick(self.handle, int(n)))
 

@@ -1,18 +1,26 @@
 """Multi-GPU support: particle columns are independent chains (mjhmc/samplers/hmc_state.py works
 column-wise everywhere), so a job shards COLUMNS over ranks -- one process per GPU -- and nothing
-is exchanged on the data path.  What crosses ranks (host-side, tiny, or once per ``sample()``):
+is exchanged on the data path.  What crosses ranks (tiny, or once per ``sample()``):
 
   * the non-finite-rate flag of an attempt (the reference retries the WHOLE batch,
-    markov_jump_hmc.py:376-389) -> min-reduce of "iterations committed", checkpoint + deterministic
+    markov_jump_hmc.py:376-389) -> min-reduce of "iterations committed", rollback + deterministic
     replay on ranks that ran ahead;
   * integer counters (sums);
   * at the end of ``sample()``: the dwell times (to form the global time-major cumsum of
-    markov_jump_hmc.py:321-324) and ONE all-gather of the sample columns (RCCL over xGMI when the
-    process group's backend is nccl; gloo on CPU for tests).
+    markov_jump_hmc.py:321-324) and ONE all-gather of the sample columns.
 
-torch.distributed is plumbing here (process group, collectives); it is imported lazily so the
-single-GPU product path never touches torch.
+Two communicators with the same small interface:
+
+  ``RcclComm``  the product path: the library's own RCCL communicator (``mjhmc_comm_*`` of include/mjhmc_hip.h,
+                librccl loaded with dlopen): the sample all-gather runs device ring -> device ring over xGMI and
+                is re-tiled on the receiving GPU; no torch anywhere.
+  ``Comm``      a torch.distributed shim kept for the CPU tests (gloo, world size 2: tests/test_parallel_gloo.py) and
+                for running two ranks on ONE GPU (RCCL refuses two ranks on one device); host-staged.
 """
+import ctypes
+import os
+import time
+
 import numpy as np
 
 
@@ -20,6 +28,9 @@ class ShardPlan(object):
     """Contiguous column blocks: rank r owns [offset[r], offset[r] + count[r])."""
 
     def __init__(self, n_total, world):
+        if int(n_total) < int(world):
+            raise ValueError('cannot shard %d particle columns over %d ranks: every rank needs at least one'
+                             % (n_total, world))
         base, extra = divmod(int(n_total), int(world))
         self.n_total = int(n_total)
         self.world = int(world)
@@ -34,8 +45,138 @@ class ShardPlan(object):
         return (np.searchsorted(self.offsets, np.asarray(cols), side='right') - 1).astype(np.int64)
 
 
-class Comm(object):
-    """Thin wrapper over a torch.distributed process group (nccl == RCCL on ROCm, or gloo)."""
+class _CommBase(object):
+    on_device = False          # True: sample blocks are gathered ring-to-ring on the GPUs (RcclComm)
+
+    def allreduce_sizes(self, m):
+        v = np.zeros(self.world, dtype=np.int64)
+        v[self.rank] = m
+        return self.allreduce_ints(v, 'sum')
+
+
+class RcclComm(_CommBase):
+    """This rank's end of the library's RCCL communicator.
+
+    Rendezvous: rank 0 draws the 128-byte unique id and publishes it through a file the other ranks wait for
+    (``id_path``; default: a name in the system temp directory built from the launcher's pid and MASTER_PORT, which
+    every rank of one ``torch.distributed.run`` / ``mpirun`` job on a node shares)."""
+
+    on_device = True
+    _created = 0
+
+    def __init__(self, rank=None, world=None, device=None, id_path=None, timeout=300.0):
+        from . import _lib, engine
+        self._lib_mod = _lib
+        rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
+        world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
+        device = int(os.environ.get('LOCAL_RANK', str(rank))) if device is None else int(device)
+        self.rank, self.world, self.backend, self.device = rank, world, 'rccl', device
+        self.ctx = engine.context(device)
+        self.lib = self.ctx.lib
+        if id_path is None:
+            import tempfile
+            id_path = os.path.join(tempfile.gettempdir(), 'mjhmc_comm_%d_%s_%d.id'
+                                   % (os.getppid(), os.environ.get('MASTER_PORT', '0'), RcclComm._created))
+        RcclComm._created += 1
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        if rank == 0:
+            _lib.check(self.lib.mjhmc_comm_unique_id(buf))
+            tmp = '%s.%d.tmp' % (id_path, os.getpid())
+            with open(tmp, 'wb') as f:
+                f.write(buf.raw)
+            os.replace(tmp, id_path)                     # atomic: readers never see a partial id
+        else:
+            t0 = time.time()
+            while not os.path.exists(id_path):
+                if time.time() - t0 > timeout:
+                    raise RuntimeError('rank %d: no communicator id at %s after %.0f s' % (rank, id_path, timeout))
+                time.sleep(0.01)
+            with open(id_path, 'rb') as f:
+                buf.raw = f.read(_lib.COMM_ID_BYTES)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mjhmc_comm_create(self.ctx.handle, rank, world, buf, ctypes.byref(h)))
+        self.handle = h
+        self.barrier()                                   # everyone has read the id: rank 0 may remove the file
+        if rank == 0:
+            try:
+                os.remove(id_path)
+            except OSError:
+                pass
+
+    # -- small host-value collectives ---------------------------------------------------------
+    def allreduce_ints(self, values, op='sum'):
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.int64).ravel()).copy()
+        code = {'sum': self._lib_mod.OP_SUM, 'min': self._lib_mod.OP_MIN, 'max': self._lib_mod.OP_MAX}[op]
+        self._lib_mod.check(self.lib.mjhmc_comm_allreduce_i64(self.handle, self._lib_mod.ptr(v), v.size, code))
+        return v
+
+    def allreduce_f64(self, values, op='sum'):
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel()).copy()
+        code = {'sum': self._lib_mod.OP_SUM, 'min': self._lib_mod.OP_MIN, 'max': self._lib_mod.OP_MAX}[op]
+        self._lib_mod.check(self.lib.mjhmc_comm_allreduce_f64(self.handle, self._lib_mod.ptr(v), v.size, code))
+        return v.reshape(np.shape(values))
+
+    def bcast(self, arr, src=0):
+        v = np.ascontiguousarray(np.asarray(arr, dtype=np.float64)).copy()
+        self._lib_mod.check(self.lib.mjhmc_comm_bcast(self.handle, self._lib_mod.ptr(v), v.nbytes, int(src)))
+        return v
+
+    def allgather_columns(self, block):
+        """block (D, m_r) float64 with rank-dependent m_r -> list of the world's blocks (host values: state reads,
+        dwelling times; the sample blocks take allgather_ring / allgather_picked instead)."""
+        block = np.ascontiguousarray(block, dtype=np.float64)
+        D = block.shape[0]
+        sizes = self.allreduce_sizes(block.shape[1])
+        nbytes = np.ascontiguousarray(sizes * D * 8, dtype=np.int64)
+        out = np.empty(int(sizes.sum()) * D, dtype=np.float64)
+        self._lib_mod.check(self.lib.mjhmc_comm_allgatherv(self.handle, self._lib_mod.ptr(block), self._lib_mod.ptr(nbytes),
+                                                           self._lib_mod.ptr(out)))
+        parts, at = [], 0
+        for r in range(self.world):
+            m = int(sizes[r])
+            parts.append(out[at:at + D * m].reshape(D, m))
+            at += D * m
+        return parts
+
+    def barrier(self):
+        self.allreduce_ints([1], 'sum')
+
+    # -- the data-path collective: sample columns, device ring to device ring --------------------
+    def allgather_ring(self, dev, slot0, n, stacked, counts):
+        """ring slots [slot0, slot0 + n) of every rank's DeviceSampler -> the unsharded sample block,
+        (D, n * N_total) time-major or (D, N_total, n) when ``stacked``."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        total = int(counts.sum())
+        out = np.empty((dev.ndims, total, n) if stacked else (dev.ndims, n * total))
+        self._lib_mod.check(self.lib.mjhmc_comm_allgather_ring(self.handle, dev.handle, int(slot0), int(n), 1 if stacked else 0,
+                                                               self._lib_mod.ptr(counts), self._lib_mod.ptr(out)))
+        return out
+
+    def allgather_picked(self, dev, local_idx, counts):
+        """every rank's picked ring columns (local pool indices), all-gathered: (D, sum counts), rank 0's first."""
+        local_idx = np.ascontiguousarray(local_idx, dtype=np.int64)
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        out = np.empty((dev.ndims, int(counts.sum())))
+        self._lib_mod.check(self.lib.mjhmc_comm_allgather_columns(self.handle, dev.handle, self._lib_mod.ptr(local_idx),
+                                                                  local_idx.size, self._lib_mod.ptr(counts),
+                                                                  self._lib_mod.ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.mjhmc_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm(_CommBase):
+    """torch.distributed shim (gloo on CPU for the tests; two ranks on one GPU): host-staged collectives.
+    torch is imported here and nowhere else in the package."""
 
     def __init__(self, group=None):
         import torch
@@ -57,9 +198,10 @@ class Comm(object):
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t.cpu().numpy()
 
-    def allreduce_f64(self, values):
+    def allreduce_f64(self, values, op='sum'):
         t = self._t(np.asarray(values, dtype=np.float64), self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        ops = {'sum': self.dist.ReduceOp.SUM, 'min': self.dist.ReduceOp.MIN, 'max': self.dist.ReduceOp.MAX}
+        self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t.cpu().numpy()
 
     def bcast(self, arr, src=0):
@@ -81,11 +223,6 @@ class Comm(object):
         self.dist.all_gather(outs, mine, group=self.group)
         return [o.cpu().numpy()[:, :int(sizes[r])] for r, o in enumerate(outs)]
 
-    def allreduce_sizes(self, m):
-        v = np.zeros(self.world, dtype=np.int64)
-        v[self.rank] = m
-        return self.allreduce_ints(v, 'sum')
-
     def barrier(self):
         self.dist.barrier(group=self.group)
 
@@ -106,7 +243,8 @@ def gather_vector(comm, plan, local):
 
 
 def assemble_stacked(comm, plan, local, n, preserve_order):
-    """HMCBase.sample / resample=False (markov_jump_hmc.py:166-173,331-338) from per-rank rings.
+    """HMCBase.sample / resample=False (markov_jump_hmc.py:166-173,331-338) from per-rank host blocks (the
+    host-staged path of the torch shim; RcclComm gathers the device rings instead, see allgather_ring).
     local: (D, N_local, n) if preserve_order else (D, n * N_local) time-major."""
     D = local.shape[0]
     n_loc = int(plan.counts[comm.rank])
@@ -119,12 +257,13 @@ def assemble_stacked(comm, plan, local, n, preserve_order):
     return np.ascontiguousarray(full.transpose(0, 2, 1)).reshape(D, n * plan.n_total)
 
 
-def assemble_resample(comm, plan, n_samples, dwell_local, gather_local, uniforms=None):
+def assemble_resample(comm, plan, n_samples, dwell_local, gather_local, uniforms=None, dev=None):
     """Dwell-time-weighted resampling of ContinuousTimeHMC.sample (markov_jump_hmc.py:309-329) over
     sharded columns.
 
     dwell_local : (n_samples, N_local) dwelling times recorded by this rank
     gather_local: f(local pool indices t * N_local + c) -> (D, m) columns from this rank's sample ring
+                  (host-staged path), or None with ``dev`` = the rank's DeviceSampler when ``comm.on_device``
     uniforms    : the n_samples * N_total numbers of ``np.random.random`` (drawn on rank 0 and broadcast
                   when None), so every rank forms the same indices.
     Returns (resamples (D, n_samples * N_total), global pool indices)."""
@@ -144,10 +283,17 @@ def assemble_resample(comm, plan, n_samples, dwell_local, gather_local, uniforms
     if sample_idx.size and sample_idx[-1] >= dwell_t.size:
         raise IndexError('index 0 is out of bounds for axis 0 with size 0')                    # infinite dwell time
     t_of, col_of = np.divmod(sample_idx, N)
-    mine = np.nonzero((col_of >= lo) & (col_of < lo + n_loc))[0]
-    block = gather_local(t_of[mine] * n_loc + (col_of[mine] - lo))
-    parts = comm.allgather_columns(block)                                                       # the one sample gather
     owner = plan.owner_of(col_of)
+    mine = np.nonzero(owner == comm.rank)[0]
+    local_idx = t_of[mine] * n_loc + (col_of[mine] - lo)
+    if comm.on_device and dev is not None:                                                      # the one sample gather
+        counts = np.bincount(owner, minlength=comm.world).astype(np.int64)
+        flat = comm.allgather_picked(dev, local_idx, counts)       # rank 0's columns, rank 1's, ...
+        out = np.empty_like(flat)
+        out[:, np.argsort(owner, kind='stable')] = flat            # back into sample order
+        return out, sample_idx
+    block = gather_local(local_idx)
+    parts = comm.allgather_columns(block)
     out = np.empty((block.shape[0], sample_idx.size))
     for r, part in enumerate(parts):
         out[:, np.nonzero(owner == r)[0]] = part

@@ -43,8 +43,9 @@ class HMCBase(object):
         self._comm, self._plan = comm, None      # mjhmc_amd.parallel.Comm: shard particle columns over ranks
         self._pending = np.zeros(6, dtype=np.int64)  # local l, f, r, fl, E, dEdX increments not yet reduced
         self._acc_evals = np.zeros(2, dtype=np.int64)   # E / dEdX evaluations of the iteration in flight (retries included)
-        self._iter_evals = []                           # per committed iteration: (E, dEdX) evaluations, local
+        self._iter_evals = []                           # per committed iteration of the CURRENT batch call: (E, dEdX), local
         self._dev = None
+        self._in_retry = False
         if not isinstance(self, ContinuousTimeHMC):
             if not isinstance(distribution, Distribution):
                 raise NotImplementedError(
@@ -93,10 +94,12 @@ class HMCBase(object):
 
     @state.setter
     def state(self, Z):
-        """Assigning an HMCState uploads its X (and V) (figures/poe_fig.py:59)."""
-        self._dev.write(_lib.F_X, Z.X)
+        """Assigning an HMCState uploads its X (and V) (figures/poe_fig.py:59); with sharded columns every rank
+        uploads its own block."""
+        cols = slice(None) if self._plan is None else slice(*self._plan.span(self._comm.rank))
+        self._dev.write(_lib.F_X, np.ascontiguousarray(Z.X[:, cols]))
         if getattr(Z, 'V', None) is not None:
-            self._dev.write(_lib.F_V, Z.V)
+            self._dev.write(_lib.F_V, np.ascontiguousarray(Z.V[:, cols]))
 
     def E(self, X):
         return self.energy_func(X).reshape((1, -1))
@@ -126,9 +129,9 @@ class HMCBase(object):
         self._acc_evals[:] = 0
 
     def eval_trace(self, n_last):
-        """(E_evals, dEdX_evals) per iteration for the last ``n_last`` committed iterations, summed over
-        ranks: the increments of Distribution.E_count / dEdX_count a per-step host loop would observe
-        (mjhmc/misc/autocor.py:246-248)."""
+        """(E_evals, dEdX_evals) per iteration for the last ``n_last`` committed iterations of the most recent
+        batch call (sample / _record / burn_in), summed over ranks: the increments of Distribution.E_count /
+        dEdX_count a per-step host loop would observe (mjhmc/misc/autocor.py:246-248)."""
         tr = np.array(self._iter_evals[-n_last:], dtype=np.int64).reshape(-1, 2)
         if self._comm is not None:
             tr = self._comm.allreduce_ints(tr.ravel(), 'sum').reshape(-1, 2)
@@ -157,30 +160,38 @@ class HMCBase(object):
 
     def _run(self, n_iter, ring_slot0=-1, replay=None):
         """n_iter iterations launched back to back; the host only steps in on a non-finite rate."""
+        if not self._in_retry:
+            self._iter_evals = []                         # the trace describes one batch call, it does not grow for ever
         if replay is not None:                            # recorded random numbers: one attempt at a time
             for i in range(n_iter):
                 self._one(ring_slot0 + i if ring_slot0 >= 0 else -1, replay)
             return
+        # only the jump processes can meet a non-finite rate; the discrete-time samplers never roll back
+        sync = self._comm is not None and self._mode != _lib.MODE_CONTROL
         done = 0
         while done < n_iter:
             self._push_hparams()
             slot = ring_slot0 + done if ring_slot0 >= 0 else -1
-            if self._comm is not None:
-                self._dev.checkpoint()
-            stats, n_done = self._dev.iterate(n_iter - done, ring_slot0=slot)
-            if self._comm is not None:
+            todo = n_iter - done
+            if sync and todo > 1:
+                self._dev.checkpoint()                    # once per batch; a single iteration needs none (rollback)
+            stats, n_done = self._dev.iterate(todo, ring_slot0=slot)
+            if sync:
                 # the reference aborts the WHOLE batch on one bad particle: every rank keeps only the
-                # iterations all ranks committed; a rank that ran ahead restores + replays (bit-identical:
+                # iterations all ranks committed; a rank that ran ahead rolls back + replays (bit-identical:
                 # the RNG is a pure function of (seed, particle id, tick))
                 from ..parallel import agree_on_progress
                 common = agree_on_progress(self._comm, n_done)
                 if common < n_done:
-                    self._dev.restore()
-                    if common:
-                        redo, again = self._dev.iterate(common, ring_slot0=slot)
-                        assert again == common
-                    self._dev.advance_tick(1)             # the failed attempt's tick, consumed everywhere
-                failed_somewhere = common < n_iter - done
+                    if todo == 1:
+                        self._dev.rollback()              # ping-pong inputs are intact; the tick stays consumed
+                    else:
+                        self._dev.restore()
+                        if common:
+                            redo, again = self._dev.iterate(common, ring_slot0=slot)
+                            assert again == common
+                        self._dev.advance_tick(1)         # the failed attempt's tick, consumed everywhere
+                failed_somewhere = common < todo
                 n_done = common
             else:
                 failed_somewhere = len(stats) > n_done
@@ -206,9 +217,13 @@ class HMCBase(object):
         if self._comm is not None:
             self._run(1)
         else:
+            self._iter_evals = []
             self._one(-1, replay)
 
     def _stack(self, n_samples, preserve_order):
+        if self._comm is not None and self._comm.on_device:
+            # the one data-path collective: device rings all-gathered over RCCL, re-tiled on the receiving GPU
+            return self._comm.allgather_ring(self._dev, 0, n_samples, bool(preserve_order), self._plan.counts)
         local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order))
         if self._comm is None:
             return local
@@ -322,7 +337,8 @@ class ContinuousTimeHMC(HMCBase):
             if self._comm is not None:
                 from ..parallel import assemble_resample
                 out, self._last_resample_idx = assemble_resample(
-                    self._comm, self._plan, n_samples, self._dev.ring_read_dwell(0, n_samples), self._dev.ring_gather)
+                    self._comm, self._plan, n_samples, self._dev.ring_read_dwell(0, n_samples), self._dev.ring_gather,
+                    dev=self._dev)
                 return out
             dwell_t = self._dev.ring_read_dwell(0, n_samples).reshape(-1)   # time-major, as np.concatenate
             total_t = np.sum(dwell_t)
@@ -356,9 +372,13 @@ class MarkovJumpHMC(ContinuousTimeHMC):
         if depth > MAX_RETRY_DEPTH:
             raise RuntimeError('non-finite transition rates persist after %d halvings' % MAX_RETRY_DEPTH)
         self._dev.reset_flf_cache()
-        if self._comm is not None:
-            self._run(1, ring_slot)
-        else:
-            self._one(ring_slot, replay)
+        nested, self._in_retry = self._in_retry, True
+        try:
+            if self._comm is not None:
+                self._run(1, ring_slot)
+            else:
+                self._one(ring_slot, replay)
+        finally:
+            self._in_retry = nested
         self.epsilon *= 2
         self.num_leapfrog_steps = int(self.num_leapfrog_steps / 2)

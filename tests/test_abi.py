@@ -34,7 +34,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_abi_version_and_no_device_error(lib):
-    assert lib.mjhmc_abi_version() == 1
+    assert lib.mjhmc_abi_version() == 2
     import torch
     if torch.cuda.device_count() == 0:
         h = ctypes.c_void_p()

@@ -63,6 +63,44 @@ for name, cls, X, kw in (('mjhmc', MarkovJumpHMC, X0, {}), ('mjhmc-stack', Marko
         s.state.X, s.state.EX                          # collectives are SPMD: mirror rank 0's gathers
     comm.barrier()
 
+# ProductOfT keeps dE/dX as part of the state: a rank that ran ahead of a failure elsewhere must get it back too.
+# Huge initial momenta on rank 1's columns only: the leapfrog energy error there exceeds log(DBL_MAX) at the
+# nominal step size (a non-finite rate) and shrinks as the retry halves it.
+from mjhmc_amd.misc.distributions import ProductOfT
+rs2 = np.random.RandomState(8)
+Dp, Np = 36, 120
+sp = rs2.rand(Dp, Dp); Wp = rs2.randn(Dp, Dp); Wp[sp > 0.05] = 0; Wp += np.eye(Dp)
+lognu = np.log(rs2.rand(Dp) * 2 + 2.1)
+Xp = rs2.randn(Dp, Np)
+Vp = rs2.randn(Dp, Np)
+Vp[:, 100:] *= 3000.0
+
+
+def run_pot(comm):
+    class FixedT(ProductOfT):
+        def init_X(self):
+            self.Xinit = Xp
+    d = FixedT(ndims=Dp, nbasis=Dp, nbatch=Np, lognu=lognu, W=Wp)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        s = MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.3, num_leapfrog_steps=6, seed=99, comm=comm,
+                          resample=False, Vinit=Vp)
+        out = s.sample(6)
+    return s, d, out, buf.getvalue().count('doubling back')
+
+
+s, d, out, nretry = run_pot(comm)
+if comm.rank == 0:
+    s1, d1, out1, nretry1 = run_pot(None)
+    assert nretry1 > 0, 'the ProductOfT case no longer provokes a retry'
+    assert nretry == nretry1 and np.array_equal(out, out1), ('pot', nretry, nretry1)
+    assert (s.l_count, s.f_count, s.r_count) == (s1.l_count, s1.f_count, s1.r_count)
+    assert (d.E_count, d.dEdX_count) == (d1.E_count, d1.dEdX_count)
+    assert np.array_equal(s.state.X, s1.state.X) and np.array_equal(s.state.V, s1.state.V)
+else:
+    s.state.X, s.state.V
+comm.barrier()
+
 # autocorrelation of a sharded run: every rank transforms its own columns, the lag sums are added
 from mjhmc_amd.misc.autocor import calculate_autocorrelation
 akw = dict(epsilon=0.3, beta=0.3, num_leapfrog_steps=5, seed=4242, resample=False)
@@ -97,8 +135,52 @@ def test_two_ranks_on_one_gpu_match_unsharded(tmp_path):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-4000:])
 
 
+def test_rccl_communicator_entry_points(tmp_path):
+    """The library's own RCCL communicator (mjhmc_comm_*, include/mjhmc_hip.h) with one rank -- RCCL refuses two ranks
+    on one device, and the box has one -- through every entry point: the host-value collectives, and the device-ring
+    all-gathers behind sample() on all three output paths, which must reproduce the communicator-free run bit for bit."""
+    import numpy as np
+    from mjhmc_amd.parallel import RcclComm, ShardPlan
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC, ControlHMC
+    from mjhmc_amd.misc.distributions import TestGaussian, SparseImageCode
+    comm = RcclComm(0, 1, device=0, id_path=str(tmp_path / 'comm.id'))
+    assert comm.world == 1 and comm.on_device and comm.backend == 'rccl'
+    assert comm.allreduce_ints([3, -4], 'sum').tolist() == [3, -4] and comm.allreduce_ints([7], 'min').tolist() == [7]
+    assert comm.allreduce_f64(np.array([1.5, 2.5]), 'max').tolist() == [1.5, 2.5]
+    assert np.array_equal(comm.bcast(np.arange(5.0)), np.arange(5.0))
+    blk = np.random.RandomState(0).randn(3, 7)
+    parts = comm.allgather_columns(blk)
+    assert len(parts) == 1 and np.array_equal(parts[0], blk)
+    comm.barrier()
+
+    for cls, kw, po in ((MarkovJumpHMC, {}, False), (MarkovJumpHMC, dict(resample=False), False),
+                        (MarkovJumpHMC, dict(resample=False), True), (ControlHMC, {}, True)):
+        outs = []
+        for c in (comm, None):
+            np.random.seed(1)
+            d = TestGaussian(ndims=24, nbatch=301, sigma=1.3)
+            s = cls(distribution=d, epsilon=0.3, beta=0.3, num_leapfrog_steps=5, seed=4242, comm=c, **kw)
+            np.random.seed(2)
+            outs.append((s.sample(7, preserve_order=po), s.l_count, s.f_count, s.r_count, d.E_count, d.dEdX_count,
+                         s.state.X))
+        a, b = outs
+        assert a[0].shape == b[0].shape and np.array_equal(a[0], b[0]), (cls.__name__, kw, po)
+        assert a[1:6] == b[1:6] and np.array_equal(a[6], b[6])
+    # a bf16 ring goes through the same gather (rows are 2 KB of bfloat16)
+    from tests.helpers import sic_problem, to_bf16
+    B, imgs, a0 = sic_problem(0)
+    X0 = to_bf16(a0[:, None] + 0.1 * np.random.RandomState(3).randn(1024, 40))
+    outs = []
+    for c in (comm, None):
+        d = SparseImageCode(n_patches=1, n_batches=40, n_basis=1024, basis=B, imgs=imgs, init=X0)
+        s = MarkovJumpHMC(distribution=d, epsilon=0.05, beta=0.2, num_leapfrog_steps=4, seed=6, comm=c, resample=False)
+        outs.append(s.sample(3))
+    assert np.array_equal(outs[0], outs[1])
+    comm.close()
+
+
 def test_single_rank_nccl_group(tmp_path):
-    """world_size 1 over nccl (RCCL): the collective plumbing the multi-GPU bench uses."""
+    """world_size 1 over nccl (RCCL) through the torch.distributed shim (kept for the gloo tests)."""
     code = r'''
 import os, sys
 import numpy as np
