@@ -439,7 +439,8 @@ static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout,
   a.V = (const __bf16*)V;
   a.V_gen = (__bf16*)Vgen;
   a.N = s->N;
-  a.ntiles = s->Npad / 32;
+  const int ppt = sic_particles_per_tile(s->en->sic_P);
+  a.ntiles = (s->N + ppt - 1) / ppt;
   a.first_pid = s->first_pid;
   a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), 0u, 0u};
   sic_launch_eval(a, s->en->sic_model(), s->stream);
@@ -591,11 +592,12 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         break;
       }
       const int P = (int)params[0], I = (int)params[1], C = (int)params[2];
-      if (P != 1 || I != kSicImg || C != kSicCoeffs || ndims != P * C) {
+      if (P < 1 || P > 32 || I != kSicImg || C != kSicCoeffs || ndims != P * C) {
         rc = fail(MJHMC_ERR_UNSUPPORTED,
-                  "SPARSE_CODE device kernel is built for n_patches=1, img_size=256, n_coeffs=1024 (BASELINE config 5)");
+                  "SPARSE_CODE device kernel is built for img_size=256, n_coeffs=1024, 1 <= n_patches <= 32");
         break;
       }
+      e->sic_P = P;
       if (nparams != (size_t)5 + (size_t)I * C + (size_t)P * I) {
         rc = fail(MJHMC_ERR_INVALID, "SPARSE_CODE parameter vector has the wrong length");
         break;
@@ -629,10 +631,10 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
               const int i = 32 * ws + 16 * sx + 8 * (j >> 2) + 4 * h + (j & 3);
               a2[(((size_t)ks * 2 + h) * C + c) * 8 + j] = bf16_of(B[(size_t)i * C + c]);
             }
-      std::vector<float> yv(I);
-      for (int i = 0; i < I; ++i) yv[i] = (float)Y[i];
+      std::vector<float> yv((size_t)P * I);
+      for (size_t i = 0; i < yv.size(); ++i) yv[i] = (float)Y[i];
       const void* src[3] = {a1.data(), a2.data(), yv.data()};
-      const size_t bytes[3] = {a1.size() * 2, a2.size() * 2, (size_t)I * 4};
+      const size_t bytes[3] = {a1.size() * 2, a2.size() * 2, yv.size() * 4};
       for (int i = 0; i < 3 && !rc; ++i) {
         if (hipMalloc(&e->sic[i], bytes[i]) != hipSuccess ||
             hipMemcpy(e->sic[i], src[i], bytes[i], hipMemcpyHostToDevice) != hipSuccess)
@@ -706,17 +708,13 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   s->seed = seed;
   int rc = 0;
   if (e->is_pot()) {
-    if (dtype != MJHMC_F32 || mode != MJHMC_MODE_MJHMC) {
+    if (dtype != MJHMC_F32) {
       delete s;
-      return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs in float32, MJHMC mode (the reference evaluates it in float32)");
+      return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs in float32 (the reference evaluates it in float32)");
     }
     s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   } else if (e->is_sic()) {
-    if (mode != MJHMC_MODE_MJHMC) {
-      delete s;
-      return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE runs in MJHMC mode");
-    }
-    s->sh = Shape{0, 0, kSicCoeffs, kSicCoeffs / 8, 2};
+    s->sh = Shape{0, 0, s->D, s->D / 8, 2};  // a particle row = n_patches x 1024 bfloat16
   } else {
     rc = pick_shape(s->D, dtype, &s->sh);
   }
@@ -1166,6 +1164,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.trans = a.trans;
         pa.noise = a.noise;
         pa.rexp = a.rexp;
+        pa.runif = a.runif;
+        pa.mode = a.mode;
+        pa.p_flip = a.p_flip;
         pa.ctl = a.ctl;
         pa.stats = a.stats;
         pa.N = a.N;
@@ -1204,11 +1205,15 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         sa.trans = a.trans;
         sa.noise = (const __bf16*)a.noise;
         sa.rexp = a.rexp;
+        sa.runif = a.runif;
+        sa.mode = a.mode;
+        sa.p_flip = a.p_flip;
         sa.ctl = a.ctl;
         sa.stats = a.stats;
         sa.N = a.N;
         sa.Npad = a.Npad;
-        sa.ntiles = a.Npad / 32;
+        const int ppt = sic_particles_per_tile(s->en->sic_P);
+        sa.ntiles = (a.N + ppt - 1) / ppt;
         sa.first_pid = a.first_pid;
         sa.L = a.L;
         sa.iter = a.iter;
@@ -1375,7 +1380,7 @@ int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
       if (field == MJHMC_F_DEDX && s->en->is_pot()) {
         src = s->Gbuf[s->vcur];
       } else if (field == MJHMC_F_DEDX && s->en->is_sic()) {
-        if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, (size_t)s->Npad * kSicCoeffs * sizeof(float)));
+        if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, (size_t)s->Npad * s->D * sizeof(float)));
         TRY(run_eval(s, s->Xcur, s->scratch, nullptr, nullptr, nullptr, nullptr));
         s->download_f32 = true;
         const int rc = download_cols(s, s->scratch, nullptr, s->N, (double*)host_dst, mat, s->N, 1, 0, true);
@@ -1616,7 +1621,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
     if (dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T evaluates in float32");
     w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   } else if (e->is_sic()) {
-    w.sh = Shape{0, 0, kSicCoeffs, kSicCoeffs / 8, 2};
+    w.sh = Shape{0, 0, w.D, w.D / 8, 2};
   } else {
     TRY(pick_shape(w.D, dtype, &w.sh));
   }
@@ -1626,7 +1631,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
     const size_t mb = mat_bytes(&w);
     HIPCHK(hipMalloc(&Xd, mb));
     HIPCHK(hipMemsetAsync(Xd, 0, mb, w.stream));
-    if (dEdX_out) HIPCHK(hipMalloc(&Gd, e->is_sic() ? (size_t)w.Npad * kSicCoeffs * sizeof(float) : mb));
+    if (dEdX_out) HIPCHK(hipMalloc(&Gd, e->is_sic() ? (size_t)w.Npad * w.D * sizeof(float) : mb));
     if (E_out) HIPCHK(hipMalloc(&Ed, w.Npad * ssize(&w)));
     TRY(upload_matrix(&w, X, Xd));
     TRY(run_eval(&w, Xd, Gd, Ed, nullptr, nullptr, nullptr));
@@ -1648,9 +1653,10 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
 int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V, int64_t n, double eps, int n_steps,
                    double* X_out, double* V_out, double* EX_out, double* EV_out, double* dEdX_out) {
   if (!e || !X || !V || !X_out || !V_out || n < 1 || n_steps < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
-  if (dtype != MJHMC_F64 && dtype != MJHMC_F32) return fail(MJHMC_ERR_INVALID, "dtype must be F64 or F32");
-  if (e->is_dense())
-    return fail(MJHMC_ERR_UNSUPPORTED, "the stand-alone leapfrog operator exists for the elementwise energies");
+  if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
+    return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
+  if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
+  if (e->is_pot() && dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T integrates in float32");
   HIPCHK(hipSetDevice(e->ctx->device));
   mjhmc_sampler w;
   w.ctx = e->ctx;
@@ -1660,26 +1666,70 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
   w.first_pid = 0;
   w.D = e->ep.ndims;
   w.dtype = dtype;
-  TRY(pick_shape(w.D, dtype, &w.sh));
+  if (e->is_pot()) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
+  else if (e->is_sic()) w.sh = Shape{0, 0, w.D, w.D / 8, 2};
+  else TRY(pick_shape(w.D, dtype, &w.sh));
   void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // X, V, X', V', G, EX, EV
   auto body = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     const size_t mb = mat_bytes(&w), vb = (size_t)w.Npad * ssize(&w);
+    const size_t gb = e->is_sic() ? (size_t)w.Npad * w.D * sizeof(float) : mb;  // SPARSE_CODE hands dE/dX out in float32
     for (int i = 0; i < 5; ++i) {
       if (i == 4 && !dEdX_out) continue;
-      HIPCHK(hipMalloc(&buf[i], mb));
-      HIPCHK(hipMemsetAsync(buf[i], 0, mb, w.stream));
+      HIPCHK(hipMalloc(&buf[i], i == 4 ? gb : mb));
+      HIPCHK(hipMemsetAsync(buf[i], 0, i == 4 ? gb : mb, w.stream));
     }
     if (EX_out) HIPCHK(hipMalloc(&buf[5], vb));
     if (EV_out) HIPCHK(hipMalloc(&buf[6], vb));
     TRY(upload_matrix(&w, X, buf[0]));
     TRY(upload_matrix(&w, V, buf[1]));
-    if (dtype == MJHMC_F64) TRY(leap_t<double>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
-    else TRY(leap_t<float>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
+    if (e->is_pot()) {
+      PotLeapArgs a;
+      a.X = (const float*)buf[0];
+      a.V = (const float*)buf[1];
+      a.X_out = (float*)buf[2];
+      a.V_out = (float*)buf[3];
+      a.G = (float*)buf[4];
+      a.EX = (float*)buf[5];
+      a.EV = (float*)buf[6];
+      a.N = n;
+      a.ntiles = w.Npad / 32;
+      a.D = w.D;
+      a.L = n_steps;
+      a.eps = (float)eps;
+      a.chalf = (float)(-eps / 2.);
+      pot_launch_leap(a, e->pot_model(), w.stream);
+      HIPCHK(hipGetLastError());
+    } else if (e->is_sic()) {
+      SicLeapArgs a;
+      a.X = (const __bf16*)buf[0];
+      a.V = (const __bf16*)buf[1];
+      a.X_out = (__bf16*)buf[2];
+      a.V_out = (__bf16*)buf[3];
+      a.G = (float*)buf[4];
+      a.EX = (float*)buf[5];
+      a.EV = (float*)buf[6];
+      a.N = n;
+      const int ppt = sic_particles_per_tile(e->sic_P);
+      a.ntiles = (n + ppt - 1) / ppt;
+      a.L = n_steps;
+      a.eps = (float)eps;
+      a.chalf = (float)(-eps / 2.);
+      sic_launch_leap(a, e->sic_model(), w.stream);
+      HIPCHK(hipGetLastError());
+    } else if (dtype == MJHMC_F64) {
+      TRY(leap_t<double>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
+    } else {
+      TRY(leap_t<float>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
+    }
     const size_t total = (size_t)w.D * n;
     TRY(download_cols(&w, buf[2], nullptr, n, X_out, total, n, 1, 0, true));
     TRY(download_cols(&w, buf[3], nullptr, n, V_out, total, n, 1, 0, true));
-    if (dEdX_out) TRY(download_cols(&w, buf[4], nullptr, n, dEdX_out, total, n, 1, 0, true));
+    if (dEdX_out) {
+      w.download_f32 = e->is_sic();
+      TRY(download_cols(&w, buf[4], nullptr, n, dEdX_out, total, n, 1, 0, true));
+      w.download_f32 = false;
+    }
     if (EX_out) TRY(read_vec(&w, buf[5], EX_out, (size_t)n * sizeof(double)));
     if (EV_out) TRY(read_vec(&w, buf[6], EV_out, (size_t)n * sizeof(double)));
     HIPCHK(hipStreamSynchronize(w.stream));

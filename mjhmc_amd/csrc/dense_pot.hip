@@ -430,14 +430,17 @@ __global__ __launch_bounds__(256, 1) void pot_flf_kernel(const PotJumpArgs a, co
 }
 
 // ---------------------------------------------------------------------------------------------------
-// the jump kernel (MJHMC mode): one sampling_iteration attempt for a tile of 32 particles
+// the jump kernel: one sampling_iteration attempt for a tile of 32 particles.
+// MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (ContinuousTimeHMC, :251-290) or kModeControl (HMCBase /
+// HMC / ControlHMC, :116-148 -- the comparison arm of the reference's ProductOfT experiments,
+// search/control_poe_36/mjhmc_objective.py:14).
 // ---------------------------------------------------------------------------------------------------
-template <int NB, bool REPLAY>
+template <int NB, bool REPLAY, int MODE>
 __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, const PotModel mdl) {
   __shared__ Shared<NB> sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  unsigned nL = 0, nF = 0, nR = 0;
+  unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
     const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
     const float H0 = EX0 + EV0;
     // H of the inverse-L proposal: cached, or integrated by pot_flf_kernel for the cold particles
-    const float Hflf = a.Hwork[p];
+    const float Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.f;
     Tile<NB> x, v, g;
     tile_load<NB>(a.X_in, p, w, h, x);
     tile_load<NB>(a.V_in, p, w, h, v);
@@ -457,48 +460,83 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
     const float EVL = pot_kinetic<NB>(sh, w, c, h, v);
     const float HL = EXL + EVL;
 
-    // rates, waiting times, first minimum: lanes 0..31 of wave 0, one particle each
+    // rates / acceptance, waiting times, first minimum: lanes 0..31 of wave 0, one particle each
     if (w == 0 && h == 0) {
       const uint32_t pid = (uint32_t)(a.first_pid + (alive ? p : 0));
-      double best;
-      bool bad;
-      const int k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
+      double best = 0.0;
+      bool bad = false, gate = false;
+      int k;
+      if constexpr (MODE == kModeMJHMC)
+        k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
+      else if constexpr (MODE == kModeCT)
+        k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
+      else
+        k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, alive ? p : 0, a.N, a.runif, a.key, gate);
       any_bad |= (bad && alive);
-      sh.move[c] = k;
+      sh.move[c] = k | (gate ? 4 : 0);
       a.dwell[p] = best;
       a.dwell_ring[p] = best;
       a.trans[p] = (uint8_t)k;
       if (alive) {
-        nL += (k == 0);
-        nF += (k == 1);
-        nR += (k == 2);
+        if constexpr (MODE == kModeControl) {  // l_count, f_count, R applied, fl_count (markov_jump_hmc.py:143-148)
+          n0 += (k == 3);
+          n1 += (k == 2);
+          n2 += gate ? 1u : 0u;
+          n3 += (k == 1);
+        } else {
+          n0 += (k == 0);
+          n1 += (k == 1);
+          n2 += (k == 2);
+        }
       }
-      // scalars of the L and F successors; R's kinetic energy is filled in below
-      a.EX_out[p] = (k == 0) ? EXL : EX0;
-      a.EV_out[p] = (k == 0) ? EVL : EV0;
-      a.Hflf_out[p] = (k == 0) ? H0 : __builtin_nanf("");
+      // scalars of the successors that keep or take whole states; a refreshed kinetic energy is filled in below
+      const bool took_L = MODE == kModeControl ? (k & 1) : (k == 0);
+      a.EX_out[p] = took_L ? EXL : EX0;
+      a.EV_out[p] = took_L ? EVL : EV0;
+      a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nanf("");
     }
     __syncthreads();
-    const int k = sh.move[c];
-    const bool tile_has_r = __ballot(k == 2) != 0ull;
-    if (k != 0) {  // F / R keep the position (and its gradient)
-      tile_load<NB>(a.X_in, p, w, h, x);
-      tile_load<NB>(a.G_in, p, w, h, g);
-      tile_load<NB>(a.V_in, p, w, h, v);
-      if (k == 1) {
+    const int mv = sh.move[c];
+    const int k = mv & 3;
+    bool refresh;  // this column's momentum is redrawn (HMCState.R)
+    if constexpr (MODE == kModeControl) {
+      if (!(k & 1)) {  // rejected: back to the pre-move state
+        tile_load<NB>(a.X_in, p, w, h, x);
+        tile_load<NB>(a.G_in, p, w, h, g);
+        tile_load<NB>(a.V_in, p, w, h, v);
+      } else {  // accepted L F: flip
 #pragma unroll
         for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
-      } else {  // HMCState.R (hmc_state.py:121-129)
-        Tile<NB> z;
-        if constexpr (REPLAY) tile_load<NB>(a.noise, alive ? p : 0, w, h, z);
-        else pot_normals<NB>(a.key, (uint32_t)(a.first_pid + (alive ? p : 0)), w, h, a.D, z);
-#pragma unroll
-        for (int r = 0; r < NB; ++r) v.b[r] = v.b[r] * a.r_keep + z.b[r] * a.r_mix;
       }
+      if (k & 2) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
+      }
+      refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
+    } else {
+      const bool keep_L = (k == 0);
+      if (!keep_L) {  // F / R keep the position (and its gradient)
+        tile_load<NB>(a.X_in, p, w, h, x);
+        tile_load<NB>(a.G_in, p, w, h, g);
+        tile_load<NB>(a.V_in, p, w, h, v);
+      }
+      if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
+#pragma unroll
+        for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
+      }
+      refresh = (k == 2);
     }
-    if (tile_has_r) {  // all waves take part in the reduction; only R columns use the result
+    const bool tile_refreshes = __ballot(refresh) != 0ull;
+    if (refresh) {  // HMCState.R (hmc_state.py:121-129)
+      Tile<NB> z;
+      if constexpr (REPLAY) tile_load<NB>(a.noise, alive ? p : 0, w, h, z);
+      else pot_normals<NB>(a.key, (uint32_t)(a.first_pid + (alive ? p : 0)), w, h, a.D, z);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) v.b[r] = v.b[r] * a.r_keep + z.b[r] * a.r_mix;
+    }
+    if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result
       const float evr = pot_kinetic<NB>(sh, w, c, h, v);
-      if (k == 2 && w == 0 && h == 0) a.EV_out[p] = evr;
+      if (refresh && w == 0 && h == 0) a.EV_out[p] = evr;
     }
     tile_store<NB>(a.X_out, p, w, h, x);
     tile_store<NB>(a.V_out, p, w, h, v);
@@ -509,14 +547,46 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
     a.ctl->failed = 1;
     a.ctl->failed_iter = a.iter;
   }
-  __shared__ unsigned tally[3];
-  if (threadIdx.x < 3) tally[threadIdx.x] = 0;
+  __shared__ unsigned tally[4];
+  if (threadIdx.x < 4) tally[threadIdx.x] = 0;
   __syncthreads();
-  if (nL) atomicAdd(&tally[0], nL);
-  if (nF) atomicAdd(&tally[1], nF);
-  if (nR) atomicAdd(&tally[2], nR);
+  if (n0) atomicAdd(&tally[0], n0);
+  if (n1) atomicAdd(&tally[1], n1);
+  if (n2) atomicAdd(&tally[2], n2);
+  if (n3) atomicAdd(&tally[3], n3);
   __syncthreads();
-  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+  if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100; figures/poe_fig.py:59 assigns and
+// integrates states of a ProductOfT sampler): dE/dX at the start point, L steps, energies of the end point.
+// ---------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256, 1) void pot_leap_kernel(const PotLeapArgs a, const PotModel mdl) {
+  __shared__ Shared<NB> sh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  AReg<NB> ar;
+  areg_load<NB>(mdl, w, c, h, ar);
+  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t p = tile * kP + c;
+    Tile<NB> x, v, g;
+    tile_load<NB>(a.X, p, w, h, x);
+    tile_load<NB>(a.V, p, w, h, v);
+    float ex = 0.f;
+    pot_gradient<NB>(mdl, ar, sh, w, c, h, lane, x, g, true, &ex);
+    __syncthreads();
+    pot_trajectory<NB>(mdl, ar, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &ex);
+    const float ev = pot_kinetic<NB>(sh, w, c, h, v);
+    tile_store<NB>(a.X_out, p, w, h, x);
+    tile_store<NB>(a.V_out, p, w, h, v);
+    if (a.G) tile_store<NB>(a.G, p, w, h, g);
+    if (w == 0 && h == 0) {
+      if (a.EX) a.EX[p] = ex;
+      if (a.EV) a.EV[p] = ev;
+    }
+    __syncthreads();
+  }
 }
 
 static int resident_cus() {
@@ -526,21 +596,40 @@ static int resident_cus() {
   return std::max(1, cus);
 }
 
+template <int NB, int MODE>
+static void launch_jump_mode(const PotJumpArgs& a, const PotModel& mdl, unsigned grid, hipStream_t st) {
+  const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);
+  if (replay) hipLaunchKernelGGL((pot_jump_kernel<NB, true, MODE>), dim3(grid), dim3(256), 0, st, a, mdl);
+  else hipLaunchKernelGGL((pot_jump_kernel<NB, false, MODE>), dim3(grid), dim3(256), 0, st, a, mdl);
+}
+
 template <int NB>
 static void launch_jump_nb(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
-  (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-  hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
-                     a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus());
-  hipLaunchKernelGGL(pot_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
-  if (a.rexp && a.noise) hipLaunchKernelGGL((pot_jump_kernel<NB, true>), dim3(grid), dim3(256), 0, st, a, mdl);
-  else hipLaunchKernelGGL((pot_jump_kernel<NB, false>), dim3(grid), dim3(256), 0, st, a, mdl);
+  if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
+    (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
+    hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
+                       a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+    hipLaunchKernelGGL(pot_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
+    launch_jump_mode<NB, kModeMJHMC>(a, mdl, grid, st);
+  } else if (a.mode == kModeCT) {
+    launch_jump_mode<NB, kModeCT>(a, mdl, grid, st);
+  } else {
+    launch_jump_mode<NB, kModeControl>(a, mdl, grid, st);
+  }
 }
 
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
   if (mdl.dim == 128) launch_jump_nb<1>(a, mdl, st);
   else if (mdl.dim == 256) launch_jump_nb<2>(a, mdl, st);
   else launch_jump_nb<4>(a, mdl, st);
+}
+
+void pot_launch_leap(const PotLeapArgs& a, const PotModel& mdl, hipStream_t st) {
+  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus());
+  if (mdl.dim == 128) hipLaunchKernelGGL(pot_leap_kernel<1>, dim3(grid), dim3(256), 0, st, a, mdl);
+  else if (mdl.dim == 256) hipLaunchKernelGGL(pot_leap_kernel<2>, dim3(grid), dim3(256), 0, st, a, mdl);
+  else hipLaunchKernelGGL(pot_leap_kernel<4>, dim3(grid), dim3(256), 0, st, a, mdl);
 }
 
 void pot_launch_eval(const PotEvalArgs& a, const PotModel& mdl, hipStream_t st) {

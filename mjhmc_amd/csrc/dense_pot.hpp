@@ -40,13 +40,29 @@ struct PotJumpArgs {
   uint8_t* trans;
   const float* noise;   // replay normals [N][512] or nullptr
   const double* rexp;   // replay unit exponentials [3][N] or nullptr
+  const double* runif;  // replay uniforms of the discrete-time samplers [2N+1] (accept, flip, R gate) or nullptr
   Control* ctl;
   unsigned long long* stats;
   int64_t N, Npad, ntiles, first_pid;
   int D, L, iter;
+  int mode;             // kModeMJHMC / kModeControl / kModeCT
   float eps, chalf, r_keep, r_mix;
-  double p_r;
+  double p_r, p_flip;
   RngKey key;
+};
+
+// stand-alone leapfrog operator on caller-supplied states (HMCState.leapfrog / L, hmc_state.py:86-100)
+struct PotLeapArgs {
+  const float* X;
+  const float* V;
+  float* X_out;
+  float* V_out;
+  float* G;        // dE/dX at the end point, or nullptr
+  float* EX;       // [n] or nullptr
+  float* EV;
+  int64_t N, ntiles;
+  int D, L;
+  float eps, chalf;
 };
 
 struct PotEvalArgs {
@@ -102,6 +118,69 @@ __device__ __forceinline__ int dense_decide(float H0, float HL, float Hflf, doub
   return k;
 }
 
+// ContinuousTimeHMC (markov_jump_hmc.py:251-290): clocks FL (rate sqrt(exp(H0 - H_fl))), F (rate 1), R (rate p_r);
+// min_idx is called with [f, fl, r], so ties go F, FL, R.  Returns k: 0 = FL, 1 = F, 2 = R.
+template <bool REPLAY>
+__device__ __forceinline__ int dense_decide_ct(float H0, float HL, double p_r, uint32_t pid, int64_t p, int64_t N,
+                                               const double* rexp, const RngKey& key, double& dwell, bool& bad) {
+  const double fl_rate = sqrt(exp((double)(H0 - HL)));
+  const double r_rate = p_r;
+  double eFL, eF, eR;
+  if constexpr (REPLAY) {
+    eFL = rexp[p];
+    eF = rexp[N + p];
+    eR = rexp[2 * N + p];
+  } else {
+    const u32x4 wq = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpLF, key.k0, key.k1);
+    const u32x4 qq = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
+    eFL = -log(u53(wq.w0, wq.w1));
+    eF = -log(u53(wq.w2, wq.w3));
+    eR = -log(u53(qq.w0, qq.w1));
+  }
+  bad = !(isfinite(fl_rate) && isfinite(r_rate));
+  const double dFL = fl_rate == 0.0 ? __builtin_huge_val() : (1.0 / fl_rate) * eFL;
+  const double dF = eF;  // rate 1
+  const double dR = r_rate == 0.0 ? __builtin_huge_val() : (1.0 / r_rate) * eR;
+  int kk = 0;  // rows f, fl, r (markov_jump_hmc.py:271)
+  double best = dF;
+  if (!(best != best) && (dFL < best || dFL != dFL)) {
+    kk = 1;
+    best = dFL;
+  }
+  if (!(best != best) && (dR < best || dR != dR)) {
+    kk = 2;
+    best = dR;
+  }
+  dwell = best;
+  return kk == 0 ? 1 : (kk == 1 ? 0 : 2);
+}
+
+// Discrete-time control samplers (markov_jump_hmc.py:116-148): accept the L F proposal with min(1, exp(H0 - H1)) (a NaN
+// difference accepts, as `Ediff < 0` is False, :112-113), flip with probability p_flip; `gate`: the batch-wide
+// momentum refresh fires this iteration.  Returns k = accepted | flipped << 1.
+template <bool REPLAY>
+__device__ __forceinline__ int dense_control(float H0, float HL, double p_r, double p_flip, uint32_t pid, int64_t p,
+                                             int64_t N, const double* runif, const RngKey& key, bool& gate) {
+  double uacc, uflip, ugate;
+  if constexpr (REPLAY) {
+    uacc = runif[p];
+    uflip = runif[N + p];
+    ugate = runif[2 * N];
+  } else {
+    const u32x4 q = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotExpR, key.k0, key.k1);
+    const u32x4 f = philox4x32_10(pid, key.tick_lo, key.tick_hi, kSlotFlip, key.k0, key.k1);
+    const u32x4 g = philox4x32_10(0xFFFFFFFFu, key.tick_lo, key.tick_hi, kSlotFlip, key.k0, key.k1);
+    uacc = u53(q.w2, q.w3);
+    uflip = u53(f.w0, f.w1);
+    ugate = u53(g.w2, g.w3);
+  }
+  const double dH = (double)(H0 - HL);
+  const bool accept = !(dH < 0.0) || (uacc < exp(dH));
+  const bool flip = uflip < p_flip;
+  gate = ugate < p_r;
+  return (accept ? 1 : 0) | (flip ? 2 : 0);
+}
+
 // float32 Box-Muller pair from the same Philox words as normal_pair (the float64 version costs ~4x
 // the instructions; for float32 / bfloat16 state its extra digits are rounded away anyway)
 __device__ __forceinline__ void normal_pair_f32(const RngKey& k, uint32_t pid, uint32_t pair, float& z0, float& z1) {
@@ -117,5 +196,6 @@ __device__ __forceinline__ void normal_pair_f32(const RngKey& k, uint32_t pid, u
 
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_eval(const PotEvalArgs& a, const PotModel& mdl, hipStream_t st);
+void pot_launch_leap(const PotLeapArgs& a, const PotModel& mdl, hipStream_t st);
 
 }  // namespace mjhmc

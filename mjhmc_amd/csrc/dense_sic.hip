@@ -1,12 +1,17 @@
 // SparseImageCode (sparse-coding posterior over coefficients, mjhmc/misc/tf_distributions.py:204-272) on
 // the bf16 matrix cores: bf16 state in HBM, bf16 MFMA operands, fp32 accumulation and fp32 integrator
-// registers (BASELINE.json configs[4]).  Built for one patch per particle (n_patches = 1), n_coeffs = 1024,
-// img_size = 256:
+// registers (BASELINE.json configs[4]).  n_coeffs = 1024, img_size = 256, P = n_patches patches per particle (the
+// reference's default is 9, tf_distributions.py:208; BASELINE configs[4] is one):
 //
-//   resid = B a - y ,  E = 1/2 |resid|^2 + lambda * sum log(1 + a^2)            (Cauchy prior, :262-267)
-//   dE/da = B^T resid + lambda * 2a / (1 + a^2)                                 (or lambda * sign(a), Laplace)
+//   resid_p = B a_p - y_p ,  E = mean_p 1/2 |resid_p|^2 + lambda * sum log(1 + a^2)   (Cauchy prior, :259-267)
+//   dE/da_p = B^T resid_p / P + lambda * 2a / (1 + a^2)                               (or lambda * sign(a), Laplace)
 //
-// One workgroup = 8 waves (two per SIMD) owns a tile of 32 particles.  Wave w holds coefficient rows
+// A particle's state row is its P coefficient vectors back to back (patch-major, :249 for one active column), i.e.
+// P consecutive 1024-rows of the (N * P, 1024) matrix: every (particle, patch) pair is a COLUMN of the two GEMMs, and
+// only the energy sums and the jump decision couple the P columns of a particle.  A tile is 32 columns holding
+// floor(32 / P) whole particles (P = 9: 27 of the 32 columns work).
+//
+// One workgroup = 8 waves (two per SIMD) owns a tile of 32 columns.  Wave w holds coefficient rows
 // [128w, 128w+128) of X and V as fp32 MFMA accumulator tiles (4 blocks of 32 rows) and image rows
 // [32w, 32w+32) of the residual (1 block).  v_mfma_f32_32x32x16_bf16 throughout:
 //   GEMM1  resid[i][n] = sum_c B[i][c] a[c][n] - y[i]     64 k-steps x 1 block  per wave
@@ -70,7 +75,38 @@ struct SicShared {
   f32x4 pubA[8][4][2][64];  // 64 KB: a as B fragments, [wave][block][k-step half][lane]
   f32x4 pubR[8][2][64];     // 16 KB: scaled residual as B fragments
   float red[2][8][kP];
+  float colsum[kP];         // per-column energies, summed over a particle's columns when n_patches > 1
   int move[kP];
+};
+
+// what column c of a tile works on
+struct Col {
+  int64_t part;  // particle (clamped to a valid one when the column idles)
+  int64_t q;     // row of the (N * P, 1024) coefficient matrix: part * P + patch
+  int patch;
+  int g0;        // first column of this particle's group
+  bool alive;    // the column holds a real (particle, patch) pair: its results are stored
+  bool leader;   // first column of a live particle: writes the per-particle scalars and tallies
+};
+
+// slot = index of the column's particle among the tile's particles; `part_of(slot)` resolves it (identity for the jump
+// kernel, a lookup in the cold list for the inverse-L pass)
+template <class PartOf>
+__device__ __forceinline__ Col col_of(int64_t tile, int c, int P, int64_t n_parts, const PartOf& part_of) {
+  const int ppt = kP / P, cpt = ppt * P;
+  const int cc = c < cpt ? c : cpt - 1;
+  const int64_t slot = tile * ppt + cc / P;
+  Col k;
+  k.alive = (c < cpt) && slot < n_parts;
+  k.part = part_of(slot < n_parts ? slot : n_parts - 1);
+  k.patch = cc % P;
+  k.q = k.part * P + k.patch;
+  k.g0 = (cc / P) * P;
+  k.leader = k.alive && k.patch == 0;
+  return k;
+}
+struct Identity {
+  __device__ int64_t operator()(int64_t s) const { return s; }
 };
 
 __device__ __forceinline__ f32x4 frag_of(const f32x16& acc, int s, float scale) {
@@ -81,7 +117,7 @@ __device__ __forceinline__ f32x4 frag_of(const f32x16& acc, int s, float scale) 
 }
 
 // residual of the tile at the X held in x (GEMM1).  Leaves it in `res` (fp32 accumulator layout).
-__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane,
+__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane, int patch,
                                              const CTile& x, f32x16& res) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
@@ -90,7 +126,7 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
   }
   __syncthreads();
   {  // res starts at -y[i]
-    const float* yv = mdl.y + 32 * w + 4 * h;
+    const float* yv = mdl.y + kI * patch + 32 * w + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(yv + 8 * g);
@@ -136,8 +172,8 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
 template <bool CAUCHY>
 __device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane,
                                          const f32x16& res, const CTile& x, float scale, CTile& acc) {
-  sh.pubR[w][0][lane] = frag_of(res, 0, scale);
-  sh.pubR[w][1][lane] = frag_of(res, 1, scale);
+  sh.pubR[w][0][lane] = frag_of(res, 0, scale * mdl.invP);  // d/da_p of the MEAN over patches
+  sh.pubR[w][1][lane] = frag_of(res, 1, scale * mdl.invP);
   __syncthreads();
   const f32x4* a2 = reinterpret_cast<const f32x4*>(mdl.A2) + (size_t)h * kC + 128 * w + c;
 #pragma unroll 1
@@ -172,10 +208,21 @@ __device__ __forceinline__ float half_swap_sum(float s) {
   return __int_as_float(sw[0]) + __int_as_float(sw[1]);
 }
 
-// E(x) per particle from the residual at x:  1/2 |res|^2 + lambda * prior(x)
+// sum of a per-column value over the columns of the caller's particle (n_patches of them, consecutive)
+__device__ __forceinline__ float group_total(SicShared& sh, int w, int c, int h, int P, int g0, float col_tot) {
+  if (P == 1) return col_tot;
+  if (w == 0 && h == 0) sh.colsum[c] = col_tot;
+  __syncthreads();
+  float t = 0.f;
+  for (int j = 0; j < P; ++j) t += sh.colsum[g0 + j];
+  __syncthreads();
+  return t;
+}
+
+// E(x) per PARTICLE from the residuals at x:  mean_p 1/2 |res_p|^2 + lambda * prior(x)  (tf_distributions.py:257-270)
 template <bool CAUCHY>
-__device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, int w, int c, int h, const f32x16& res,
-                                            const CTile& x) {
+__device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, int w, int c, int h, const Col& col,
+                                            const f32x16& res, const CTile& x) {
   float s = 0.f;
 #pragma unroll
   for (int q = 0; q < 16; ++q) s += 0.5f * res[q] * res[q];
@@ -187,17 +234,18 @@ __device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, 
       const float a = x.b[b][q];
       pr += CAUCHY ? logf(1.0f + a * a) : fabsf(a);
     }
-  const float part = half_swap_sum(s + mdl.lambda * pr);
+  const float part = half_swap_sum(s * mdl.invP + mdl.lambda * pr);
   if (h == 0) sh.red[0][w][c] = part;
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) tot += sh.red[0][k][c];
   __syncthreads();
-  return tot;
+  return group_total(sh, w, c, h, mdl.P, col.g0, tot);
 }
 
-__device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h, const CTile& v) {
+// sum(v^2) / 2 per PARTICLE
+__device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h, int P, const Col& col, const CTile& v) {
   float s = 0.f;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -210,21 +258,21 @@ __device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h,
 #pragma unroll
   for (int k = 0; k < 8; ++k) tot += sh.red[1][k][c];
   __syncthreads();
-  return tot / 2.0f;
+  return group_total(sh, w, c, h, P, col.g0, tot) / 2.0f;
 }
 
 // L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
-// separate roundings meaningless).  Returns E(x_new); x, v updated in place.
+// separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place.
 template <bool CAUCHY>
 __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane,
-                                                CTile& x, CTile& v, int L, float eps, float chalf) {
+                                                const Col& col, CTile& x, CTile& v, int L, float eps, float chalf) {
   f32x16 res;
-  sic_residual(mdl, sh, w, c, h, lane, x, res);
-  sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, chalf, v);
+  sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
+  if (L > 0) sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, chalf, v);
   for (int s = 1; s <= L; ++s) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) x.b[b] = x.b[b] + eps * v.b[b];
-    sic_residual(mdl, sh, w, c, h, lane, x, res);
+    sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
     sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, s < L ? 2.0f * chalf : chalf, v);
   }
   // the successor position is stored in bf16 (and GEMM1 already saw bf16(x)): evaluate the prior on
@@ -233,7 +281,39 @@ __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& 
   for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int q = 0; q < 16; ++q) x.b[b][q] = (float)(__bf16)x.b[b][q];
-  return sic_energy<CAUCHY>(mdl, sh, w, c, h, res, x);
+  return sic_energy<CAUCHY>(mdl, sh, w, c, h, col, res, x);
+}
+
+__device__ __forceinline__ void round_to_state(CTile& t) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.b[b][q] = (float)(__bf16)t.b[b][q];
+}
+
+// v += mix * (standard normals of this lane's dims of particle `pid`; dims patch * 1024 + ...), group by group: one
+// Box-Muller quadruple's temporaries at a time keeps this rare branch from dictating the kernel's register budget
+__device__ __forceinline__ void sic_add_normals(const RngKey& key, uint32_t pid, int patch, int w, int h, float mix,
+                                                CTile& v) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll 1
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = kC * patch + 128 * w + 32 * b + 8 * g4 + 4 * h;
+      float z0, z1, z2, z3;
+      normal_pair_f32(key, pid, (uint32_t)(d >> 1), z0, z1);
+      normal_pair_f32(key, pid, (uint32_t)((d >> 1) + 1), z2, z3);
+      f32x4 add;
+      add[0] = z0 * mix;
+      add[1] = z1 * mix;
+      add[2] = z2 * mix;
+      add[3] = z3 * mix;
+      // g4 is a runtime index here: address the four registers through selects
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if ((q >> 2) == g4) v.b[b][q] += add[q & 3];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -242,11 +322,11 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
   __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int64_t p = tile * kP + c;
+    const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
     CTile x;
-    ctile_load(a.X, p, w, h, x);
+    ctile_load(a.X, col.q, w, h, x);
     f32x16 res;
-    sic_residual(mdl, sh, w, c, h, lane, x, res);
+    sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
     if (a.G) {
       CTile g;
 #pragma unroll
@@ -254,42 +334,36 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
 #pragma unroll
         for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
       sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, 1.0f, g);
-      float* row = a.G + (size_t)p * kC + 128 * w + 4 * h;  // dE/dX is handed out in float32
+      if (col.alive) {
+        float* row = a.G + (size_t)col.q * kC + 128 * w + 4 * h;  // dE/dX is handed out in float32
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          f32x4 o;
+          for (int gq = 0; gq < 4; ++gq) {
+            f32x4 o;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = g.b[b][4 * gq + k];
-          *reinterpret_cast<f32x4*>(row + 32 * b + 8 * gq) = o;
-        }
+            for (int k = 0; k < 4; ++k) o[k] = g.b[b][4 * gq + k];
+            *reinterpret_cast<f32x4*>(row + 32 * b + 8 * gq) = o;
+          }
+      }
     }
-    const float ex = sic_energy<CAUCHY>(mdl, sh, w, c, h, res, x);
-    if (a.E && w == 0 && h == 0) a.E[p] = ex;
+    const float ex = sic_energy<CAUCHY>(mdl, sh, w, c, h, col, res, x);
+    if (a.E && w == 0 && h == 0 && col.leader) a.E[col.part] = ex;
     if (a.EV) {
       CTile v;
       if (a.V_gen) {
-        const uint32_t pid = (uint32_t)(a.first_pid + (p < a.N ? p : 0));
-#pragma unroll 1
-        for (int gq = 0; gq < 16; ++gq) {
-          const int b = gq >> 2, g4 = gq & 3;
-          const int d = 128 * w + 32 * b + 8 * g4 + 4 * h;
-          float z0, z1, z2, z3;
-          normal_pair_f32(a.key, pid, (uint32_t)(d >> 1), z0, z1);
-          normal_pair_f32(a.key, pid, (uint32_t)((d >> 1) + 1), z2, z3);
-          // round to the state dtype so EV matches the stored momentum
-          v.b[b][4 * g4 + 0] = (float)(__bf16)z0;
-          v.b[b][4 * g4 + 1] = (float)(__bf16)z1;
-          v.b[b][4 * g4 + 2] = (float)(__bf16)z2;
-          v.b[b][4 * g4 + 3] = (float)(__bf16)z3;
-        }
-        ctile_store(a.V_gen, p, w, h, v);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v.b[b][q] = 0.f;
+        sic_add_normals(a.key, (uint32_t)(a.first_pid + col.part), col.patch, w, h, 1.0f, v);
+        round_to_state(v);  // EV matches the stored momentum
+        if (col.alive) ctile_store(a.V_gen, col.q, w, h, v);
       } else {
-        ctile_load(a.V, p, w, h, v);
+        ctile_load(a.V, col.q, w, h, v);
       }
-      const float ev = sic_kinetic(sh, w, c, h, v);
-      if (w == 0 && h == 0) a.EV[p] = ev;
+      const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
+      if (w == 0 && h == 0 && col.leader) a.EV[col.part] = ev;
     }
   }
 }
@@ -315,140 +389,202 @@ __global__ void sic_cold_list_kernel(const float* __restrict__ Hflf_in, float* _
   if (cold) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)p;
 }
 
+struct FromList {
+  const int* list;
+  __device__ int64_t operator()(int64_t s) const { return list[s]; }
+};
+
 template <bool CAUCHY>
 __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, const SicModel mdl) {
   __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
-  for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
-    const int slot = tile * kP + c;
-    const int64_t p = a.cold_list[slot < ncold ? slot : ncold - 1];
+  const int ppt = kP / mdl.P;
+  for (int64_t tile = blockIdx.x; tile * ppt < ncold; tile += gridDim.x) {
+    const Col col = col_of(tile, c, mdl.P, (int64_t)ncold, FromList{a.cold_list});  // the last tile repeats an entry
     CTile x, v;
-    ctile_load(a.X_in, p, w, h, x);
-    ctile_load(a.V_in, p, w, h, v);
+    ctile_load(a.X_in, col.q, w, h, x);
+    ctile_load(a.V_in, col.q, w, h, v);
 #pragma unroll
     for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
-    const float ex = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, x, v, a.L, a.eps, a.chalf);
-    const float ev = sic_kinetic(sh, w, c, h, v);
-    if (w == 0 && h == 0) a.Hwork[p] = ex + ev;
+    const float ex = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    round_to_state(v);  // the same rounding the jump kernel applies to the forward proposal
+    const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
+    if (w == 0 && h == 0 && col.leader) a.Hwork[col.part] = ex + ev;
     __syncthreads();
   }
 }
 
-template <bool CAUCHY, bool REPLAY>
+// MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
+// the reference's sparse-coding experiments, search/control_sp_img/control_objective.py:10)
+template <bool CAUCHY, bool REPLAY, int MODE>
 __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, const SicModel mdl) {
   __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  unsigned nL = 0, nF = 0, nR = 0;
+  unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int64_t p = tile * kP + c;
-    const bool alive = p < a.N;
+    const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
+    const int64_t p = col.part;
     const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
     const float H0 = EX0 + EV0;
-    const float Hflf = a.Hwork[p];
+    const float Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.f;
     CTile x, v;
-    ctile_load(a.X_in, p, w, h, x);
-    ctile_load(a.V_in, p, w, h, v);
-    const float EXL = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, x, v, a.L, a.eps, a.chalf);
-    // the successor state is stored in bf16: report the kinetic energy of what is stored
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v.b[b][q] = (float)(__bf16)v.b[b][q];
-    const float EVL = sic_kinetic(sh, w, c, h, v);
+    ctile_load(a.X_in, col.q, w, h, x);
+    ctile_load(a.V_in, col.q, w, h, v);
+    const float EXL = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
+    const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
-    if (w == 0 && h == 0) {
-      const uint32_t pid = (uint32_t)(a.first_pid + (alive ? p : 0));
-      double best;
-      bool bad;
-      const int k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
-      any_bad |= (bad && alive);
-      sh.move[c] = k;
-      a.dwell[p] = best;
-      a.dwell_ring[p] = best;
-      a.trans[p] = (uint8_t)k;
-      if (alive) {
-        nL += (k == 0);
-        nF += (k == 1);
-        nR += (k == 2);
+    if (w == 0 && h == 0) {  // every column of a particle reaches the same decision; its leader reports it
+      const uint32_t pid = (uint32_t)(a.first_pid + p);
+      double best = 0.0;
+      bool bad = false, gate = false;
+      int k;
+      if constexpr (MODE == kModeMJHMC) k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
+      else if constexpr (MODE == kModeCT) k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
+      else k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, p, a.N, a.runif, a.key, gate);
+      sh.move[c] = k | (gate ? 4 : 0);
+      if (col.leader) {
+        any_bad |= bad;
+        a.dwell[p] = best;
+        a.dwell_ring[p] = best;
+        a.trans[p] = (uint8_t)k;
+        if constexpr (MODE == kModeControl) {  // l_count, f_count, R applied, fl_count (markov_jump_hmc.py:143-148)
+          n0 += (k == 3);
+          n1 += (k == 2);
+          n2 += gate ? 1u : 0u;
+          n3 += (k == 1);
+        } else {
+          n0 += (k == 0);
+          n1 += (k == 1);
+          n2 += (k == 2);
+        }
+        const bool took_L = MODE == kModeControl ? (k & 1) : (k == 0);
+        a.EX_out[p] = took_L ? EXL : EX0;
+        a.EV_out[p] = took_L ? EVL : EV0;
+        a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nanf("");
       }
-      a.EX_out[p] = (k == 0) ? EXL : EX0;
-      a.EV_out[p] = (k == 0) ? EVL : EV0;
-      a.Hflf_out[p] = (k == 0) ? H0 : __builtin_nanf("");
     }
     __syncthreads();
-    const int k = sh.move[c];
-    const bool tile_has_r = __ballot(k == 2) != 0ull;
-    if (k != 0) {  // F / R keep the position
-      ctile_load(a.X_in, p, w, h, x);
-      ctile_load(a.V_in, p, w, h, v);
-      if (k == 1) {
+    const int mv = sh.move[c];
+    const int k = mv & 3;
+    bool refresh;  // this column's momentum is redrawn (HMCState.R)
+    if constexpr (MODE == kModeControl) {
+      if (!(k & 1)) {  // rejected: back to the pre-move state
+        ctile_load(a.X_in, col.q, w, h, x);
+        ctile_load(a.V_in, col.q, w, h, v);
+      } else {  // accepted L F: flip
 #pragma unroll
         for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
-      } else {  // HMCState.R (hmc_state.py:121-129), group by group to keep the register budget
-        const uint32_t pid = (uint32_t)(a.first_pid + (alive ? p : 0));
+      }
+      if (k & 2) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v.b[b] = v.b[b] * a.r_keep;
-        if constexpr (REPLAY) {
-          const __bf16* zrow = a.noise + (size_t)(alive ? p : 0) * kC + 128 * w + 4 * h;
+        for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
+      }
+      refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
+    } else {
+      if (k != 0) {  // F / R keep the position
+        ctile_load(a.X_in, col.q, w, h, x);
+        ctile_load(a.V_in, col.q, w, h, v);
+      }
+      if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
+      }
+      refresh = (k == 2);
+    }
+    const bool tile_refreshes = __ballot(refresh) != 0ull;
+    if (refresh) {  // HMCState.R (hmc_state.py:121-129)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const bf16x4 z = *reinterpret_cast<const bf16x4*>(zrow + 32 * b + 8 * g4);
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk) v.b[b][4 * g4 + kk] += (float)z[kk] * a.r_mix;
-            }
-        } else {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-#pragma unroll 1
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const int d = 128 * w + 32 * b + 8 * g4 + 4 * h;
-              float z0, z1, z2, z3;
-              normal_pair_f32(a.key, pid, (uint32_t)(d >> 1), z0, z1);
-              normal_pair_f32(a.key, pid, (uint32_t)((d >> 1) + 1), z2, z3);
-              f32x4 add;
-              add[0] = z0 * a.r_mix;
-              add[1] = z1 * a.r_mix;
-              add[2] = z2 * a.r_mix;
-              add[3] = z3 * a.r_mix;
-              // g4 is a runtime index here: address the four registers through selects
-#pragma unroll
-              for (int q = 0; q < 16; ++q)
-                if ((q >> 2) == g4) v.b[b][q] += add[q & 3];
-            }
-          }
-        }
+      for (int b = 0; b < 4; ++b) v.b[b] = v.b[b] * a.r_keep;
+      if constexpr (REPLAY) {
+        const __bf16* zrow = a.noise + (size_t)col.q * kC + 128 * w + 4 * h;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) v.b[b][q] = (float)(__bf16)v.b[b][q];
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const bf16x4 z = *reinterpret_cast<const bf16x4*>(zrow + 32 * b + 8 * g4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v.b[b][4 * g4 + kk] += (float)z[kk] * a.r_mix;
+          }
+      } else {
+        sic_add_normals(a.key, (uint32_t)(a.first_pid + p), col.patch, w, h, a.r_mix, v);
       }
+      round_to_state(v);
     }
-    if (tile_has_r) {
-      const float evr = sic_kinetic(sh, w, c, h, v);
-      if (k == 2 && w == 0 && h == 0) a.EV_out[p] = evr;
+    if (tile_refreshes) {
+      const float evr = sic_kinetic(sh, w, c, h, mdl.P, col, v);
+      if (refresh && w == 0 && h == 0 && col.leader) a.EV_out[p] = evr;
     }
-    ctile_store(a.X_out, p, w, h, x);
-    ctile_store(a.V_out, p, w, h, v);
+    if (col.alive) {
+      ctile_store(a.X_out, col.q, w, h, x);
+      ctile_store(a.V_out, col.q, w, h, v);
+    }
     __syncthreads();
   }
   if (any_bad) {
     a.ctl->failed = 1;
     a.ctl->failed_iter = a.iter;
   }
-  __shared__ unsigned tally[3];
-  if (threadIdx.x < 3) tally[threadIdx.x] = 0;
+  __shared__ unsigned tally[4];
+  if (threadIdx.x < 4) tally[threadIdx.x] = 0;
   __syncthreads();
-  if (nL) atomicAdd(&tally[0], nL);
-  if (nF) atomicAdd(&tally[1], nF);
-  if (nR) atomicAdd(&tally[2], nR);
+  if (n0) atomicAdd(&tally[0], n0);
+  if (n1) atomicAdd(&tally[1], n1);
+  if (n2) atomicAdd(&tally[2], n2);
+  if (n3) atomicAdd(&tally[3], n3);
   __syncthreads();
-  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+  if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
+// HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
+template <bool CAUCHY>
+__global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, const SicModel mdl) {
+  __shared__ SicShared sh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
+    CTile x, v;
+    ctile_load(a.X, col.q, w, h, x);
+    ctile_load(a.V, col.q, w, h, v);
+    const float ex = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    round_to_state(v);
+    const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
+    if (a.G) {  // dE/dX of the stored end point
+      f32x16 res;
+      sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
+      CTile g;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
+      sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, 1.0f, g);
+      if (col.alive) {
+        float* row = a.G + (size_t)col.q * kC + 128 * w + 4 * h;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = g.b[b][4 * gq + k];
+            *reinterpret_cast<f32x4*>(row + 32 * b + 8 * gq) = o;
+          }
+      }
+    }
+    if (col.alive) {
+      ctile_store(a.X_out, col.q, w, h, x);
+      ctile_store(a.V_out, col.q, w, h, v);
+    }
+    if (w == 0 && h == 0 && col.leader) {
+      if (a.EX) a.EX[col.part] = ex;
+      if (a.EV) a.EV[col.part] = ev;
+    }
+    __syncthreads();
+  }
 }
 
 static int sic_cus() {
@@ -458,27 +594,44 @@ static int sic_cus() {
   return std::max(1, cus);
 }
 
-void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-  (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-  hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
-                     a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+template <bool CAUCHY, int MODE>
+static void sic_launch_mode(const SicJumpArgs& a, const SicModel& mdl, unsigned grid, hipStream_t st) {
+  const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);
+  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE>), dim3(grid), dim3(512), 0, st, a, mdl);
+  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE>), dim3(grid), dim3(512), 0, st, a, mdl);
+}
+
+template <bool CAUCHY>
+static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-  const bool replay = a.rexp && a.noise;
-  if (mdl.cauchy) {
-    hipLaunchKernelGGL(sic_flf_kernel<true>, dim3(grid), dim3(512), 0, st, a, mdl);
-    if (replay) hipLaunchKernelGGL((sic_jump_kernel<true, true>), dim3(grid), dim3(512), 0, st, a, mdl);
-    else hipLaunchKernelGGL((sic_jump_kernel<true, false>), dim3(grid), dim3(512), 0, st, a, mdl);
+  if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
+    (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
+    hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
+                       a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+    hipLaunchKernelGGL(sic_flf_kernel<CAUCHY>, dim3(grid), dim3(512), 0, st, a, mdl);
+    sic_launch_mode<CAUCHY, kModeMJHMC>(a, mdl, grid, st);
+  } else if (a.mode == kModeCT) {
+    sic_launch_mode<CAUCHY, kModeCT>(a, mdl, grid, st);
   } else {
-    hipLaunchKernelGGL(sic_flf_kernel<false>, dim3(grid), dim3(512), 0, st, a, mdl);
-    if (replay) hipLaunchKernelGGL((sic_jump_kernel<false, true>), dim3(grid), dim3(512), 0, st, a, mdl);
-    else hipLaunchKernelGGL((sic_jump_kernel<false, false>), dim3(grid), dim3(512), 0, st, a, mdl);
+    sic_launch_mode<CAUCHY, kModeControl>(a, mdl, grid, st);
   }
+}
+
+void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
+  if (mdl.cauchy) sic_launch_jump_t<true>(a, mdl, st);
+  else sic_launch_jump_t<false>(a, mdl, st);
 }
 
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
   if (mdl.cauchy) hipLaunchKernelGGL(sic_eval_kernel<true>, dim3(grid), dim3(512), 0, st, a, mdl);
   else hipLaunchKernelGGL(sic_eval_kernel<false>, dim3(grid), dim3(512), 0, st, a, mdl);
+}
+
+void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st) {
+  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
+  if (mdl.cauchy) hipLaunchKernelGGL(sic_leap_kernel<true>, dim3(grid), dim3(512), 0, st, a, mdl);
+  else hipLaunchKernelGGL(sic_leap_kernel<false>, dim3(grid), dim3(512), 0, st, a, mdl);
 }
 
 }  // namespace mjhmc

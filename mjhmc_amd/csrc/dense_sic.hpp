@@ -13,9 +13,11 @@ constexpr int kSicImg = 256;      // img_size
 struct SicModel {
   const void* A1;   // bf16 [64 k-steps][2 halves][256 image rows][8]: B[i][c] in GEMM1's fragment k-order
   const void* A2;   // bf16 [16 k-steps][2 halves][1024 coeffs][8]:    B[i][c] in GEMM2's fragment k-order
-  const float* y;   // [256] the patch
+  const float* y;   // [n_patches][256] the patches
   float lambda;
   int cauchy;
+  int P;            // n_patches: a particle is P consecutive 1024-coefficient rows, one per patch (tf_distributions.py:228-229)
+  float invP;       // the reconstruction error is the MEAN over patches (tf_distributions.py:259-260)
 };
 
 struct SicJumpArgs {
@@ -37,13 +39,29 @@ struct SicJumpArgs {
   uint8_t* trans;
   const __bf16* noise;
   const double* rexp;
+  const double* runif;  // replay uniforms of the discrete-time samplers [2N+1] or nullptr
   Control* ctl;
   unsigned long long* stats;
   int64_t N, Npad, ntiles, first_pid;
   int L, iter;
+  int mode;             // kModeMJHMC / kModeControl / kModeCT
   float eps, chalf, r_keep, r_mix;
-  double p_r;
+  double p_r, p_flip;
   RngKey key;
+};
+
+// stand-alone leapfrog operator on caller-supplied states (HMCState.leapfrog / L, hmc_state.py:86-100)
+struct SicLeapArgs {
+  const __bf16* X;
+  const __bf16* V;
+  __bf16* X_out;
+  __bf16* V_out;
+  float* G;        // float32 dE/dX at the end point [n][P * 1024], or nullptr
+  float* EX;
+  float* EV;
+  int64_t N, ntiles;
+  int L;
+  float eps, chalf;
 };
 
 struct SicEvalArgs {
@@ -59,5 +77,8 @@ struct SicEvalArgs {
 
 void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st);
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st);
+void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st);
+// particles per 32-column tile: a tile holds whole particles (P columns each)
+inline int sic_particles_per_tile(int P) { return 32 / P; }
 
 }  // namespace mjhmc

@@ -46,10 +46,13 @@ struct mjhmc_energy {
   int pot_dim = kPotDim;  // rows padded to 128, 256 or 512
   PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim, ep.ndims}; }
   bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
-  void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32)
+  void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32 [P][256])
   float sic_lambda = 0.f;
   int sic_cauchy = 1;
-  SicModel sic_model() const { return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy}; }
+  int sic_P = 1;  // n_patches
+  SicModel sic_model() const {
+    return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy, sic_P, 1.0f / (float)sic_P};
+  }
   bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
   bool is_dense() const { return is_pot() || is_sic(); }
 };

@@ -160,3 +160,39 @@ def check_iteration(s, o, delta_rel, x_tol, e_rtol, tag='', cols=None):
     # ill-conditioned near flf == l and is covered by the transition check instead)
     assert np.allclose(s.dwelling_times[sel][keep], o.dwelling_times[keep], rtol=max(1e-3, 4 * delta_rel * scale)), (tag, 'dwell')
     return int(diff.sum())
+
+
+def check_control_iteration(s, o, delta_rel, x_tol, e_rtol, tag=''):
+    """One HMCBase / HMC / ControlHMC sampling_iteration (markov_jump_hmc.py:116-148) on the device sampler and on the
+    oracle from identical inputs.  Flips and the batch-wide refresh involve no energies and must be equal; an
+    accept decision may differ only where the acceptance test `u < exp(H0 - H1)` is within the kernel's energy
+    error of a tie.  Returns the number of such near ties."""
+    en = o.energy
+    counts = (en.E_count, en.dEdX_count)
+    H0 = o.state.H()[0].copy()
+    HL = o.state.clone().L().H()[0].copy()
+    en.E_count, en.dEdX_count = counts
+    uacc = np.asarray(o.rng.stream.accept_uniforms(o.rng.tick), dtype=np.float64)
+    n = H0.shape[0]
+    r_before = o.r_count
+    s.sampling_iteration()
+    o.sampling_iteration()
+    tr = s._dev.read(8)
+    acc_o = np.isin(np.arange(n), o.last_fl_idx)
+    flip_o = np.isin(np.arange(n), o.last_flip_idx)
+    assert np.array_equal(((tr >> 1) & 1).astype(bool), flip_o), (tag, 'flips')
+    diff = (tr & 1).astype(bool) != acc_o
+    scale = max(1.0, float(np.abs(H0).max()))
+    with np.errstate(all='ignore'):
+        margin = np.abs((H0 - HL) - np.log(uacc))
+    assert (margin[diff] <= delta_rel * scale).all(), (tag, 'accept decisions off by more than the energy error',
+                                                       margin[diff], delta_rel * scale)
+    assert (s.r_count > 0) == (o.r_count > 0) and (o.r_count - r_before) in (0, n), (tag, 'refresh gate')
+    same = ~diff
+    xs = max(1.0, float(np.abs(o.state.X).max()))
+    assert np.abs(s.state.X[:, same] - o.state.X[:, same]).max() <= x_tol * xs, (tag, 'X')
+    assert np.abs(s.state.V[:, same] - o.state.V[:, same]).max() <= x_tol * max(1.0, float(np.abs(o.state.V).max())), (tag, 'V')
+    eEX = np.abs(s.state.EX[0, same] - o.state.EX[0, same]).max() / scale
+    eEV = np.abs(s.state.EV[0, same] - o.state.EV[0, same]).max() / scale
+    assert eEX <= e_rtol and eEV <= e_rtol, (tag, 'EX, EV errors / max|H|', eEX, eEV, 'allowed', e_rtol)
+    return int(diff.sum())

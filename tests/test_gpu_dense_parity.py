@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 
 from oracle import mjhmc_oracle as orc
-from tests.helpers import load, ref_init_weights, sic_problem, to_bf16, resync as _resync, check_iteration
+from tests.helpers import (load, ref_init_weights, sic_problem, to_bf16, resync as _resync, check_iteration,
+                           check_control_iteration)
 
 pytestmark = pytest.mark.gpu
 np.seterr(all='ignore')
@@ -172,6 +173,148 @@ def test_sic_iterations_from_the_reference_states():
                           rng=orc.PhiloxRNG(23, np.arange(N)), state_rounding=to_bf16)
     _resync(s, o)
     for t in range(5):
-        check_iteration(s, o, delta_rel=1e-4, x_tol=1.0 / 128, e_rtol=1e-4, tag='sic it %d' % t)
+        check_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='sic it %d' % t)
         assert s.l_count + s.f_count + s.r_count == (t + 1) * N
         _resync(s, o)
+
+
+# ---------------------------------------------------------------------------------------------
+# the comparison arms of the reference's ProductOfT and sparse-coding experiments (search/control_poe_36/
+# mjhmc_objective.py:14, search/control_sp_img/control_objective.py:10) and the other sampler families on the
+# matrix-core kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cls_name,D,N', [('ControlHMC', 36, 70), ('HMC', 36, 40), ('HMCBase', 200, 33), ('ControlHMC', 512, 40)])
+def test_pot_discrete_time_samplers_vs_oracle(cls_name, D, N):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    X0 = np.random.RandomState(D + N).randn(D, N)
+    d, W, lognu = _pot(D, N, None, X0)
+    en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
+    kw = dict(epsilon=0.1, beta=0.6, num_leapfrog_steps=5)
+    s = getattr(M, cls_name)(distribution=d, seed=41, **kw)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(41, np.arange(N)),
+                               state_rounding=lambda a: a.astype(np.float32).astype(np.float64), **kw)
+    assert (s.beta, s.p_r, s.p_flip) == (o.beta, o.p_r, o.p_flip)
+    _resync(s, o)
+    ties = 0
+    for t in range(6):
+        ties += check_control_iteration(s, o, delta_rel=2e-5, x_tol=2e-5, e_rtol=2e-5, tag='%s pot it %d' % (cls_name, t))
+        if ties == 0:
+            assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count)
+            assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
+        _resync(s, o)
+    assert ties <= 1
+    assert s.r_count > 0 or cls_name != 'ControlHMC'
+
+
+def test_pot_continuous_time_sampler_vs_oracle():
+    from mjhmc_amd.samplers.markov_jump_hmc import ContinuousTimeHMC
+    D, N = 36, 60
+    X0 = np.random.RandomState(5).randn(D, N)
+    d, W, lognu = _pot(D, N, None, X0)
+    en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
+    kw = dict(epsilon=0.1, beta=0.3, num_leapfrog_steps=5, resample=False)
+    s = ContinuousTimeHMC(distribution=d, seed=43, **kw)
+    o = orc.ContinuousTimeHMC(en, X0, rng=orc.PhiloxRNG(43, np.arange(N)),
+                              state_rounding=lambda a: a.astype(np.float32).astype(np.float64), **kw)
+    _resync(s, o)
+    for t in range(5):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        # the F clock has rate 1 and R rate p_r: only the FL clock sees energies; with 60 particles a near tie is not expected
+        assert (s.fl_count, s.f_count, s.r_count) == (o.fl_count, o.f_count, o.r_count), t
+        assert np.abs(s.state.X - o.state.X).max() <= 2e-5 * max(1.0, np.abs(o.state.X).max())
+        assert np.allclose(s.dwelling_times, o.dwelling_times, rtol=1e-3)
+        _resync(s, o)
+
+
+@pytest.mark.parametrize('cls_name', ['ControlHMC', 'HMC'])
+def test_sic_discrete_time_samplers_vs_oracle(cls_name):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    N = 40
+    B, imgs, a0 = sic_problem(0)
+    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(2).randn(1024, N))
+    d, B, imgs = _sic(1, N, True, X0)
+    en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+    kw = dict(epsilon=0.0625, beta=0.6, num_leapfrog_steps=6)
+    s = getattr(M, cls_name)(distribution=d, seed=47, **kw)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(47, np.arange(N)), state_rounding=to_bf16, **kw)
+    _resync(s, o)
+    ties = 0
+    for t in range(5):
+        ties += check_control_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='%s sic it %d' % (cls_name, t))
+        _resync(s, o)
+    assert ties <= 1
+    assert s.r_count > 0 or cls_name != 'ControlHMC'
+
+
+# ---------------------------------------------------------------------------------------------
+# HMCState operators on snapshots of dense-energy samplers (figures/poe_fig.py:58-76 assigns
+# `sampler.state = HMCState(x, sampler)` on a ProductOfT sampler and integrates it)
+# ---------------------------------------------------------------------------------------------
+def test_pot_state_assignment_and_leapfrog_operator():
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.samplers.hmc_state import HMCState
+    D, N = 36, 45
+    X0 = np.random.RandomState(6).randn(D, N)
+    d, W, lognu = _pot(D, N, None, X0)
+    en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
+    s = MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.3, num_leapfrog_steps=7, seed=3, resample=False)
+    Xn = np.random.RandomState(7).randn(D, N) * 1.3
+    Vn = np.random.RandomState(8).randn(D, N)
+    s.state = HMCState(Xn, s, V=Vn)                       # poe_fig.py:59
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)   # noqa: E731
+    assert np.array_equal(s.state.X, f32(Xn)) and np.array_equal(s.state.V, f32(Vn))
+    o = orc.MarkovJumpHMC(en, f32(Xn), epsilon=0.1, beta=0.3, num_leapfrog_steps=7, V0=f32(Vn), resample=False,
+                          rng=orc.ReplayRNG())
+    assert rel(s.state.EX, o.state.EX) < 2e-5 and rel(s.state.dEdX, o.state.dEdX) < 2e-5
+    Z = s.state.copy().L()
+    Zo = o.state.clone().L()
+    assert rel(Z.X, Zo.X) < 2e-5 and rel(Z.V, Zo.V) < 2e-5
+    assert rel(Z.EX, Zo.EX) < 2e-5 and rel(Z.EV, Zo.EV) < 2e-5 and rel(Z.dEdX, Zo.dEdX) < 5e-5
+    Z1 = s.state.copy()
+    Z1.leapfrog()                                          # a single step; energies are not refreshed (hmc_state.py:86-91)
+    o1 = o.state.clone()
+    o1.leap()
+    assert rel(Z1.X, o1.X) < 2e-5 and rel(Z1.V, o1.V) < 2e-5
+
+
+def test_sic_leapfrog_operator():
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    N = 20
+    B, imgs, a0 = sic_problem(0)
+    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(2).randn(1024, N))
+    d, B, imgs = _sic(1, N, True, X0)
+    en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+    s = MarkovJumpHMC(distribution=d, epsilon=0.0625, beta=0.3, num_leapfrog_steps=6, seed=3, resample=False)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=0.0625, beta=0.3, num_leapfrog_steps=6, V0=s.state.V, resample=False,
+                          rng=orc.ReplayRNG(), state_rounding=to_bf16)
+    Z = s.state.copy().L()
+    Zo = o.state.clone().L()
+    assert np.abs(Z.X - Zo.X).max() <= np.abs(Zo.X).max() / 128 and np.abs(Z.V - Zo.V).max() <= np.abs(Zo.V).max() / 128
+    scale = float(np.abs(Zo.H()).max())
+    assert np.abs(Z.EX - Zo.EX).max() <= 5e-4 * scale and np.abs(Z.EV - Zo.EV).max() <= 5e-4 * scale
+
+
+# ---------------------------------------------------------------------------------------------
+# SparseImageCode with the reference's default of nine patches per particle (tf_distributions.py:208,
+# experiments/spectral.py:247): 27 of a tile's 32 columns work, three particles per tile
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('P,N', [(9, 7), (2, 33), (3, 10)])
+def test_sic_several_patches_iterations_vs_oracle(P, N):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    B, imgs, a0 = sic_problem(0, n_patches=P)
+    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(P).randn(P * 1024, N))
+    d, B, imgs = _sic(P, N, True, X0)
+    en = orc.SparseImageCode(B, imgs[:, :P].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+    kw = dict(epsilon=0.0625, beta=0.2, num_leapfrog_steps=6, resample=False)
+    s = MarkovJumpHMC(distribution=d, seed=51, **kw)
+    o = orc.MarkovJumpHMC(en, X0, rng=orc.PhiloxRNG(51, np.arange(N)), state_rounding=to_bf16, **kw)
+    assert np.abs(s.state.V - o.state.V).max() < 3e-2                # bf16-rounded tick-0 momentum, all P * 1024 dims
+    _resync(s, o)
+    assert np.allclose(s.state.EX, o.state.EX, rtol=1e-4) and np.allclose(s.state.EV, o.state.EV, rtol=1e-5)
+    for t in range(4):
+        check_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='sic P=%d it %d' % (P, t))
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        _resync(s, o)
+    out = s.sample(3)                                                # ring slots of P * 1024-wide rows
+    assert out.shape == (P * 1024, 3 * N) and np.array_equal(out[:, -N:], s.state.X)

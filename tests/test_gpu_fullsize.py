@@ -108,7 +108,7 @@ def test_full_size_c5_sparse_image_code():
     assert np.abs(V0 - o.state.V).max() < 2e-2 and np.array_equal(V0, to_bf16(V0))
     resync(s, o, cols)
     d.E_count = d.dEdX_count = 0
-    check_iteration(s, o, delta_rel=1e-4, x_tol=1.0 / 128, e_rtol=1e-4, tag='C5', cols=cols)
+    check_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='C5', cols=cols)
     assert d.E_count == 2 * N and d.dEdX_count == 2 * N * L
     assert s.l_count + s.f_count + s.r_count == N
     assert np.array_equal(s.state.cache_active, s._dev.read(8) == 0)

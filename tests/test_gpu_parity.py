@@ -561,6 +561,12 @@ def test_sic_energy_and_gradient(cauchy):
     assert np.abs(G - Go).max() < 2e-2 * np.abs(Go).max()
 
 
+# Energy tolerance of the bf16 kernel against the mixed-precision oracle, relative to max|H|: the two sides agree to
+# float32 accumulation error EXCEPT where a value sits on a bf16 rounding boundary and is stored one bf16 ulp apart
+# (|v| ~ 3 -> ulp 2^-6 -> 0.05 in EV at |H| ~ 200 = 2.3e-4 per such element; measured up to 2.2e-4 over 5 iterations).
+SIC_E_TOL = 5e-4
+
+
 def test_sic_iterations_vs_oracle():
     """bf16 kernel against the mixed-precision restatement of the oracle (bf16 operands of both matrix products, end
     points stored in bf16, everything else float64): transitions equal or proven near ties.  epsilon is a power of
@@ -583,7 +589,7 @@ def test_sic_iterations_vs_oracle():
     assert np.allclose(s.state.EX, o.state.EX, rtol=1e-4) and np.allclose(s.state.EV, o.state.EV, rtol=1e-5)
     ties = 0
     for t in range(5):
-        ties += check_iteration(s, o, delta_rel=1e-4, x_tol=1.0 / 128, e_rtol=1e-4, tag='sic it %d' % t)
+        ties += check_iteration(s, o, delta_rel=SIC_E_TOL, x_tol=1.0 / 128, e_rtol=SIC_E_TOL, tag='sic it %d' % t)
         assert s.l_count + s.f_count + s.r_count == (t + 1) * N
         Xd, Vd = s.state.X, s.state.V
         assert np.array_equal(Xd, to_bf16(Xd)) and np.array_equal(Vd, to_bf16(Vd))
