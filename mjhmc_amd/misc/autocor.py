@@ -65,13 +65,13 @@ def autocorrelation(samples, e_evals, grad_evals, half_window=True, normalize=Tr
 
 
 def calculate_autocorrelation(sampler, distribution, num_steps=None, num_grad_steps=None, sample_steps=1,
-                              half_window=False, use_cached_var=False, **kwargs):
+                              half_window=False, use_cached_var=False, replay=None, **kwargs):
     """mjhmc/misc/autocor.py:10-35.  Returns (autocor, e_evals, grad_evals).
 
     When the run is recorded in the device ring (every sampler except a resampling jump sampler) the
     autocorrelation is computed there and the (n_dims, n_batch, n_samples) block is never downloaded."""
     smp, samples, e_evals, grad_evals, n_keep = _generate(sampler, distribution, num_steps, num_grad_steps,
-                                                          download=False, **kwargs)
+                                                          download=False, replay=replay, **kwargs)
     if samples is not None:
         return autocorrelation(samples, e_evals, grad_evals, half_window)
     sums = smp._dev.ring_autocor(0, n_keep, linear=False)
@@ -82,17 +82,19 @@ def calculate_autocorrelation(sampler, distribution, num_steps=None, num_grad_st
     return autocor, e_evals, grad_evals
 
 
-def generate_samples(sampler, distribution, num_steps=None, num_grad_steps=None, **kwargs):
+def generate_samples(sampler, distribution, num_steps=None, num_grad_steps=None, replay=None, **kwargs):
     """Same contract as the reference:
 
     Returns (samples [n_dims, n_batch, n_samples], e_evals [n_samples], grad_evals [n_samples]) where
-    ``grad_evals[t] = distribution.dEdX_count / n_batch`` after step t (counters reset after construction)."""
+    ``grad_evals[t] = distribution.dEdX_count / n_batch`` after step t (counters reset after construction).
+    ``replay``: recorded random numbers, one entry per iteration as ``sampling_iteration(replay=...)`` takes them
+    (parity tests against the reference's own generate_samples, tests/golden/g9_*)."""
     _, samples, e_evals, grad_evals, _ = _generate(sampler, distribution, num_steps, num_grad_steps,
-                                                   download=True, **kwargs)
+                                                   download=True, replay=replay, **kwargs)
     return samples, e_evals, grad_evals
 
 
-def _generate(sampler, distribution, num_steps, num_grad_steps, download, **kwargs):
+def _generate(sampler, distribution, num_steps, num_grad_steps, download, replay=None, **kwargs):
     """(sampler, samples or None, e_evals, grad_evals, n_keep).  ``samples`` is None when ``download`` is
     false and ring slots [0, n_keep) hold the run."""
     assert (((num_steps is None) and (num_grad_steps is not None)) or
@@ -123,7 +125,7 @@ def _generate(sampler, distribution, num_steps, num_grad_steps, download, **kwar
             assert grad_evals[-1] >= num_grad_steps
         return smp, samples, e_evals, grad_evals, num_steps
 
-    smp._record(num_steps)                                                 # one batched launch sequence
+    smp._record(num_steps, replay)                                         # one batched launch sequence
     trace = np.cumsum(smp.eval_trace(num_steps), axis=0)
     e_evals = trace[:, 0] / float(n_batch)
     grad_evals = trace[:, 1] / float(n_batch)

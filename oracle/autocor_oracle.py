@@ -4,11 +4,13 @@ Follows mjhmc/misc/autocor.py: fft_autocor (:37-49), the lag-product estimator o
 of autocorrelation (:52-117, with compile_autocor_func :119-140) and slow_autocorrelation (:177-211).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 
-Parity status: UNPINNED by the reference.  mjhmc/misc/autocor.py cannot be imported here (Python 2 print
-statements at :19, mklfft absent), and the one reference test of this code (tests/test_fast_ac.py) drives a
-DataFrame API that no longer exists in the module.  The restatement is pinned instead against the
-definition it implements: test_oracle_golden.py checks fft_autocor against the explicit circular lag sums
-and slow_autocorrelation against explicit lag-product means."""
+Parity status: pinned through fixtures G9 (tests/golden/g9_generate_*.npz).  mjhmc/misc/autocor.py cannot be
+imported as a module (Python 2 print statements at :19, mklfft absent), and the one reference test of this code
+(tests/test_fast_ac.py) drives a DataFrame API that no longer exists in it; oracle/capture_golden.py therefore
+executes the reference's fft_autocor, slow_autocorrelation and generate_samples FROM THE REFERENCE'S FILE (each is
+valid Python 3 on its own; numpy.fft stands in for mklfft's identical fftn / ifftn) on a recorded run of the
+imported samplers.  test_oracle_golden.py checks this restatement against those outputs, and against the explicit
+lag-sum definitions."""
 import numpy as np
 
 

@@ -302,6 +302,57 @@ def capture_trajectories(refs):
     print('g3_trajectories')
 
 
+def reference_autocor_functions(ref_root):
+    """fft_autocor (:37-49), slow_autocorrelation (:177-211) and generate_samples (:213-261) of the reference's
+    mjhmc/misc/autocor.py, executed from the reference's own file.  The module as a whole cannot be imported (Python 2
+    print statements at :19-34, `from mklfft.fftpack import fftn, ifftn` at :5 with mklfft absent); these three
+    functions are valid Python 3 on their own, and mklfft.fftpack.fftn / ifftn are numpy.fft's fftn / ifftn computed
+    by MKL (same signature, same transform), so numpy.fft stands in for them."""
+    lines = open(os.path.join(ref_root, 'mjhmc', 'misc', 'autocor.py')).read().split('\n')
+    ns = {'np': np, 'fftn': np.fft.fftn, 'ifftn': np.fft.ifftn}
+    for name in ('fft_autocor', 'slow_autocorrelation', 'generate_samples'):
+        start = next(i for i, ln in enumerate(lines) if ln.startswith('def %s(' % name))
+        stop = next((i for i in range(start + 1, len(lines)) if lines[i].startswith('def ')), len(lines))
+        exec('\n'.join(lines[start:stop]), ns)
+    return ns['fft_autocor'], ns['slow_autocorrelation'], ns['generate_samples']
+
+
+def capture_autocor(refs, ref_root):
+    """G9: the reference's main caller and the step right after it -- generate_samples (autocor.py:213-261) run on
+    the imported samplers with every random number recorded, then fft_autocor / slow_autocorrelation of its output."""
+    rs, _, rd, ru = refs
+    fft_autocor, slow_autocorrelation, generate_samples = reference_autocor_functions(ref_root)
+    for name, cls_name, kind, ndims, nbatch, eps, L, beta, T, seed in (
+            ('g9_generate_mjhmc_diag_6x40', 'MarkovJumpHMC', 'diag', 6, 40, 0.5, 4, 0.4, 24, 601),
+            ('g9_generate_control_iso_3x50', 'ControlHMC', 'iso', 3, 50, 0.3, 6, 0.6, 24, 602)):
+        np.random.seed(seed)
+        X0 = np.random.randn(ndims, nbatch)
+        par = energy_params(kind, ndims, nbatch)
+        d = make_harness(rd, kind, X0, **par)
+        kw = dict(epsilon=eps, beta=beta, num_leapfrog_steps=L)
+        if cls_name == 'MarkovJumpHMC':
+            kw['resample'] = False
+        with Recorder(rs, ru, nbatch) as rec:
+            samples, e_evals, grad_evals = generate_samples(getattr(rs, cls_name), d, num_steps=T, **kw)
+        out = dict(kind=kind, cls=cls_name, Xinit=X0, eps=eps, L=L, beta_in=beta, T=T, normals=np.stack(rec.normals),
+                   samples=samples, e_evals=e_evals, grad_evals=grad_evals, fft_autocor=fft_autocor(samples),
+                   slow_autocor=slow_autocorrelation(samples, e_evals, grad_evals, half_window=False)[0])
+        if cls_name == 'MarkovJumpHMC':
+            assert len(rec.exps) == T, 'a retry happened: pick a milder step size'
+            out['exps'] = np.stack(rec.exps)
+        else:
+            out['u_acc'] = np.stack(rec.uniforms[0::3])
+            out['u_flip'] = np.stack(rec.uniforms[1::3])
+            out['u_r'] = np.array([float(u) for u in rec.uniforms[2::3]])
+            smp = getattr(rs, cls_name)(distribution=make_harness(rd, kind, X0, **par), **kw)
+            out['p_r'], out['beta'], out['p_flip'] = smp.p_r, smp.beta, smp.p_flip
+        for k, v in par.items():
+            if k not in ('J', 'sep_vec'):
+                out['par_' + k] = np.asarray(v)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+        print(name, samples.shape, 'grad_evals[-1]', grad_evals[-1], 'autocor[1]', out['fft_autocor'][1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -340,6 +391,8 @@ def main():
     capture_control(refs, 'g7_base_iso_3x50', 'HMCBase', 'iso', 3, 50, 0.3, 6, 0.6, 12, 403)
     # G8: ContinuousTimeHMC (F / FL / R clocks); trans rows are min_idx's [f, fl, r] order
     capture_mjhmc(refs, 'g8_cthmc_diag_6x40', 'diag', 6, 40, 0.5, 4, 0.4, 15, 501, cls_name='ContinuousTimeHMC')
+    # G9: generate_samples + autocorrelation, from the reference's own (extracted) functions
+    capture_autocor(refs, args.ref)
 
 
 if __name__ == '__main__':

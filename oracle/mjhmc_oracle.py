@@ -358,7 +358,7 @@ class SparseImageCode(Energy):
     def dEdX_val(self, X):
         R, _ = self._resid(X)
         P = self.Y.shape[0]
-        g = np.einsum('ic,pin->pcn', self.B, self.rnd(R)).reshape(X.shape) / P
+        g = np.einsum('ic,pin->pcn', self.B, self.rnd(R / P)).reshape(X.shape)   # d/da_p of the MEAN over patches
         pen = 2 * X / (1 + X ** 2) if self.cauchy else np.sign(X)
         return g + self.lmbda * pen
 

@@ -128,3 +128,37 @@ def test_bad_arguments_fail_loudly():
         smp._dev.ring_autocor(2, 3)                                          # runs past the ring
     with pytest.raises(EngineError):
         smp._dev.ring_autocor(0, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# G9: the reference's own generate_samples / fft_autocor / slow_autocorrelation outputs (captured by executing those
+# functions from the reference's file, oracle/capture_golden.py: capture_autocor) on a recorded run
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['g9_generate_mjhmc_diag_6x40', 'g9_generate_control_iso_3x50'])
+def test_g9_generate_samples_and_autocorrelation_match_the_reference(name):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc import autocor as ac
+    from tests.helpers import load, bits_equal
+    from tests.test_gpu_parity import product_distribution
+    from tests.test_oracle_golden import g9_replay_feed
+    g = load(name)
+    T = int(g['T'])
+    cls = getattr(M, str(g['cls']))
+    kw = dict(epsilon=float(g['eps']), beta=float(g['beta_in']), num_leapfrog_steps=int(g['L']), Vinit=g['normals'][0], seed=5)
+    if str(g['cls']) == 'MarkovJumpHMC':
+        kw['resample'] = False
+    samples, e_evals, grad_evals = ac.generate_samples(cls, product_distribution(g, g['Xinit']), num_steps=T,
+                                                       replay=g9_replay_feed(g), **kw)
+    assert samples.shape == g['samples'].shape
+    assert np.array_equal(e_evals, g['e_evals']) and np.array_equal(grad_evals, g['grad_evals'])   # counter traces: exact
+    np.testing.assert_allclose(samples, g['samples'], rtol=1e-10, atol=1e-12)
+    if str(g['kind']) == 'diag':
+        assert bits_equal(samples, g['samples'])            # exact-product force: the chain is bit-identical
+    # the autocorrelation estimators on the REFERENCE's samples, and end to end on the device ring
+    np.testing.assert_allclose(ac.fft_autocor(g['samples']), g['fft_autocor'], rtol=0, atol=ATOL)
+    got, _, _ = ac.slow_autocorrelation(g['samples'], g['e_evals'], g['grad_evals'], half_window=False)
+    np.testing.assert_allclose(got, g['slow_autocor'], rtol=0, atol=ATOL)
+    auto, e2, g2 = ac.calculate_autocorrelation(cls, product_distribution(g, g['Xinit']), num_steps=T,
+                                                replay=g9_replay_feed(g), **kw)
+    np.testing.assert_allclose(auto, g['fft_autocor'], rtol=0, atol=ATOL)
+    assert np.array_equal(e2, g['e_evals']) and np.array_equal(g2, g['grad_evals'])

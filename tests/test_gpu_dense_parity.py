@@ -197,10 +197,11 @@ def test_pot_discrete_time_samplers_vs_oracle(cls_name, D, N):
     _resync(s, o)
     ties = 0
     for t in range(6):
+        before = (d.E_count, d.dEdX_count, en.E_count, en.dEdX_count)
         ties += check_control_iteration(s, o, delta_rel=2e-5, x_tol=2e-5, e_rtol=2e-5, tag='%s pot it %d' % (cls_name, t))
         if ties == 0:
             assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count)
-            assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count)
+        assert (d.E_count - before[0], d.dEdX_count - before[1]) == (en.E_count - before[2], en.dEdX_count - before[3]) == (N, 5 * N)
         _resync(s, o)
     assert ties <= 1
     assert s.r_count > 0 or cls_name != 'ControlHMC'

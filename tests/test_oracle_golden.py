@@ -180,3 +180,50 @@ def test_autocor_oracle_against_its_definition():
     brute, e2, _ = ac.autocorrelation(X, e, e, half_window=False, brute_force=True)
     assert brute.shape == (T - 1, 1) and e2.shape == (T - 1,)
     np.testing.assert_allclose(brute[:, 0], means[:T - 1] / means[0], rtol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------
+# G9: the reference's generate_samples (autocor.py:213-261) and the autocorrelation of its output
+# (:37-49, :177-211), captured by executing those functions from the reference's own file
+# ---------------------------------------------------------------------------------------------
+def g9_replay_feed(g):
+    """per-iteration (normals, other numbers) of a G9 run, in the form sampling_iteration(replay=...) takes"""
+    if str(g['cls']) == 'MarkovJumpHMC':
+        return [(g['normals'][1 + t], np.nan_to_num(g['exps'][t], nan=1.0)) for t in range(int(g['T']))]
+    feed, used = [], 1
+    for t in range(int(g['T'])):
+        fired = g['u_r'][t] < float(g['p_r'])
+        noise = g['normals'][used] if fired else np.zeros_like(g['Xinit'])
+        used += int(fired)
+        feed.append((noise, np.concatenate([g['u_acc'][t], g['u_flip'][t], [g['u_r'][t]]])))
+    return feed
+
+
+@pytest.mark.parametrize('name', ['g9_generate_mjhmc_diag_6x40', 'g9_generate_control_iso_3x50'])
+def test_g9_generate_samples_and_autocorrelation(name):
+    from oracle import autocor_oracle as ac
+    g = load(name)
+    en = oracle_energy(g)
+    T, N = int(g['T']), g['Xinit'].shape[1]
+    kw = dict(epsilon=float(g['eps']), beta=float(g['beta_in']), num_leapfrog_steps=int(g['L']), V0=g['normals'][0])
+    if str(g['cls']) == 'MarkovJumpHMC':
+        s = orc.MarkovJumpHMC(en, g['Xinit'], resample=False,
+                              rng=orc.ReplayRNG(normals=list(g['normals'][1:]), exps=list(g['exps'])), **kw)
+    else:
+        unif = []
+        for t in range(T):
+            unif += [g['u_acc'][t], g['u_flip'][t], g['u_r'][t]]
+        s = orc.ControlHMC(en, g['Xinit'], rng=orc.ReplayRNG(normals=list(g['normals'][1:]), uniforms=unif), **kw)
+    en.E_count = en.dEdX_count = 0                         # distribution.reset() (autocor.py:241)
+    samples = np.zeros_like(g['samples'])
+    e_evals, grad_evals = np.zeros(T), np.zeros(T)
+    for t in range(T):                                     # the loop of autocor.py:242-248
+        samples[:, :, t] = s.sample(1)
+        grad_evals[t] = en.dEdX_count / float(N)
+        e_evals[t] = en.E_count / float(N)
+    assert bits_equal(samples, g['samples'])
+    assert np.array_equal(e_evals, g['e_evals']) and np.array_equal(grad_evals, g['grad_evals'])
+    np.testing.assert_allclose(ac.fft_autocor(samples), g['fft_autocor'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(ac.slow_autocorrelation(samples, e_evals, grad_evals)[0], g['slow_autocor'], rtol=1e-13)
+    auto, e2, g2 = ac.autocorrelation(samples, e_evals, grad_evals, half_window=False)
+    np.testing.assert_allclose(auto, g['fft_autocor'], rtol=0, atol=1e-13)
