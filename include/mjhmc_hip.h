@@ -63,7 +63,8 @@ typedef enum {
   MJHMC_E_FUNNEL_NEAL = 4,
   MJHMC_E_FUNNEL_REF = 5,
   MJHMC_E_PRODUCT_OF_T = 6,
-  MJHMC_E_SPARSE_CODE = 7
+  MJHMC_E_SPARSE_CODE = 7,
+  MJHMC_E_USER_EXPR = 8      /* created by mjhmc_energy_create_expr only */
 } mjhmc_energy_kind;
 
 /* arithmetic type of state and force.  BF16: bfloat16 state in HBM and as MFMA operands, float32
@@ -117,6 +118,20 @@ int mjhmc_ctx_info(mjhmc_ctx* ctx, char* name, size_t name_cap, int* n_cu, uint6
 /* Replaces constructing a Distribution subclass (mjhmc/misc/distributions.py:20-59). */
 int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* params, size_t nparams,
                         mjhmc_energy** out);
+/* LambdaDistribution(energy_func, energy_grad_func, ...) with arbitrary callables (README.md:27-36,
+ * mjhmc/misc/distributions.py:198-251).  A Python callable cannot run on the device; the caller states the same two
+ * functions as C expressions of ONE coordinate for a separable energy
+ *     E(x) = sum_d energy_expr(x_d)      dE/dx_d = grad_expr(x_d)
+ * with `x` the coordinate (double), `d` its index (int) and `p[k]` the float64 parameters, e.g.
+ * ("0.5*x*x/(p[0]*p[0])", "x/(p[0]*p[0])") or ("log(1.0 + x*x/p[d])", "2.0*x/(p[d] + x*x)").  The engine's kernel
+ * templates are compiled around them with hipRTC for gfx950 (include_dir: the directory holding elementwise.hpp and
+ * philox.hpp, mjhmc_amd/csrc of this package); float64 state; every sampler family and the replay mode work as for the
+ * built-in elementwise energies.  A compile error in the expressions is returned as MJHMC_ERR_INVALID with the
+ * compiler's log in mjhmc_last_error(). */
+int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr, const char* grad_expr,
+                             const double* params, size_t nparams, const char* include_dir, mjhmc_energy** out);
+/* compile-only check of a pair of expressions (needs no device): 0, or MJHMC_ERR_INVALID with the compiler's log */
+int mjhmc_expr_check(int ndims, const char* energy_expr, const char* grad_expr, const char* include_dir);
 int mjhmc_energy_destroy(mjhmc_energy* e);
 
 /* One evaluation of E_val / dEdX_val (mjhmc/misc/distributions.py:66-81) on n columns.

@@ -10,10 +10,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+KERNEL_HEADERS = os.path.join(_HERE, 'csrc')     # elementwise.hpp / philox.hpp: what hipRTC compiles user expressions against
 LIB_PATH = os.environ.get('MJHMC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmjhmc_hip.so')
 
 # enums of include/mjhmc_hip.h
-E_ISO_GAUSS, E_DIAG_GAUSS, E_ROUGH_WELL, E_MM_GAUSS, E_FUNNEL_NEAL, E_FUNNEL_REF, E_PRODUCT_OF_T, E_SPARSE_CODE = range(8)
+E_ISO_GAUSS, E_DIAG_GAUSS, E_ROUGH_WELL, E_MM_GAUSS, E_FUNNEL_NEAL, E_FUNNEL_REF, E_PRODUCT_OF_T, E_SPARSE_CODE, E_USER_EXPR = range(9)
 F64, F32, BF16 = 0, 1, 2
 MODE_MJHMC, MODE_CONTROL, MODE_CTHMC = 0, 1, 2
 F_X, F_V, F_EX, F_EV, F_DEDX, F_HFLF, F_CACHE, F_DWELL, F_TRANS = range(9)
@@ -44,6 +45,9 @@ PROTOTYPES = {
     'mjhmc_ctx_info': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_uint64)]),
     'mjhmc_energy_create': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(_P)]),
+    'mjhmc_energy_create_expr': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, _P, ctypes.c_size_t,
+                                                ctypes.c_char_p, ctypes.POINTER(_P)]),
+    'mjhmc_expr_check': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]),
     'mjhmc_energy_destroy': (ctypes.c_int, [_P]),
     'mjhmc_eval': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _P, _P]),
     'mjhmc_sampler_create': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _P, _P,

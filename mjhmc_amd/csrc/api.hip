@@ -37,7 +37,7 @@ static int ilog2(int v) {
 }
 
 // lanes-per-particle / elements-per-lane selection (see elementwise.hpp header comment)
-static int pick_shape(int D, int dtype, Shape* out) {
+int pick_shape(int D, int dtype, Shape* out) {
   const int esize = dtype == MJHMC_F64 ? 8 : 4;
   const int VEC = 16 / esize;
   Shape s;
@@ -405,6 +405,9 @@ static int run_eval_t(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, c
   a.CH = s->sh.CH;
   a.logG = s->sh.logG;
   a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), 0u, 0u};
+  if constexpr (sizeof(T) == 8) {
+    if (s->en->is_user()) return user_launch_eval(s->en, a, s->stream);
+  }
   TRY(dispatch_eval<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
   HIPCHK(hipGetLastError());
   return 0;
@@ -653,8 +656,46 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
   return 0;
 }
 
+int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr, const char* grad_expr,
+                             const double* params, size_t nparams, const char* include_dir, mjhmc_energy** out) {
+  if (!ctx || !out || !energy_expr || !grad_expr || !include_dir) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (ndims < 1) return fail(MJHMC_ERR_INVALID, "ndims must be >= 1");
+  if (nparams && !params) return fail(MJHMC_ERR_INVALID, "params is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  Shape sh;
+  TRY(pick_shape(ndims, MJHMC_F64, &sh));
+  mjhmc_energy* e = new mjhmc_energy();
+  e->ctx = ctx;
+  if (nparams) e->params.assign(params, params + nparams);
+  std::memset(&e->ep, 0, sizeof(e->ep));
+  e->ep.kind = MJHMC_E_USER_EXPR;
+  e->ep.ndims = ndims;
+  const int rc = user_energy_build(e, energy_expr, grad_expr, include_dir, params, nparams, sh.E);
+  if (rc) {
+    std::string keep = g_err;
+    mjhmc_energy_destroy(e);
+    g_err = keep;
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+int mjhmc_expr_check(int ndims, const char* energy_expr, const char* grad_expr, const char* include_dir) {
+  if (!energy_expr || !grad_expr || !include_dir) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (ndims < 1) return fail(MJHMC_ERR_INVALID, "ndims must be >= 1");
+  Shape sh;
+  TRY(pick_shape(ndims, MJHMC_F64, &sh));
+  std::vector<char> code;
+  std::vector<std::string> lowered;
+  std::string err;
+  const int rc = user_expr_compile(user_expr_source(energy_expr, grad_expr), include_dir, sh.E, &code, &lowered, &err);
+  return rc ? fail(rc, err) : 0;
+}
+
 int mjhmc_energy_destroy(mjhmc_energy* e) {
   if (!e) return 0;
+  user_energy_free(e);
   if (e->dev64) (void)hipFree(e->dev64);
   if (e->dev32) (void)hipFree(e->dev32);
   for (float* q : e->pot)
@@ -692,6 +733,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
   if ((dtype == MJHMC_BF16) != e->is_sic())
     return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
+  if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   if (mode < MJHMC_MODE_MJHMC || mode > MJHMC_MODE_CTHMC) return fail(MJHMC_ERR_INVALID, "unknown sampler mode");
   if (first_particle_id < 0 || first_particle_id + nparticles > 0xFFFFFFFFLL)
     return fail(MJHMC_ERR_INVALID, "global particle ids must fit 32 bits");
@@ -1035,7 +1077,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // Fused launches: always for the Gaussian forces (one iteration is HBM-bound), for the other elementwise energies
   // while the batch is small (launch-/latency-bound) -- big batches of those take the compacted passes below instead.
   const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
-  const bool fusable = !s->en->is_dense() && (gaussian || s->N < 16384 || s->D <= 4);
+  const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || s->N < 16384 || s->D <= 4);
   if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !std::getenv("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);
@@ -1056,7 +1098,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
 
   // Several particles per wave and a big batch: the inverse-L trajectory of the cold-cache particles runs in its
   // own compacted pass (mjhmc_flf_kernel) instead of in every wave of the jump kernel that holds a cold particle.
-  const bool compact = s->mode == MJHMC_MODE_MJHMC && !s->en->is_dense() && !replay_normal && !replay_exp &&
+  const bool compact = s->mode == MJHMC_MODE_MJHMC && !s->en->is_dense() && !s->en->is_user() && !replay_normal && !replay_exp &&
                        s->sh.logG < 6 && s->N >= 16384 && !std::getenv("MJHMC_NO_COMPACT");
   if (compact) {
     if (!s->flf_list) {
@@ -1248,7 +1290,11 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         a.Hflf_in = (const T*)s->Hpre;  // every cache reads as warm in the jump kernel
         a.defer_r = 1;                  // and the momentum refresh of the R-movers follows as a compacted pass
       }
-      TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+      if (s->en->is_user()) {
+        if constexpr (sizeof(T) == 8) TRY(user_launch_jump(s->en, a, s->stream));
+      } else {
+        TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+      }
       if (compact) {
         int* r_count = s->flf_counts + n_iter + i;
         hipLaunchKernelGGL(compact_list_kernel<MovedBy>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)), dim3(1024),
@@ -1325,6 +1371,9 @@ static int leap_t(mjhmc_sampler& w, void* Xd, void* Vd, void* Xo, void* Vo, void
   a.L = L;
   a.eps = (T)eps;
   a.chalf = (T)(-eps / 2.);
+  if constexpr (sizeof(T) == 8) {
+    if (w.en->is_user()) return user_launch_leap(w.en, a, w.stream);
+  }
   TRY(dispatch_leap<T>(w.en->ep.kind, a, w.en->ep, w.sh.E, w.stream));
   HIPCHK(hipGetLastError());
   return 0;
@@ -1607,6 +1656,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
   if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE evaluates with BF16 state");
+  if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   HIPCHK(hipSetDevice(e->ctx->device));
   // a throw-away sampler-shaped workspace keeps one code path for re-tiling and evaluation
   mjhmc_sampler w;
@@ -1657,6 +1707,7 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
   if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
   if (e->is_pot() && dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T integrates in float32");
+  if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   HIPCHK(hipSetDevice(e->ctx->device));
   mjhmc_sampler w;
   w.ctx = e->ctx;

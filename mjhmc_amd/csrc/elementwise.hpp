@@ -19,11 +19,13 @@
 // update is evaluated as the reference writes it (mul, then add), which makes X and V
 // bit-identical to the NumPy path for linear forces.
 #pragma once
+#ifndef __HIPCC_RTC__  // hipRTC (user-expression energies, user_expr.hip) compiles the device half of this header only
 #include <hip/hip_runtime.h>
-#include <stdint.h>
 
 #include <algorithm>
 #include <cstdlib>
+#endif
+#include <stdint.h>
 
 #include "philox.hpp"
 
@@ -1462,6 +1464,7 @@ __global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T>
   }
 }
 
+#ifndef __HIPCC_RTC__
 template <typename T>
 inline void launch_refresh(const RefreshArgs<T>& a, int E, int64_t n_max, hipStream_t st) {
   const int64_t threads = n_max << a.logG;
@@ -1471,6 +1474,8 @@ inline void launch_refresh(const RefreshArgs<T>& a, int E, int64_t n_max, hipStr
   else if (E == 4 * VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 4 * VEC>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 8 * VEC>), grid, block, 0, st, a);
 }
+
+#endif  // !__HIPCC_RTC__
 
 // ------------------------------------------------------------------------------------------
 // HMCState.leapfrog / HMCState.L as an operator on caller-supplied states (hmc_state.py:86-100): the reference's
@@ -1519,11 +1524,14 @@ __global__ __launch_bounds__(256) void mjhmc_leap_kernel(const LeapArgs<T> a, co
   }
 }
 
+#ifndef __HIPCC_RTC__
 template <class En, typename T, int E>
 inline void launch_leap_t(const LeapArgs<T>& a, const En& en, hipStream_t st) {
   const int64_t threads = a.N << a.logG;
   hipLaunchKernelGGL((mjhmc_leap_kernel<En, T, E>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, en);
 }
+
+#endif  // !__HIPCC_RTC__
 
 // ------------------------------------------------------------------------------------------
 // evaluation kernel: E(X), dEdX(X), optionally kinetic energy / generated initial momentum
@@ -1596,6 +1604,7 @@ struct EnergyParams {
   const void* dev_f32;
 };
 
+#ifndef __HIPCC_RTC__
 // Persistent launch: as many 256-thread blocks as the device keeps resident for this kernel
 // (occupancy query, cached per instantiation), never more than there are slots to hand out.
 template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, int WPP = 0, bool FUSED = false>
@@ -1729,5 +1738,7 @@ MJHMC_DECLARE_ENERGY_LAUNCHERS(rough)
 MJHMC_DECLARE_ENERGY_LAUNCHERS(mm)
 MJHMC_DECLARE_ENERGY_LAUNCHERS(funnel_neal)
 MJHMC_DECLARE_ENERGY_LAUNCHERS(funnel_ref)
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace mjhmc

@@ -9,6 +9,7 @@
 #include "dense_pot.hpp"
 #include "dense_sic.hpp"
 #include "elementwise.hpp"
+#include "user_expr.hpp"
 
 using namespace mjhmc;
 
@@ -55,6 +56,8 @@ struct mjhmc_energy {
   }
   bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
   bool is_dense() const { return is_pot() || is_sic(); }
+  UserEnergy* user = nullptr;  // MJHMC_E_USER_EXPR: the hipRTC-built kernels of this energy
+  bool is_user() const { return ep.kind == MJHMC_E_USER_EXPR; }
 };
 
 struct Shape {
@@ -121,6 +124,8 @@ inline size_t ssize(const mjhmc_sampler* s) { return s->dtype == MJHMC_F64 ? 8 :
 inline size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_bytes(s); }
 
 
+// lanes-per-particle / elements-per-lane selection of the elementwise kernels for ndims = D
+int pick_shape(int D, int dtype, Shape* out);
 // device staging buffer of at least `elems` float64 (host layout side of every re-tiling)
 int ensure_stage(mjhmc_sampler* s, size_t elems);
 // device particle-major rows -> s->stage in the reference's (ndims, columns) layout: stage[d*rs + k*cs + off] = row(k)[d],

@@ -4,7 +4,9 @@
 // cannot be consumed by 10^5..10^6 independent lanes.  Bit-level recipe mirrored by
 // oracle/philox.py.
 #pragma once
+#ifndef __HIPCC_RTC__  // hipRTC pre-includes the device runtime and has no header search path to it
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace mjhmc {

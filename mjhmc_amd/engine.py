@@ -69,6 +69,23 @@ class DeviceEnergy(object):
                                           ctypes.byref(h)))
         self.handle = h
 
+    @classmethod
+    def from_expr(cls, ctx, ndims, energy_expr, grad_expr, params=()):
+        """A separable energy E(x) = sum_d energy_expr(x_d), dE/dx_d = grad_expr(x_d) given as C expressions of
+        ``x`` (coordinate), ``d`` (its index) and ``p[k]`` (float64 parameters); compiled with hipRTC around the
+        engine's kernel templates (mjhmc_energy_create_expr, include/mjhmc_hip.h)."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.kind = _lib.E_USER_EXPR
+        self.ndims = int(ndims)
+        self.params = np.ascontiguousarray(np.atleast_1d(np.asarray(params, dtype=np.float64)).ravel())
+        h = ctypes.c_void_p()
+        check(ctx.lib.mjhmc_energy_create_expr(ctx.handle, self.ndims, str(energy_expr).encode(), str(grad_expr).encode(),
+                                               ptr(self.params) if self.params.size else None, self.params.size,
+                                               _lib.KERNEL_HEADERS.encode(), ctypes.byref(h)))
+        self.handle = h
+        return self
+
     def eval(self, X, want_E=True, want_grad=True, dtype='float64'):
         X = as_f64(X)
         if X.ndim != 2 or X.shape[0] != self.ndims:

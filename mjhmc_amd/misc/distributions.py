@@ -45,7 +45,10 @@ class Distribution(object):
         """DeviceEnergy for this distribution on ``device`` (cached)."""
         if self._dev is None or self._dev.ctx.device != device:
             kind, params = self.device_energy()
-            self._dev = engine.DeviceEnergy(engine.context(device), kind, self.ndims, params)
+            if kind == _lib.E_USER_EXPR:                   # params = (energy_expr, grad_expr, float64 parameters)
+                self._dev = engine.DeviceEnergy.from_expr(engine.context(device), self.ndims, *params)
+            else:
+                self._dev = engine.DeviceEnergy(engine.context(device), kind, self.ndims, params)
         return self._dev
 
     # -- reference API --------------------------------------------------------------------
@@ -133,29 +136,57 @@ class Distribution(object):
 class LambdaDistribution(Distribution):
     """'Anonymous' distribution (distributions.py:198-251, README.md:27-36).
 
-    The reference's class ignores its callables (it evaluates a non-existent ``self.J``); the
-    README contract is what is kept: ``init`` is the initial state.  The sampling kernels need a
-    device functor, so name one with ``device_energy=(kind, params)`` -- or let the constructor
-    recognise the callables: they are probed on a few points and matched against the built-in
-    elementwise families (isotropic Gaussian with any sigma, as in the README example).
+    The reference's class ignores its callables (it evaluates a non-existent ``self.J``); the README contract is
+    what is kept: ``energy_func`` / ``energy_grad_func`` define the distribution and ``init`` is the initial state.
+    Python callables cannot run inside a GPU kernel, so the device needs the same functions in one of three forms:
+
+    * nothing: the callables are probed on a few points and matched against the built-in elementwise families
+      (isotropic Gaussian with any sigma -- the README example -- and diagonal Gaussians);
+    * ``device_expr=(energy_expr, grad_expr)`` [+ ``device_params``]: C expressions of one coordinate for a separable
+      energy ``E(x) = sum_d energy_expr(x_d)``, ``dE/dx_d = grad_expr(x_d)`` with ``x`` the coordinate, ``d`` its
+      index and ``p[k]`` the float64 ``device_params``; the engine's kernels are compiled around them with hipRTC
+      (mjhmc_energy_create_expr).  When callables are given as well they are checked against the compiled energy;
+    * ``device_energy=(kind, params)``: one of the built-in device energies by name.
     """
 
-    def __init__(self, energy_func=None, energy_grad_func=None, init=None, name=None, device_energy=None):
+    def __init__(self, energy_func=None, energy_grad_func=None, init=None, name=None, device_energy=None,
+                 device_expr=None, device_params=()):
         self.energy_func = energy_func
         self.energy_grad_func = energy_grad_func
         self.init = np.array(init, dtype=np.float64)
         self.name = name or str(np.random.random())
         self._functor = device_energy
-        if self._functor is None:
+        self._checked = False
+        if device_expr is not None:
+            e_expr, g_expr = device_expr
+            self._functor = (_lib.E_USER_EXPR, (str(e_expr), str(g_expr), np.asarray(device_params, dtype=np.float64)))
+        elif self._functor is None:
             self._functor = _recognise(energy_func, energy_grad_func, self.init.shape[0])
+            self._checked = True
         super(LambdaDistribution, self).__init__(ndims=self.init.shape[0], nbatch=self.init.shape[1])
 
     def device_energy(self):
         if self._functor is None:
             raise NotImplementedError(
-                'LambdaDistribution %r: the callables match no built-in device energy; pass '
-                'device_energy=(kind, params) or subclass Distribution' % self.name)
+                'LambdaDistribution %r: the callables match no built-in device energy.  State them for the device as '
+                'device_expr=("<E of one coordinate x>", "<dE/dx>") (separable energies, compiled with hipRTC), pass '
+                'device_energy=(kind, params), or subclass Distribution' % self.name)
         return self._functor
+
+    def bind(self, device=0):
+        dev = super(LambdaDistribution, self).bind(device)
+        if not self._checked and self.energy_func is not None and self.energy_grad_func is not None:
+            # the callables are the contract (README.md:27-36): the device energy must be the same function
+            self._checked = True
+            P = np.random.RandomState(12345).randn(self.ndims, 7)
+            E, G = dev.eval(P)
+            e = np.asarray(self.energy_func(P), dtype=np.float64).reshape(-1)
+            g = np.asarray(self.energy_grad_func(P), dtype=np.float64)
+            if not (np.allclose(E, e, rtol=1e-9, atol=1e-12) and np.allclose(G, g, rtol=1e-9, atol=1e-12)):
+                raise ValueError('LambdaDistribution %r: the device energy disagrees with energy_func / '
+                                 'energy_grad_func (max |dE| %g, max |d grad| %g)'
+                                 % (self.name, np.abs(E - e).max(), np.abs(G - g).max()))
+        return dev
 
     def gen_init_X(self):
         self.Xinit = self.init
@@ -165,8 +196,8 @@ class LambdaDistribution(Distribution):
 
 
 def _recognise(energy_func, grad_func, ndims):
-    """Match user callables against the isotropic-Gaussian family by probing (no sampling is ever
-    done with the callables themselves)."""
+    """Match user callables against the built-in Gaussian families by probing (no sampling is ever done with the
+    callables themselves): g(x) = j * x elementwise with E = sum j x^2 / 2 -- isotropic when all j are equal."""
     if energy_func is None or grad_func is None:
         return None
     rng = np.random.RandomState(12345)
@@ -179,12 +210,14 @@ def _recognise(energy_func, grad_func, ndims):
     if g.shape != P.shape or e.shape != (5,):
         return None
     ratio = g / P
-    inv_s2 = float(np.median(ratio))
-    if inv_s2 <= 0 or not np.allclose(ratio, inv_s2, rtol=1e-12, atol=0):
+    j = np.median(ratio, axis=1)
+    if np.any(j <= 0) or not np.allclose(ratio, j[:, None], rtol=1e-12, atol=0):
         return None
-    if not np.allclose(e, 0.5 * inv_s2 * np.sum(P ** 2, axis=0), rtol=1e-12, atol=0):
+    if not np.allclose(e, 0.5 * np.sum(j[:, None] * P ** 2, axis=0), rtol=1e-12, atol=0):
         return None
-    return (_lib.E_ISO_GAUSS, np.array([1.0 / np.sqrt(inv_s2)]))
+    if np.allclose(j, j[0], rtol=1e-12, atol=0):
+        return (_lib.E_ISO_GAUSS, np.array([1.0 / np.sqrt(float(np.median(j)))]))
+    return (_lib.E_DIAG_GAUSS, j)
 
 
 class Gaussian(Distribution):

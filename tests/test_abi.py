@@ -74,3 +74,13 @@ def test_hyperparameter_validation_is_host_side():
         MarkovJumpHMC(distribution=TestGaussian(ndims=2, nbatch=10), beta=1.0)
     with pytest.raises(NotImplementedError):
         MarkovJumpHMC(Xinit=None, E=None, dEdX=None)
+
+
+def test_user_expression_energies_compile_without_a_device(lib):
+    """mjhmc_expr_check: hipRTC builds the engine's kernel templates around a pair of C expressions for gfx950 with no
+    GPU present (LambdaDistribution(device_expr=...), include/mjhmc_hip.h: mjhmc_energy_create_expr)."""
+    inc = _lib.KERNEL_HEADERS.encode()
+    assert lib.mjhmc_expr_check(10, b"log(1.0 + x*x/p[d])", b"2.0*x/(p[d] + x*x)", inc) == 0, lib.mjhmc_last_error()
+    assert lib.mjhmc_expr_check(700, b"0.5*x*x + p[0]*cos(x)", b"x - p[0]*sin(x)", inc) == 0, lib.mjhmc_last_error()
+    rc = lib.mjhmc_expr_check(4, b"0.5*x*y", b"x", inc)
+    assert rc == -1 and b"undeclared identifier 'y'" in lib.mjhmc_last_error()

@@ -427,6 +427,91 @@ def test_readme_example_runs_unchanged():
     assert anonymous_gaussian.E_count >= 100 * 12
 
 
+# ---------------------------------------------------------------------------------------------
+# LambdaDistribution beyond the isotropic Gaussian (README.md:27-36: the callables define the distribution)
+# ---------------------------------------------------------------------------------------------
+def _student_like(D):
+    w = np.linspace(0.5, 3.0, D)
+
+    def E(X):
+        return np.sum(np.log(1.0 + X ** 2 / w[:, None]), axis=0).reshape((1, -1))
+
+    def dEdX(X):
+        return 2.0 * X / (w[:, None] + X ** 2)
+    return w, E, dEdX
+
+
+@pytest.mark.parametrize('cls_name,D,N', [('MarkovJumpHMC', 10, 90), ('MarkovJumpHMC', 300, 33), ('ControlHMC', 7, 64),
+                                          ('ContinuousTimeHMC', 40, 50)])
+def test_lambda_distribution_with_device_expressions(cls_name, D, N):
+    """A separable energy stated as C expressions (compiled with hipRTC around the engine's kernels) next to the
+    NumPy callables: the sampler must follow the oracle run on the CALLABLES, transitions exactly, state to 1e-10."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import LambdaDistribution
+    w, E, dEdX = _student_like(D)
+    X0 = np.random.RandomState(D).randn(D, N) * 2.0
+    d = LambdaDistribution(energy_func=E, energy_grad_func=dEdX, init=X0, name='student-like',
+                           device_expr=("log(1.0 + x*x/p[d])", "2.0*x/(p[d] + x*x)"), device_params=w)
+    assert close(d.E(X0)[0], E(X0)[0]) and close(d.dEdX(X0), dEdX(X0))
+    kw = dict(epsilon=0.3, beta=0.4, num_leapfrog_steps=5)
+    extra = dict(resample=False) if cls_name != 'ControlHMC' else {}
+    s = getattr(M, cls_name)(distribution=d, seed=61, **kw, **extra)
+    en = orc.LambdaEnergy(E, dEdX)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(61, np.arange(N)), **kw, **extra)
+    for t in range(8):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        if cls_name == 'MarkovJumpHMC':
+            assert np.array_equal(s._dev.read(8), o.last_transition), t
+            assert close(s.dwelling_times, o.dwelling_times), t
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), t
+        assert close(s.state.EX, o.state.EX) and close(s.state.EV, o.state.EV), t
+        assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count), t
+    out = s.sample(5)                                             # batched launches + the sample ring
+    assert out.shape == (D, 5 * N) and np.isfinite(out).all()
+    Z = s.state.copy().L()                                        # the snapshot operators go through the same energy
+    o.state.X[:], o.state.V[:] = s.state.X, s.state.V
+    o.state.refresh_EX(); o.state.refresh_EV(); o.state.refresh_grad()
+    Zo = o.state.clone().L()
+    assert close(Z.X, Zo.X) and close(Z.V, Zo.V) and close(Z.EX, Zo.EX)
+
+
+def test_lambda_distribution_checks_the_expressions_against_the_callables():
+    from mjhmc_amd import _lib
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import LambdaDistribution
+    w, E, dEdX = _student_like(6)
+    X0 = np.random.RandomState(1).randn(6, 20)
+    wrong = LambdaDistribution(energy_func=E, energy_grad_func=dEdX, init=X0,
+                               device_expr=("log(1.0 + x*x/p[d])", "x/(p[d] + x*x)"), device_params=w)   # gradient off by 2
+    with pytest.raises(ValueError):
+        MarkovJumpHMC(distribution=wrong, epsilon=0.1, beta=0.1)
+    broken = LambdaDistribution(init=X0, device_expr=("log(1.0 + x*x/q)", "x"))
+    with pytest.raises(_lib.EngineError) as info:
+        MarkovJumpHMC(distribution=broken, epsilon=0.1, beta=0.1)
+    assert "undeclared identifier 'q'" in str(info.value)
+    opaque = LambdaDistribution(energy_func=E, energy_grad_func=dEdX, init=X0)        # matches no built-in family
+    with pytest.raises(NotImplementedError):
+        MarkovJumpHMC(distribution=opaque, epsilon=0.1, beta=0.1)
+
+
+def test_lambda_distribution_recognises_a_diagonal_gaussian():
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import LambdaDistribution
+    j = 10 ** np.linspace(-2, 0, 12)
+    X0 = np.random.RandomState(2).randn(12, 50)
+    d = LambdaDistribution(energy_func=lambda X: 0.5 * np.sum(j[:, None] * X ** 2, axis=0).reshape((1, -1)),
+                           energy_grad_func=lambda X: j[:, None] * X, init=X0)
+    s = MarkovJumpHMC(distribution=d, epsilon=0.4, beta=0.3, num_leapfrog_steps=5, seed=9, resample=False)
+    en = orc.DiagGaussian(12, 2)
+    o = orc.MarkovJumpHMC(en, X0, epsilon=0.4, beta=0.3, num_leapfrog_steps=5, resample=False,
+                          rng=orc.PhiloxRNG(9, np.arange(50)))
+    for t in range(6):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        assert np.array_equal(s._dev.read(8), o.last_transition) and close(s.state.X, o.state.X), t
+
+
 @pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC', 'HMC', 'HMCBase'])
 def test_statistical_1d_gaussian(cls_name):
     """mjhmc/tests/test_continuous_samplers.py:19-41 with usable hyper-parameters: mean, std within 0.05."""
