@@ -71,13 +71,98 @@ __device__ __forceinline__ void ctile_store(__bf16* base, int64_t p, int w, int 
     }
 }
 
+constexpr int kRing = 8;    // dictionary fragments (1 KB each) a wave keeps in flight / staged
+constexpr int kYLds = 12;   // patches whose pixels fit the LDS copy (more: read from global memory)
+
+// ALL of the workgroup's LDS is this one object (a second __shared__ object beside an LDS-DMA target makes hipcc
+// drain the DMA queue before LDS reads, cdna_hip_programming.md section 5)
 struct SicShared {
-  f32x4 pubA[8][4][2][64];  // 64 KB: a as B fragments, [wave][block][k-step half][lane]
-  f32x4 pubR[8][2][64];     // 16 KB: scaled residual as B fragments
+  f32x4 pubA[8][4][2][64];    // 64 KB: a as B fragments, [wave][block][k-step half][lane]
+  f32x4 pubR[8][2][64];       // 16 KB: scaled residual as B fragments
+  f32x4 ring[8][kRing][64];   // 64 KB: per-wave ring of dictionary (A operand) fragments, filled by LDS-DMA
+  float ys[kYLds * kI];       // 12 KB: the patches
   float red[2][8][kP];
-  float colsum[kP];         // per-column energies, summed over a particle's columns when n_patches > 1
+  float colsum[kP];           // per-column energies, summed over a particle's columns when n_patches > 1
   int move[kP];
+  unsigned tally[4];
 };
+
+// ---- the dictionary stream -----------------------------------------------------------------------------------------
+// Both GEMMs of a leapfrog step read the whole dictionary (512 KB in each fragment order) from L2, 64 KB per wave
+// and GEMM, one 1 KB fragment per MFMA.  Loading a fragment into registers right before its MFMA exposes a full L2
+// round trip per MFMA (and every register spent on prefetch spills elsewhere: the kernel sits at the 256-VGPR budget).
+// So the fragments go through LDS instead: `global_load_lds_dwordx4` (no VGPR destination) fills a per-wave ring of
+// kRing slots, kRing fragments ahead of the MFMA that consumes them.  The fragment sequence of a wave is fixed --
+// GEMM1 (64 fragments), GEMM2 (64), GEMM1, ... -- so the ring runs ahead ACROSS the GEMMs, the barriers between them
+// and the tiles of the persistent loop: L2 latency is paid once per kernel.  Each wave reads only the slots it filled
+// itself: ordering is the wave's own counted `s_waitcnt vmcnt(kRing - 1)`, no barrier.  The DMA is inline asm, so
+// hipcc neither counts it nor drains it at `__syncthreads()`; its own waits (for loads it does count) can only
+// over-wait, because the counter completes in issue order.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+// lane l's 16 bytes at (sbase + voff) land at lds_dst + 16 l.  sbase is wave-uniform (scalar registers: its arithmetic
+// is free), voff the lane's byte offset (ONE loop-invariant VGPR): per-lane 64-bit source pointers would cost two
+// VGPRs per in-flight address, spill, and every spill reload is a counted load that drains the ring
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+constexpr unsigned kFrag1 = 2 * kI * 16;  // bytes between consecutive GEMM1 fragments (k-steps) of a lane
+constexpr unsigned kFrag2 = 2 * kC * 16;  // bytes between consecutive GEMM2 k-steps; blocks of a k-step are 512 B apart
+
+struct AStream {
+  const char* a1;   // GEMM1 fragments: A1[k-step][h][image row][8 bf16]           (wave-uniform base)
+  const char* a2;   // GEMM2 fragments: A2[k-step][h][coefficient row][8 bf16]
+  unsigned v1, v2;  // this lane's byte offset inside a GEMM1 / GEMM2 fragment
+  unsigned lds0;    // LDS byte address of this wave's ring
+  int only1;        // the kernel runs GEMM1 only (an evaluation without gradient): the sequence is GEMM1, GEMM1, ...
+};
+
+// fragment `pos` (0..63 GEMM1 k-steps, 64..127 GEMM2 (k-step, block) pairs) into ring slot pos % kRing
+__device__ __forceinline__ void astream_issue(const AStream& s, int pos) {
+  const unsigned dst = s.lds0 + (unsigned)(pos & (kRing - 1)) * 1024u;
+  if (pos < 64) glds16(s.a1 + (size_t)pos * kFrag1, s.v1, dst);
+  else glds16(s.a2 + (size_t)((pos - 64) >> 2) * kFrag2 + ((pos - 64) & 3) * 512, s.v2, dst);
+}
+
+__device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& sh, int w, int c, int h, bool only1) {
+  AStream s;
+  s.a1 = reinterpret_cast<const char*>(mdl.A1);
+  s.a2 = reinterpret_cast<const char*>(mdl.A2);
+  s.v1 = (unsigned)(h * kI + 32 * w + c) * 16u;
+  s.v2 = (unsigned)(h * kC + 128 * w + c) * 16u;
+  s.lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&sh.ring[w][0][0]));
+  s.only1 = only1 ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < kRing; ++j) astream_issue(s, j);  // the first GEMM1 fragments
+  return s;
+}
+
+// before the wave exits: no DMA may still be writing LDS that the next workgroup will own
+__device__ __forceinline__ void astream_close() { wait_vm<0>(); }
+
+// a GEMM1 whose GEMM2 is not run (a trajectory of zero steps): put the ring back on GEMM1's first fragments
+__device__ __forceinline__ void astream_rewind(const AStream& s) {
+  wait_vm<0>();
+#pragma unroll
+  for (int j = 0; j < kRing; ++j) astream_issue(s, j);
+}
+
+// the patches into LDS (once per kernel)
+__device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared& sh) {
+  if (mdl.P <= kYLds)
+    for (int i = threadIdx.x; i < mdl.P * kI; i += blockDim.x) sh.ys[i] = mdl.y[i];
+  __syncthreads();
+}
 
 // what column c of a tile works on
 struct Col {
@@ -117,8 +202,8 @@ __device__ __forceinline__ f32x4 frag_of(const f32x16& acc, int s, float scale) 
 }
 
 // residual of the tile at the X held in x (GEMM1).  Leaves it in `res` (fp32 accumulator layout).
-__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane, int patch,
-                                             const CTile& x, f32x16& res) {
+__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
+                                             int lane, int patch, const CTile& x, f32x16& res) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     sh.pubA[w][b][0][lane] = frag_of(x.b[b], 0, 1.0f);
@@ -126,7 +211,7 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
   }
   __syncthreads();
   {  // res starts at -y[i]
-    const float* yv = mdl.y + kI * patch + 32 * w + 4 * h;
+    const float* yv = (mdl.P <= kYLds ? sh.ys : mdl.y) + kI * patch + 32 * w + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(yv + 8 * g);
@@ -134,73 +219,70 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
       for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
     }
   }
-  // A1[kstep][h][i][8 bf16]: 16 bytes per lane, lanes of a half contiguous
-  const f32x4* a1 = reinterpret_cast<const f32x4*>(mdl.A1) + (size_t)h * kI + 32 * w + c;
-  // 16 chunks of 4 k-steps, two per trip; chunk n+1's A fragments are in flight while chunk n's MFMAs run
-  f32x4 fa[2][4];
+  // 64 k-steps; the fragment of k-step ks is in ring slot ks % kRing, and its slot is refilled with the fragment
+  // kRing positions further down the stream as soon as it has been read
+  const f32x4* ring = &sh.ring[w][0][lane];
+  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi) {
+    // refill: wave-uniform address of the fragment that goes into slot 0; slot j gets refill + (j & 3) step + (j >> 2) step_hi
 #pragma unroll
-  for (int t = 0; t < 4; ++t) fa[0][t] = a1[(size_t)t * 2 * kI];
+    for (int j = 0; j < kRing; ++j) {
+      const int ks = ch * kRing + j;
+      wait_vm<kRing - 1>();
+      const f32x4 fa = ring[j * 64];
+      const f32x4 fb = sh.pubA[ks >> 3][(ks >> 1) & 3][ks & 1][lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be refilled
+      __builtin_amdgcn_sched_barrier(0);
+      glds16(refill + (j & 3) * step + (j >> 2) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
+      res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), res,
+                                                    0, 0, 0);
+    }
+  };
 #pragma unroll 1
-  for (int ch = 0; ch < 16; ch += 2) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fa[1][t] = a1[(size_t)((ch + 1) * 4 + t) * 2 * kI];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ks = ch * 4 + t;
-      const f32x4 fb = sh.pubA[ks >> 3][(ks >> 1) & 3][ks & 1][lane];
-      res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0][t]), __builtin_bit_cast(bf16x8, fb),
-                                                    res, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int nxt = ch + 2 < 16 ? ch + 2 : 15;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fa[0][t] = a1[(size_t)(nxt * 4 + t) * 2 * kI];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ks = (ch + 1) * 4 + t;
-      const f32x4 fb = sh.pubA[ks >> 3][(ks >> 1) & 3][ks & 1][lane];
-      res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[1][t]), __builtin_bit_cast(bf16x8, fb),
-                                                    res, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  for (int ch = 0; ch < 64 / kRing - 1; ++ch)
+    chunk(ch, as.a1 + (size_t)(ch + 1) * kRing * kFrag1, as.v1, kFrag1, 4 * kFrag1);
+  if (as.only1) chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1);  // the next GEMM1's first fragments
+  else chunk(64 / kRing - 1, as.a2, as.v2, 512, kFrag2);  // GEMM2's first: (k-step 0, blocks 0..3), (k-step 1, blocks 0..3)
 }
 
 // acc[c][n] += sum_i B[i][c] * (scale * res[i][n]) + scale * prior'(x)   (GEMM2 into the caller's tile)
 template <bool CAUCHY>
-__device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane,
-                                         const f32x16& res, const CTile& x, float scale, CTile& acc) {
+__device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
+                                         int lane, const f32x16& res, const CTile& x, float scale, CTile& acc) {
   sh.pubR[w][0][lane] = frag_of(res, 0, scale * mdl.invP);  // d/da_p of the MEAN over patches
   sh.pubR[w][1][lane] = frag_of(res, 1, scale * mdl.invP);
-  __syncthreads();
-  const f32x4* a2 = reinterpret_cast<const f32x4*>(mdl.A2) + (size_t)h * kC + 128 * w + c;
-#pragma unroll 1
-  for (int ks = 0; ks < 16; ks += 2) {
-    f32x4 fa[2][4];
+  {  // the prior's force first (x is not read again until the drift): lambda * 2a / (1 + a^2), or lambda * sign(a)
+    const float sl = scale * mdl.lambda;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) fa[u][b] = a2[(size_t)(ks + u) * 2 * kC + 32 * b];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const f32x4 fb = sh.pubR[(ks + u) >> 1][(ks + u) & 1][lane];
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        acc.b[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[u][b]),
-                                                           __builtin_bit_cast(bf16x8, fb), acc.b[b], 0, 0, 0);
-    }
+      for (int q = 0; q < 16; ++q) {
+        const float a = x.b[b][q];
+        if (CAUCHY) acc.b[b][q] += (sl * 2.0f) * a * __builtin_amdgcn_rcpf(1.0f + a * a);  // v_rcp_f32: 1 ulp
+        else acc.b[b][q] += sl * (a > 0.f ? 1.0f : (a < 0.f ? -1.0f : 0.0f));
+      }
   }
-  const float sl = scale * mdl.lambda;
+  __syncthreads();
+  const f32x4* ring = &sh.ring[w][0][lane];
+  // stream positions 64 + 8 ch + j = (k-step 2 ch + (j >> 2), block j & 3); refilled kRing positions ahead: the same
+  // (j >> 2, block) of chunk ch + 1, or, from the last chunk, the next GEMM1's first fragments
+  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi) {
+    f32x4 fb[2];
+    fb[0] = sh.pubR[ch][0][lane];
+    fb[1] = sh.pubR[ch][1][lane];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float a = x.b[b][q];
-      if (CAUCHY) acc.b[b][q] += sl * (2.0f * a / (1.0f + a * a));
-      else acc.b[b][q] += sl * (a > 0.f ? 1.0f : (a < 0.f ? -1.0f : 0.0f));
+    for (int j = 0; j < kRing; ++j) {
+      wait_vm<kRing - 1>();
+      const f32x4 fa = ring[j * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      glds16(refill + (j & 3) * step + (j >> 2) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
+      acc.b[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
+                                                             __builtin_bit_cast(bf16x8, fb[j >> 2]), acc.b[j & 3], 0, 0, 0);
     }
+  };
+#pragma unroll 1
+  for (int ch = 0; ch < 64 / kRing - 1; ++ch) chunk(ch, as.a2 + (size_t)(2 * ch + 2) * kFrag2, as.v2, 512, kFrag2);
+  chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1);  // the next GEMM1's fragments 0..7: consecutive k-steps
 }
 
 __device__ __forceinline__ float half_swap_sum(float s) {
@@ -261,34 +343,38 @@ __device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h,
   return group_total(sh, w, c, h, P, col.g0, tot) / 2.0f;
 }
 
-// L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
-// separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place.
-template <bool CAUCHY>
-__device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, int w, int c, int h, int lane,
-                                                const Col& col, CTile& x, CTile& v, int L, float eps, float chalf) {
-  f32x16 res;
-  sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
-  if (L > 0) sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, chalf, v);
-  for (int s = 1; s <= L; ++s) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) x.b[b] = x.b[b] + eps * v.b[b];
-    sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
-    sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, s < L ? 2.0f * chalf : chalf, v);
-  }
-  // the successor position is stored in bf16 (and GEMM1 already saw bf16(x)): evaluate the prior on
-  // what will be stored, so EX is the energy of the stored state
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) x.b[b][q] = (float)(__bf16)x.b[b][q];
-  return sic_energy<CAUCHY>(mdl, sh, w, c, h, col, res, x);
-}
-
 __device__ __forceinline__ void round_to_state(CTile& t) {
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.b[b][q] = (float)(__bf16)t.b[b][q];
+    for (int q = 0; q < 16; ++q) {
+      // opaque: otherwise hipcc shares these conversions with the ones that published the tile as an MFMA operand two
+      // GEMMs earlier and keeps 64 single bf16 values alive (spilled) across both of them
+      asm volatile("" : "+v"(t.b[b][q]));
+      t.b[b][q] = (float)(__bf16)t.b[b][q];
+    }
+}
+
+// L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
+// separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place.
+template <bool CAUCHY>
+__device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
+                                                int lane, const Col& col, CTile& x, CTile& v, int L, float eps,
+                                                float chalf) {
+  f32x16 res;
+  sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+  if (L > 0) sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, chalf, v);
+  else astream_rewind(as);
+  for (int s = 1; s <= L; ++s) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x.b[b] = x.b[b] + eps * v.b[b];
+    sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+    sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, s < L ? 2.0f * chalf : chalf, v);
+  }
+  // the successor position is stored in bf16 (and GEMM1 already saw bf16(x)): evaluate the prior on
+  // what will be stored, so EX is the energy of the stored state
+  round_to_state(x);
+  return sic_energy<CAUCHY>(mdl, sh, w, c, h, col, res, x);
 }
 
 // v += mix * (standard normals of this lane's dims of particle `pid`; dims patch * 1024 + ...), group by group: one
@@ -321,19 +407,21 @@ template <bool CAUCHY>
 __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, const SicModel mdl) {
   __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  stage_patches(mdl, sh);
+  const AStream as = astream_open(mdl, sh, w, c, h, a.G == nullptr);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
     CTile x;
     ctile_load(a.X, col.q, w, h, x);
     f32x16 res;
-    sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
+    sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
     if (a.G) {
       CTile g;
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
-      sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, 1.0f, g);
+      sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
       if (col.alive) {
         float* row = a.G + (size_t)col.q * kC + 128 * w + 4 * h;  // dE/dX is handed out in float32
 #pragma unroll
@@ -366,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
       if (w == 0 && h == 0 && col.leader) a.EV[col.part] = ev;
     }
   }
+  astream_close();
 }
 
 __global__ void sic_cold_list_kernel(const float* __restrict__ Hflf_in, float* __restrict__ Hwork, int64_t N,
@@ -401,6 +490,9 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
   const int ppt = kP / mdl.P;
+  if ((int64_t)blockIdx.x * ppt >= ncold) return;  // nothing for this workgroup
+  stage_patches(mdl, sh);
+  const AStream as = astream_open(mdl, sh, w, c, h, false);
   for (int64_t tile = blockIdx.x; tile * ppt < ncold; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, (int64_t)ncold, FromList{a.cold_list});  // the last tile repeats an entry
     CTile x, v;
@@ -408,12 +500,13 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
     ctile_load(a.V_in, col.q, w, h, v);
 #pragma unroll
     for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
-    const float ex = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);  // the same rounding the jump kernel applies to the forward proposal
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (w == 0 && h == 0 && col.leader) a.Hwork[col.part] = ex + ev;
     __syncthreads();
   }
+  astream_close();
 }
 
 // MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
@@ -425,6 +518,9 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
+  if (threadIdx.x < 4) sh.tally[threadIdx.x] = 0;
+  stage_patches(mdl, sh);
+  const AStream as = astream_open(mdl, sh, w, c, h, false);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
     const int64_t p = col.part;
@@ -434,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
     CTile x, v;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
-    const float EXL = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float EXL = sic_trajectory<CAUCHY>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
     const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
@@ -529,15 +625,13 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
     a.ctl->failed = 1;
     a.ctl->failed_iter = a.iter;
   }
-  __shared__ unsigned tally[4];
-  if (threadIdx.x < 4) tally[threadIdx.x] = 0;
+  astream_close();
+  if (n0) atomicAdd(&sh.tally[0], n0);
+  if (n1) atomicAdd(&sh.tally[1], n1);
+  if (n2) atomicAdd(&sh.tally[2], n2);
+  if (n3) atomicAdd(&sh.tally[3], n3);
   __syncthreads();
-  if (n0) atomicAdd(&tally[0], n0);
-  if (n1) atomicAdd(&tally[1], n1);
-  if (n2) atomicAdd(&tally[2], n2);
-  if (n3) atomicAdd(&tally[3], n3);
-  __syncthreads();
-  if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+  if (threadIdx.x < 4 && sh.tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)sh.tally[threadIdx.x]);
 }
 
 // HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
@@ -545,23 +639,25 @@ template <bool CAUCHY>
 __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, const SicModel mdl) {
   __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  stage_patches(mdl, sh);
+  const AStream as = astream_open(mdl, sh, w, c, h, false);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
     CTile x, v;
     ctile_load(a.X, col.q, w, h, x);
     ctile_load(a.V, col.q, w, h, v);
-    const float ex = sic_trajectory<CAUCHY>(mdl, sh, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (a.G) {  // dE/dX of the stored end point
       f32x16 res;
-      sic_residual(mdl, sh, w, c, h, lane, col.patch, x, res);
+      sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
       CTile g;
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
-      sic_kick<CAUCHY>(mdl, sh, w, c, h, lane, res, x, 1.0f, g);
+      sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
       if (col.alive) {
         float* row = a.G + (size_t)col.q * kC + 128 * w + 4 * h;
 #pragma unroll
@@ -585,6 +681,7 @@ __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, c
     }
     __syncthreads();
   }
+  astream_close();
 }
 
 static int sic_cus() {
