@@ -136,8 +136,9 @@ __device__ __forceinline__ void astream_issue(const AStream& s, int pos) {
 
 __device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& sh, int w, int c, int h, bool only1) {
   AStream s;
-  s.a1 = reinterpret_cast<const char*>(mdl.A1);
-  s.a2 = reinterpret_cast<const char*>(mdl.A2);
+  const size_t copy = (size_t)((blockIdx.x >> 3) % (unsigned)mdl.copies) * (size_t)(kI * kC * 2);  // blocks b, b + 8 share an XCD
+  s.a1 = reinterpret_cast<const char*>(mdl.A1) + copy;
+  s.a2 = reinterpret_cast<const char*>(mdl.A2) + copy;
   s.v1 = (unsigned)(h * kI + 32 * w + c) * 16u;
   s.v2 = (unsigned)(h * kC + 128 * w + c) * 16u;
   s.lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&sh.ring[w][0][0]));
@@ -220,28 +221,39 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
     }
   }
   // 64 k-steps; the fragment of k-step ks is in ring slot ks % kRing, and its slot is refilled with the fragment
-  // kRing positions further down the stream as soon as it has been read
+  // kRing positions further down the stream as soon as it has been read.  The LDS reads of k-step ks + 1 are issued
+  // before the MFMA of k-step ks (one register set ahead), so an MFMA never waits for the LDS round trip.
   const f32x4* ring = &sh.ring[w][0][lane];
-  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi) {
+  f32x4 fa, fb, na, nb;
+  wait_vm<kRing - 1>();
+  fa = ring[0];
+  fb = sh.pubA[0][0][0][lane];
+  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi, bool last) {
     // refill: wave-uniform address of the fragment that goes into slot 0; slot j gets refill + (j & 3) step + (j >> 2) step_hi
 #pragma unroll
     for (int j = 0; j < kRing; ++j) {
       const int ks = ch * kRing + j;
-      wait_vm<kRing - 1>();
-      const f32x4 fa = ring[j * 64];
-      const f32x4 fb = sh.pubA[ks >> 3][(ks >> 1) & 3][ks & 1][lane];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be refilled
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fa, fb are here; slot j has been read: it may be refilled
       __builtin_amdgcn_sched_barrier(0);
       glds16(refill + (j & 3) * step + (j >> 2) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
+      if (!(last && j == kRing - 1)) {
+        wait_vm<kRing - 1>();  // fragment ks + 1 has landed
+        const int kn = ks + 1;
+        na = ring[((j + 1) & (kRing - 1)) * 64];
+        nb = sh.pubA[kn >> 3][(kn >> 1) & 3][kn & 1][lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), res,
                                                     0, 0, 0);
+      fa = na;
+      fb = nb;
     }
   };
 #pragma unroll 1
   for (int ch = 0; ch < 64 / kRing - 1; ++ch)
-    chunk(ch, as.a1 + (size_t)(ch + 1) * kRing * kFrag1, as.v1, kFrag1, 4 * kFrag1);
-  if (as.only1) chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1);  // the next GEMM1's first fragments
-  else chunk(64 / kRing - 1, as.a2, as.v2, 512, kFrag2);  // GEMM2's first: (k-step 0, blocks 0..3), (k-step 1, blocks 0..3)
+    chunk(ch, as.a1 + (size_t)(ch + 1) * kRing * kFrag1, as.v1, kFrag1, 4 * kFrag1, false);
+  if (as.only1) chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1, true);  // the next GEMM1's first fragments
+  else chunk(64 / kRing - 1, as.a2, as.v2, 512, kFrag2, true);  // GEMM2's first: (k-step 0, blocks 0..3), (k-step 1, blocks 0..3)
 }
 
 // acc[c][n] += sum_i B[i][c] * (scale * res[i][n]) + scale * prior'(x)   (GEMM2 into the caller's tile)
@@ -264,25 +276,33 @@ __device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared& sh, con
   __syncthreads();
   const f32x4* ring = &sh.ring[w][0][lane];
   // stream positions 64 + 8 ch + j = (k-step 2 ch + (j >> 2), block j & 3); refilled kRing positions ahead: the same
-  // (j >> 2, block) of chunk ch + 1, or, from the last chunk, the next GEMM1's first fragments
-  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi) {
+  // (j >> 2, block) of chunk ch + 1, or, from the last chunk, the next GEMM1's first fragments.  The dictionary fragment
+  // of position + 1 is read from the ring before the MFMA of this position.
+  f32x4 fa, na;
+  wait_vm<kRing - 1>();
+  fa = ring[0];
+  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi, bool last) {
     f32x4 fb[2];
     fb[0] = sh.pubR[ch][0][lane];
     fb[1] = sh.pubR[ch][1][lane];
 #pragma unroll
     for (int j = 0; j < kRing; ++j) {
-      wait_vm<kRing - 1>();
-      const f32x4 fa = ring[j * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fa (and fb) are here; slot j may be refilled
       __builtin_amdgcn_sched_barrier(0);
       glds16(refill + (j & 3) * step + (j >> 2) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
+      if (!(last && j == kRing - 1)) {
+        wait_vm<kRing - 1>();
+        na = ring[((j + 1) & (kRing - 1)) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       acc.b[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
                                                              __builtin_bit_cast(bf16x8, fb[j >> 2]), acc.b[j & 3], 0, 0, 0);
+      fa = na;
     }
   };
 #pragma unroll 1
-  for (int ch = 0; ch < 64 / kRing - 1; ++ch) chunk(ch, as.a2 + (size_t)(2 * ch + 2) * kFrag2, as.v2, 512, kFrag2);
-  chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1);  // the next GEMM1's fragments 0..7: consecutive k-steps
+  for (int ch = 0; ch < 64 / kRing - 1; ++ch) chunk(ch, as.a2 + (size_t)(2 * ch + 2) * kFrag2, as.v2, 512, kFrag2, false);
+  chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1, true);  // the next GEMM1's fragments 0..7: consecutive k-steps
 }
 
 __device__ __forceinline__ float half_swap_sum(float s) {

@@ -18,7 +18,9 @@ struct SicModel {
   int cauchy;
   int P;            // n_patches: a particle is P consecutive 1024-coefficient rows, one per patch (tf_distributions.py:228-229)
   float invP;       // the reconstruction error is the MEAN over patches (tf_distributions.py:259-260)
+  int copies;       // identical copies of A1 / A2 laid out back to back
 };
+constexpr int kSicCopies = 1;
 
 struct SicJumpArgs {
   const __bf16* X_in;

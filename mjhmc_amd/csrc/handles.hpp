@@ -51,8 +51,9 @@ struct mjhmc_energy {
   float sic_lambda = 0.f;
   int sic_cauchy = 1;
   int sic_P = 1;  // n_patches
+  int sic_copies = 1;
   SicModel sic_model() const {
-    return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy, sic_P, 1.0f / (float)sic_P};
+    return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy, sic_P, 1.0f / (float)sic_P, sic_copies};
   }
   bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
   bool is_dense() const { return is_pot() || is_sic(); }
