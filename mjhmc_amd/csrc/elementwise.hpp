@@ -913,9 +913,20 @@ __device__ __forceinline__ void slot_store(char* base, uint32_t lane_off, uint32
 // chains are evaluated ONCE, lane-parallel -- lane 0 works on the L clock, lane 1 on the R clock /
 // the FLF rate, lane 2 on the F clock -- instead of three times in sequence in every lane
 // (2 exp + 2 sqrt + 3 log + 3 div + 2 Philox  ->  1 of each), then exchanged inside the group.
-template <typename T, bool REPLAY>
+// the unit exponential this lane contributes to decide() when the group has >= 4 lanes and the counter RNG is used
+// (lane 0: L clock, lane 1: R clock, lanes 2..: F clock).  It depends on (particle id, tick) only, so a caller may
+// draw it long before the energies exist (block-level decide: off the critical path between the two barriers).
+__device__ __forceinline__ double decide_draw(const RngKey& key, const LaneMap& m, uint32_t pid) {
+  const int role = m.j;
+  const u32x4 w = philox4x32_10(pid, key.tick_lo, key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, key.k0, key.k1);
+  const double uA = u53(w.w0, w.w1);
+  const double uF = group_lane(u53(w.w2, w.w3), m, 0);
+  return neg_log_unit(role >= 2 ? uF : uA);
+}
+
+template <typename T, bool REPLAY, bool PREDRAWN = false>
 __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, const LaneMap& m, T H0, T HL, T Hflf,
-                                       int64_t p, uint32_t pid, int& k, double& dwell, bool& bad) {
+                                       int64_t p, uint32_t pid, int& k, double& dwell, bool& bad, double e_pre = 0.0) {
   const double r_rate = a.p_r;
   double dL, dF, dR, l_rate, f_rate;
   if (m.G >= 4) {
@@ -927,7 +938,9 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
     const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
     f_rate = flf_rate - mn;  // :368
     double e;
-    if constexpr (REPLAY) {
+    if constexpr (PREDRAWN) {
+      e = e_pre;
+    } else if constexpr (REPLAY) {
       const int row = (role == 0) ? 0 : (role == 1 ? 2 : 1);
       e = a.rexp[(size_t)row * a.N + p];
     } else {
@@ -940,11 +953,7 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
         const double uL = u53(w.w0, w.w1), uF = u53(w.w2, w.w3), uR = u53(q.w0, q.w1);
         e = neg_log_unit(role == 0 ? uL : (role == 1 ? uR : uF));
       } else {
-        const u32x4 w =
-            philox4x32_10(pid, key.tick_lo, key.tick_hi, role == 1 ? kSlotExpR : kSlotExpLF, key.k0, key.k1);
-        const double uA = u53(w.w0, w.w1);
-        const double uF = group_lane(u53(w.w2, w.w3), m, 0);
-        e = neg_log_unit(role >= 2 ? uF : uA);
+        e = decide_draw(key, m, pid);
       }
     }
     const double rate = (role == 0) ? l_rate : (role == 1 ? r_rate : f_rate);
@@ -1059,6 +1068,13 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
 // exchanges (v_readlane) and the Philox calls (scalar unit) specialise on it.
 // WPP = 3: G == 4 (a quad per particle, e.g. ndims 17..32 in float64): two-level DPP reductions without the run-time
 // ladder, group exchanges as quad_perm broadcasts instead of ds_bpermute (C4 -3 %, isotropic 32 x 10^6 fused -8 %).
+// WPP = 5 (FUSED MJHMC launches, G == 64): as WPP = 1, with the unit exponentials of all the launch's waiting-time
+// draws made UP FRONT.  They depend on (particle id, tick) only, and the Philox + log chain behind them is ~130 of
+// decide()'s ~190 vector instructions, which a wave-per-particle kernel otherwise spends on three useful lanes.  The
+// four waves of a workgroup walk four consecutive particles; at the top of a slot they fill an LDS table
+// [iteration][particle][clock] with every lane working on a different (particle, iteration, clock) -- 16 pairs per
+// vector pass instead of one -- and the iterations then run decide() from the table (same functions on the same
+// inputs: identical bits), with no barrier inside the iteration loop.
 // FUSED = true: the launch runs a.n_fuse (<= kMaxFuse) consecutive sampling iterations per particle.  The
 // chains are independent, so between iterations nothing has to leave the wave: X, V, EX, EV, H_flf stay in
 // registers / the LDS stash, HBM sees one read and one write of the state per LAUNCH instead of per
@@ -1072,7 +1088,9 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
-  const int logG = WPP == 1 ? 6 : (WPP == 3 ? 2 : a.logG);
+  constexpr bool BD = (WPP == 5);  // block-level decide: needs all four waves of the workgroup in lockstep per iteration
+  static_assert(!BD || (FUSED && MODE == kModeMJHMC), "block-level decide exists for fused MJHMC launches");
+  const int logG = (WPP == 1 || BD) ? 6 : (WPP == 3 ? 2 : a.logG);
   const int G = 1 << logG;
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block, scalar
@@ -1087,7 +1105,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = lane & ~(G - 1);
-  m.wpp = WPP;
+  m.wpp = BD ? 1 : WPP;
   constexpr int VEC = VecOf<T>::n;
   const uint32_t lane_off = ((uint32_t)gi * a.pitch + m.j * VEC) * (uint32_t)sizeof(T);
   const uint32_t chunk_stride = (uint32_t)(G * VEC * sizeof(T));
@@ -1107,6 +1125,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   __shared__ Vec stash[4][2][C][64];
   Vec(*stash_x)[64] = stash[wib][0];
   Vec(*stash_v)[64] = stash[wib][1];
+  __shared__ double bd_e[BD ? kMaxFuse : 1][4][3];  // unit exponentials [iteration][particle of wave q][L, R, F clock]
 
   T nx[E], nv[E];
   SlotScalars<T> ns;
@@ -1122,10 +1141,15 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
   // one slot ahead, which frees the second register set (one more wave per SIMD)
   if (!FUSED && wave < nslots) fetch(wave);
 
+  // BD: the workgroup's four waves walk the slots together (slot0 + wave), so that every wave meets every barrier;
+  // a wave without a slot of its own re-runs the last one and stores nothing
+  const int64_t slot_first = BD ? (int64_t)blockIdx.x * 4 : wave;
 #pragma unroll 1
-  for (int64_t slot = wave; slot < nslots; slot += W) {
+  for (int64_t slot0 = slot_first; slot0 < nslots; slot0 += W) {
+    const bool have = !BD || slot0 + wib < nslots;
+    const int64_t slot = BD ? (have ? slot0 + wib : nslots - 1) : slot0;
     const int64_t p = slot * ppw + gi;
-    const bool alive = p < a.N;
+    const bool alive = have && p < a.N;
     if constexpr (FUSED) fetch(slot);
     // The slot's pre-move state (x0, v0) is parked in this wave's private LDS stripe (lane-linear
     // 16-byte chunks: conflict-free ds_write_b128 / ds_read_b128, no barrier -- every lane reads
@@ -1146,13 +1170,31 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     use_here(EV0);
     use_here(Hcached);
     if constexpr (!FUSED)
-      fetch(slot + W < nslots ? slot + W : slot);  // prefetch (unconditional, so waits stay countable): in flight during everything below
+      fetch(slot0 + W < nslots ? slot0 + W : slot0);  // prefetch (unconditional, so waits stay countable): in flight during everything below
     const uint32_t pid = (uint32_t)(a.first_pid + p);
     RngKey key = a.key;
     int k;
     double dwell = 0.0;
     T EXn, EVn, Hc;
     bool tally_cold = false, r_applied = false;
+    if constexpr (BD) {
+      __syncthreads();  // every wave is done with the previous slot's table
+      LaneMap mq = m;   // a quad of lanes per (particle, iteration) pair: lane 0 L clock, 1 R clock, 2 F clock
+      mq.j = lane & 3;
+      mq.G = 4;
+      mq.lane0 = lane & ~3;
+      mq.wpp = 3;
+      for (int r = wib * 16 + (lane >> 2); r - (lane >> 2) < 4 * n_it; r += 64) {  // r = 4 * iteration + particle
+        const int it = r >> 2, q = r & 3;
+        RngKey kt = a.key;
+        const uint32_t lo = kt.tick_lo + (uint32_t)it;
+        kt.tick_hi += lo < kt.tick_lo ? 1u : 0u;
+        kt.tick_lo = lo;
+        const double e = decide_draw(kt, mq, (uint32_t)(a.first_pid + slot0 + q));
+        if (it < n_it && (lane & 3) < 3) bd_e[it][q][lane & 3] = e;
+      }
+      __syncthreads();
+    }
 #pragma unroll 1
     for (int it = 0; it < n_it; ++it) {
     if constexpr (FUSED) {
@@ -1186,7 +1228,12 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     tally_cold = false;
     r_applied = false;
     if constexpr (MODE == kModeMJHMC) {
-      decide<T, REPLAY>(a, key, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
+      if constexpr (BD) {
+        const double e_pre = bd_e[it][wib][lane < 2 ? lane : 2];  // lane 0: L clock, lane 1: R clock, others: F clock
+        decide<T, false, true>(a, key, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad, e_pre);
+      } else {
+        decide<T, REPLAY>(a, key, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
+      }
       tally_cold = !warm;
       // successor state (markov_jump_hmc.py:399-410)
       if (k == 0) {  // L: proposal accepted; the pre-move state becomes the cached inverse-L state
@@ -1307,7 +1354,7 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
         if (b2) atomicAdd(&fused_tally[it][2], (unsigned)__popcll(b2));
         if (b3) atomicAdd(&fused_tally[it][3], (unsigned)__popcll(b3));
       }
-      if (a.xiter) {  // sample ring: X and the dwelling times after every iteration
+      if (a.xiter && have) {  // sample ring: X and the dwelling times after every iteration
         slot_store<T, E, FULLROW>((char*)(a.xiter + (size_t)it * a.xiter_stride) + slot * slot_bytes, lane_off,
                                   chunk_stride, m, x);
         a.dwell_ring[(size_t)it * a.Npad + p] = dwell;
@@ -1324,15 +1371,17 @@ __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const
     // and every lane of a group writes the same scalar to the same address.  With no store behind
     // a branch the compiler can COUNT them, so the wait for the prefetched loads at the loop end is
     // vmcnt(#stores) instead of vmcnt(0) -- the wave never sits waiting for HBM write acks.
-    if (!FUSED || !a.xiter)
-      slot_store<T, E, FULLROW>((char*)a.X_out + slot * slot_bytes, lane_off, chunk_stride, m, x);
-    slot_store<T, E, FULLROW>((char*)a.V_out + slot * slot_bytes, lane_off, chunk_stride, m, v);
-    a.EX_out[p] = EXn;
-    a.EV_out[p] = EVn;
-    a.Hflf_out[p] = Hc;
-    a.dwell[p] = dwell;
-    if constexpr (!FUSED) a.dwell_ring[p] = dwell;
-    a.trans[p] = (uint8_t)k;
+    if (have) {
+      if (!FUSED || !a.xiter)
+        slot_store<T, E, FULLROW>((char*)a.X_out + slot * slot_bytes, lane_off, chunk_stride, m, x);
+      slot_store<T, E, FULLROW>((char*)a.V_out + slot * slot_bytes, lane_off, chunk_stride, m, v);
+      a.EX_out[p] = EXn;
+      a.EV_out[p] = EVn;
+      a.Hflf_out[p] = Hc;
+      a.dwell[p] = dwell;
+      if constexpr (!FUSED) a.dwell_ring[p] = dwell;
+      a.trans[p] = (uint8_t)k;
+    }
     if (!FUSED && alive && m.j == 0) {
       if constexpr (MODE == kModeControl) {
         nL += (k == 3);
@@ -1632,7 +1681,8 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool replay = a.noise != nullptr;
   if constexpr (En::kFuse) if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
     if (a.mode == kModeMJHMC) {
-      if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1, true>(a, en, st);
+      if (full && a.logG == 6 && !std::getenv("MJHMC_NO_BLOCK_DECIDE")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 5, true>(a, en, st);
+      else if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1, true>(a, en, st);
       else if (full && a.logG == 2 && !std::getenv("MJHMC_NO_QUAD")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3, true>(a, en, st);
       else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, 0, true>(a, en, st);
       else launch_jump_r<En, T, E, kModeMJHMC, false, false, 0, true>(a, en, st);
