@@ -181,6 +181,11 @@ int mjhmc_restore(mjhmc_sampler* s);
 /* Undo the last call when it was mjhmc_iterate(1) and committed: the iteration's inputs are the untouched other
  * halves of the ping-pong buffers, so no copy is taken or restored (the RNG tick stays consumed). */
 int mjhmc_rollback(mjhmc_sampler* s);
+/* The position of the counter RNG (one tick per sampling_iteration attempt): together with X, V and H_flf
+ * (mjhmc_read / mjhmc_write) it is the whole resumable state of a sampler -- mjhmc_amd's save_state / load_state write it
+ * to an .npz file, and a restored sampler continues bit for bit. */
+int mjhmc_get_tick(mjhmc_sampler* s, uint64_t* tick);
+int mjhmc_set_tick(mjhmc_sampler* s, uint64_t tick);
 /* skip n RNG ticks (a rank that did not execute a failed attempt must still consume its tick) */
 int mjhmc_advance_tick(mjhmc_sampler* s, int64_t n);
 

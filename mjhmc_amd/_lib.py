@@ -60,6 +60,8 @@ PROTOTYPES = {
     'mjhmc_checkpoint': (ctypes.c_int, [_P]),
     'mjhmc_restore': (ctypes.c_int, [_P]),
     'mjhmc_rollback': (ctypes.c_int, [_P]),
+    'mjhmc_get_tick': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
+    'mjhmc_set_tick': (ctypes.c_int, [_P, ctypes.c_uint64]),
     'mjhmc_advance_tick': (ctypes.c_int, [_P, ctypes.c_int64]),
     'mjhmc_reset_flf_cache': (ctypes.c_int, [_P]),
     'mjhmc_read': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_size_t]),

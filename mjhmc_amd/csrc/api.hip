@@ -891,6 +891,19 @@ int mjhmc_rollback(mjhmc_sampler* s) {
   return 0;
 }
 
+int mjhmc_get_tick(mjhmc_sampler* s, uint64_t* tick) {
+  if (!s || !tick) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  *tick = s->tick;
+  return 0;
+}
+
+int mjhmc_set_tick(mjhmc_sampler* s, uint64_t tick) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  s->tick = tick;
+  s->undo_valid = false;
+  return 0;
+}
+
 int mjhmc_advance_tick(mjhmc_sampler* s, int64_t n) {
   if (!s || n < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
   s->tick += (uint64_t)n;
@@ -1059,9 +1072,21 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     l.K = done - l.i0;
     if (l.K > 0) {  // redo the iterations of that launch that precede the failed one (same ticks, same results)
       l.xout = out_of(l.i0, l.K, l.xin);
+      long long* redo_stats = s->stats + 4 * (size_t)n_iter;
       HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
-      TRY(launch(l, s->stats + 4 * (size_t)n_iter));
+      HIPCHK(hipMemsetAsync(redo_stats, 0, (size_t)kMaxFuse * 4 * sizeof(long long), s->stream));
+      TRY(launch(l, redo_stats));
+      Control rc;
+      std::vector<long long> rs((size_t)l.K * 4);
+      HIPCHK(hipMemcpyAsync(&rc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipMemcpyAsync(rs.data(), redo_stats, rs.size() * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
+      if (rc.failed)  // cannot happen: the same ticks on the same inputs gave finite rates for these iterations before
+        return fail(MJHMC_ERR_HIP, "the recovery launch of a fused batch reported a non-finite rate of its own");
+      // the tallies of the committed iterations of that launch come from the recovery run: in the failed launch a
+      // workgroup that started after the failure may have skipped them
+      for (int i = 0; i < l.K; ++i)
+        for (int c = 0; c < 4; ++c) hs[(size_t)(l.i0 + i) * 4 + c] = rs[(size_t)i * 4 + c];
       xlive = l.xout;
       ++committed;
     }

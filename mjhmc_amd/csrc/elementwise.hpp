@@ -1084,7 +1084,13 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
 template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, int WPP = 0, bool FUSED = false>
 __global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   static_assert(!(FUSED && REPLAY), "recorded random numbers are replayed one iteration per launch");
-  if (a.ctl->failed) return;  // an earlier attempt of this batch was rolled back: do nothing
+  if (a.ctl->failed) {  // an earlier attempt of this batch was rolled back: do nothing
+    // ... unless the failure belongs to THIS fused launch (another workgroup met it first): this workgroup must still run,
+    // report an earlier first failure of its own particles if it has one, and flush its tallies of the good iterations
+    if (!FUSED) return;
+    const int first = 0x7fffffff - __hip_atomic_load(&a.ctl->inv_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first < a.iter) return;
+  }
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.

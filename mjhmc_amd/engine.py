@@ -172,6 +172,14 @@ class DeviceSampler(object):
     def rollback(self):
         check(self.lib.mjhmc_rollback(self.handle))
 
+    def get_tick(self):
+        t = ctypes.c_uint64()
+        check(self.lib.mjhmc_get_tick(self.handle, ctypes.byref(t)))
+        return int(t.value)
+
+    def set_tick(self, tick):
+        check(self.lib.mjhmc_set_tick(self.handle, ctypes.c_uint64(int(tick))))
+
     def advance_tick(self, n=1):
         check(self.lib.mjhmc_advance_tick(self.handle, int(n)))
 

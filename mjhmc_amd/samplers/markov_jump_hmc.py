@@ -101,6 +101,39 @@ class HMCBase(object):
         if getattr(Z, 'V', None) is not None:
             self._dev.write(_lib.F_V, np.ascontiguousarray(Z.V[:, cols]))
 
+    # -- checkpoint / resume -----------------------------------------------------------------
+    _SAVED = ('epsilon', 'num_leapfrog_steps', 'beta', 'p_r', 'p_flip', 'original_epsilon', 'original_l',
+              'l_count', 'f_count', 'fl_count', 'r_count')
+
+    def save_state(self, path):
+        """Everything a run needs to continue exactly where it stands -- X, V, the inverse-L cache (H_flf, NaN =
+        cold), the counter-RNG position, hyper-parameters and counters -- as an ``.npz`` file.  A sampler built on
+        the same distribution and ``load_state``-ed continues bit for bit (the RNG is a pure function of
+        (seed, particle id, tick))."""
+        st = self.state
+        meta = {k: np.asarray(getattr(self, k)) for k in self._SAVED}
+        np.savez(path, X=st.X, V=st.V, H_flf=st.H_flf[0], dwelling_times=np.asarray(getattr(self, 'dwelling_times', 0.0)),
+                 tick=np.uint64(self._dev.get_tick()), seed=np.uint64(self.seed),
+                 E_count=self.distribution.E_count, dEdX_count=self.distribution.dEdX_count, **meta)
+
+    def load_state(self, path):
+        z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        if z['X'].shape != (self.ndims, self.nbatch):
+            raise ValueError('checkpoint holds a %r state, this sampler is %r' % (z['X'].shape, (self.ndims, self.nbatch)))
+        if int(z['seed']) != self.seed:
+            raise ValueError('checkpoint was written with seed %d, this sampler has %d' % (int(z['seed']), self.seed))
+        cols = slice(None) if self._plan is None else slice(*self._plan.span(self._comm.rank))
+        self._dev.write(_lib.F_X, np.ascontiguousarray(z['X'][:, cols]))      # re-derives EX (and dE/dX), clears the cache
+        self._dev.write(_lib.F_V, np.ascontiguousarray(z['V'][:, cols]))
+        self._dev.write(_lib.F_HFLF, np.ascontiguousarray(z['H_flf'][cols]))
+        self._dev.set_tick(int(z['tick']))
+        for k in self._SAVED:
+            setattr(self, k, z[k].item())
+        self.distribution.E_count, self.distribution.dEdX_count = int(z['E_count']), int(z['dEdX_count'])
+        if hasattr(self, 'dwelling_times'):
+            self.dwelling_times = z['dwelling_times']
+        return self
+
     def E(self, X):
         return self.energy_func(X).reshape((1, -1))
 

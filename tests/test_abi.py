@@ -84,3 +84,41 @@ def test_user_expression_energies_compile_without_a_device(lib):
     assert lib.mjhmc_expr_check(700, b"0.5*x*x + p[0]*cos(x)", b"x - p[0]*sin(x)", inc) == 0, lib.mjhmc_last_error()
     rc = lib.mjhmc_expr_check(4, b"0.5*x*y", b"x", inc)
     assert rc == -1 and b"undeclared identifier 'y'" in lib.mjhmc_last_error()
+
+
+def test_host_side_under_address_sanitizer(tmp_path):
+    """`make asan`: the translation units that hold host logic (handles, argument checks, RCCL / hipRTC plumbing) built
+    with AddressSanitizer on the host side and driven through their error paths and the hipRTC compile (no device
+    needed; GPU ASan is not available on this pool)."""
+    import subprocess
+    import sys
+    clang = '/opt/rocm/lib/llvm/bin/clang'
+    if not os.path.exists(clang):
+        pytest.skip('no ROCm clang')
+    rt = subprocess.check_output([clang, '-print-file-name=libclang_rt.asan-x86_64.so']).decode().strip()
+    if not os.path.exists(rt):
+        pytest.skip('no ASan runtime')
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'mjhmc_amd', 'csrc'), 'asan', '-j8'], stdout=subprocess.DEVNULL)
+    drive = tmp_path / 'drive.py'
+    drive.write_text('''
+import ctypes, sys
+sys.path.insert(0, %r)
+from mjhmc_amd import _lib
+lib = _lib.load()
+h = ctypes.c_void_p()
+lib.mjhmc_ctx_create(99, ctypes.byref(h))
+inc = _lib.KERNEL_HEADERS.encode()
+assert lib.mjhmc_expr_check(10, b"0.5*x*x/p[0]", b"x/p[0]", inc) == 0
+assert lib.mjhmc_expr_check(4, b"0.5*x*y", b"x", inc) == -1 and b"undeclared" in lib.mjhmc_last_error()
+assert lib.mjhmc_expr_check(0, b"x", b"x", inc) == -1
+assert lib.mjhmc_energy_create(None, 0, 2, None, 0, None) == -1
+assert lib.mjhmc_iterate(None, 1, None, None, None, -1, None, None) == -1
+assert lib.mjhmc_comm_create(None, 0, 1, None, None) == -1
+assert lib.mjhmc_rollback(None) == -1 and lib.mjhmc_get_tick(None, None) == -1
+print("asan drive ok")
+''' % ROOT)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS='detect_leaks=0',
+               MJHMC_HIP_LIB=os.path.join(ROOT, 'mjhmc_amd', 'lib', 'libmjhmc_hip_asan.so'))
+    p = subprocess.run([sys.executable, str(drive)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and 'asan drive ok' in out and 'AddressSanitizer' not in out, out[-3000:]

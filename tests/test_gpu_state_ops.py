@@ -125,3 +125,44 @@ def test_cached_init_X_and_load_cache(tmp_path):
     d.mjhmc = False
     d.cached_init_X(str(tmp_path))                      # second call only reads the file
     assert np.array_equal(d.Xinit, ctl[:, :30])
+
+
+@pytest.mark.parametrize('kind', ['diag', 'pot', 'control'])
+def test_save_and_load_state_continue_bit_for_bit(kind, tmp_path):
+    """.npz checkpoint of a sampler (state, inverse-L cache, RNG tick, counters): a fresh sampler that loads it continues
+    exactly like the original."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC, ControlHMC
+    from mjhmc_amd.misc.distributions import Gaussian, ProductOfT
+    X0 = np.random.RandomState(3).randn(36, 70)
+
+    def make():
+        if kind == 'pot':
+            class FixedT(ProductOfT):
+                def init_X(self):
+                    self.Xinit = X0
+            rs = np.random.RandomState(8)
+            W = rs.randn(36, 36) * (rs.rand(36, 36) < 0.05) + np.eye(36)
+            d = FixedT(ndims=36, nbasis=36, nbatch=70, W=W, lognu=np.log(rs.rand(36) * 2 + 2.1))
+        else:
+            class FixedG(Gaussian):
+                def init_X(self):
+                    self.Xinit = X0
+            d = FixedG(ndims=36, nbatch=70, log_conditioning=2)
+        cls, kw = (ControlHMC, {}) if kind == 'control' else (MarkovJumpHMC, dict(resample=False))
+        return cls(distribution=d, epsilon=0.3, beta=0.4, num_leapfrog_steps=5, seed=77, **kw), d
+
+    a, da = make()
+    a.sample(9)                                             # fused / batched launches
+    a.sampling_iteration()
+    path = str(tmp_path / 'ckpt.npz')
+    a.save_state(path)
+    want = a.sample(6)
+    b, db = make()
+    b.load_state(path)
+    assert np.array_equal(b.state.X, np.load(path)['X']) and np.array_equal(b.state.cache_active, ~np.isnan(np.load(path)['H_flf']))
+    got = b.sample(6)
+    assert np.array_equal(got, want)
+    assert np.array_equal(a.state.X, b.state.X) and np.array_equal(a.state.V, b.state.V)
+    assert np.array_equal(a.state.EX, b.state.EX) and np.array_equal(a.state.EV, b.state.EV)
+    assert (a.l_count, a.f_count, a.r_count, a.fl_count) == (b.l_count, b.f_count, b.r_count, b.fl_count)
+    assert (da.E_count, da.dEdX_count) == (db.E_count, db.dEdX_count)
