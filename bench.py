@@ -172,14 +172,26 @@ class Rig(object):
         self.ctx = engine.context(self.local_rank)
         self.comm = None
         if self.world > 1:
-            if os.environ.get('MJHMC_BENCH_BACKEND', 'rccl') == 'gloo':
-                import torch.distributed as dist
-                from mjhmc_amd.parallel import Comm
-                dist.init_process_group('gloo')
-                self.comm = Comm()
-            else:
-                from mjhmc_amd.parallel import RcclComm
-                self.comm = RcclComm(self.rank, self.world, device=self.local_rank)
+            # RCCL (and gloo) print a banner on stdout when a communicator comes up; stdout carries the ONE JSON line
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                self._connect()
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
+
+    def _connect(self):
+        if os.environ.get('MJHMC_BENCH_BACKEND', 'rccl') == 'gloo':
+            import torch.distributed as dist
+            from mjhmc_amd.parallel import Comm
+            dist.init_process_group('gloo')
+            self.comm = Comm()
+        else:
+            from mjhmc_amd.parallel import RcclComm
+            self.comm = RcclComm(self.rank, self.world, device=self.local_rank)
 
     def barrier(self, smp):
         smp.sync()
