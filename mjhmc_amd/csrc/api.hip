@@ -179,10 +179,12 @@ __global__ void narrow_vec(const double* __restrict__ src, T* __restrict__ dst, 
 // (a global atomic per wave serialised on the single counter: 178 us for 10^6 particles, this form ~10 us).
 constexpr int kColdChunk = 4096;
 template <typename T>
-struct ColdCache {  // H_flf is NaN
+struct ColdCache {  // H_flf is NaN; the scan also writes the copy of H_flf that the inverse-L pass completes
   const T* h;
+  T* copy;
   __device__ bool operator()(int64_t p) const {
     const T v = h[p];
+    copy[p] = v;
     return v != v;
   }
 };
@@ -1302,8 +1304,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     } else {
       if (compact) {
         hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)),
-                           dim3(1024), 0, s->stream, ColdCache<T>{a.Hflf_in}, s->N, s->ctl, s->flf_list, s->flf_counts + i);
-        HIPCHK(hipMemcpyAsync(s->Hpre, a.Hflf_in, (size_t)s->N * sizeof(T), hipMemcpyDeviceToDevice, s->stream));
+                           dim3(1024), 0, s->stream, ColdCache<T>{a.Hflf_in, (T*)s->Hpre}, s->N, s->ctl, s->flf_list, s->flf_counts + i);
         FlfArgs<T> fa;
         fa.X = a.X_in;
         fa.V = a.V_in;

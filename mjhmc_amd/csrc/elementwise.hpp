@@ -170,6 +170,8 @@ __device__ __forceinline__ T group_bcast0(T v, const LaneMap& m) {
 // defined with the other scalar kernels below
 __device__ __forceinline__ double exp_any(double h);
 __device__ __forceinline__ float exp_any(float h);
+__device__ __forceinline__ double exp_neg(double x);
+__device__ __forceinline__ float exp_neg(float x);
 
 struct NoCtx {};
 template <int E>
@@ -346,18 +348,26 @@ struct FunnelNealF {
   }
   template <int E>
   __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
-    T s = 0;
+    T s = (m.j == 0) ? T(0) : x[0] * x[0];  // only (lane 0, element 0) is dim 0
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += (e == 0 && m.j == 0) ? T(0) : x[e] * x[e];  // only (lane 0, element 0) is dim 0
+    for (int e = 1; e < E; ++e) s = __builtin_fma(x[e], x[e], s);
     Ctx c;
     c.S = group_sum(s, m.G);
     c.x0 = group_bcast0(x[0], m);
-    c.ex = exp_any(-c.x0);
+    c.ex = exp_neg(c.x0);
     return c;
   }
   template <int E>
   __device__ __forceinline__ T grad(T xe, int e, int d, const Ctx& c, const Local<E>&) const {
     return (e == 0 && d == 0) ? (c.x0 * inv_s2 - T(0.5) * c.ex * c.S + half_dm1) : xe * c.ex;
+  }
+  // v += ck * dE/dx as ONE multiply-add per coordinate: the force of x_k is x_k * exp(-x0), and ck * exp(-x0) is shared
+  // by the whole particle (counter-RNG trajectories; the replay kernels keep c * (x * ex), the reference's rounding)
+  static constexpr bool kScaledKick = true;
+  template <int E>
+  __device__ __forceinline__ T kick(T ck, T xe, T ve, int e, int d, const Ctx& c) const {
+    return (e == 0 && d == 0) ? __builtin_fma(ck, c.x0 * inv_s2 - T(0.5) * c.ex * c.S + half_dm1, ve)
+                              : __builtin_fma(xe, ck * c.ex, ve);
   }
   template <int E>
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
@@ -384,18 +394,24 @@ struct FunnelRefF {
   }
   template <int E>
   __device__ __forceinline__ Ctx prep(const T (&x)[E], const LaneMap& m) const {
-    T s = 0;
+    T s = (m.j == 0) ? T(0) : x[0] * x[0];  // only (lane 0, element 0) is dim 0
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += (e == 0 && m.j == 0) ? T(0) : x[e] * x[e];  // only (lane 0, element 0) is dim 0
+    for (int e = 1; e < E; ++e) s = __builtin_fma(x[e], x[e], s);
     Ctx c;
     c.S = group_sum(s, m.G);
     c.x0 = group_bcast0(x[0], m);
-    c.ex = exp_any(-c.x0);
+    c.ex = exp_neg(c.x0);
     return c;
   }
   template <int E>
   __device__ __forceinline__ T grad(T xe, int e, int d, const Ctx& c, const Local<E>&) const {
     return (e == 0 && d == 0) ? (T(-2) * dm1 * c.x0 * inv_s2 + c.ex * c.S) : T(-2) * xe * c.ex;
+  }
+  static constexpr bool kScaledKick = true;
+  template <int E>
+  __device__ __forceinline__ T kick(T ck, T xe, T ve, int e, int d, const Ctx& c) const {
+    return (e == 0 && d == 0) ? __builtin_fma(ck, T(-2) * dm1 * c.x0 * inv_s2 + c.ex * c.S, ve)
+                              : __builtin_fma(xe, ck * (T(-2) * c.ex), ve);
   }
   template <int E>
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
@@ -593,9 +609,19 @@ __device__ __forceinline__ T kick_product(const En& en, T c, T xe, int e, int d,
 }
 
 // v += c * dE/dx_d as one fused multiply-add
+template <class En>
+struct HasScaledKick {
+  template <class U>
+  static auto test(int) -> decltype(U::kScaledKick, char());
+  template <class U>
+  static long test(...);
+  static constexpr bool value = sizeof(test<En>(0)) == 1;
+};
+
 template <class En, typename T, int E, class Ctx, class Lc>
 __device__ __forceinline__ T kick_fma(const En& en, T c, T xe, T ve, int e, int d, const Ctx& ctx, const Lc& lc) {
   if constexpr (En::kLinearIso) return __builtin_fma(xe, c * en.inv_s2, ve);
+  else if constexpr (HasScaledKick<En>::value) return en.template kick<E>(c, xe, ve, e, d, ctx);  // force = xe * scale(ctx) for most elements
   else return __builtin_fma(c, en.template grad<E>(xe, e, d, ctx, lc), ve);
 }
 
@@ -724,12 +750,34 @@ __device__ __forceinline__ void refresh_stash(typename VecOf<T>::type (*st)[64],
 
 // exp(h) for |h| < 708 (normal result, no special cases): the library's range reduction and degree-11 polynomial
 // without its overflow / underflow / NaN handling.  Within 1 ulp of libm (tools/check_device_math.hip).
+// p = r * p + c with the constant c in a scalar register pair: one VOP3 instruction.  hipcc's own form of a Horner
+// step is v_mov x2 (the 64-bit literal into the accumulator VGPR) + v_fmac: three vector instructions.
+__device__ __forceinline__ double horner_sc(double r, double p, double c) {
+  asm("v_fma_f64 %0, %1, %0, %2" : "+v"(p) : "v"(r), "s"(c));
+  return p;
+}
+
 template <bool FENCED = true>
 __device__ __forceinline__ double exp_normal(double h) {
   if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);  // chain kept compact inside decide(): measured faster
   const double n = __builtin_rint(h * __longlong_as_double(0x3ff71547652b82feLL));        // h / ln 2
   double r = __builtin_fma(n, __longlong_as_double(0xbfe62e42fefa39efLL), h);             // - n ln2 (hi, lo)
   r = __builtin_fma(n, __longlong_as_double(0xbc7abc9e3b39803fLL), r);
+  if constexpr (!FENCED) {  // the funnel's force: this chain runs once per leapfrog step (decide()'s form below was
+                            // measured faster there as it stands)
+    double q = r * __longlong_as_double(0x3e5ade156a5dcb37LL) + __longlong_as_double(0x3e928af3fca7ab0cLL);
+    q = horner_sc(r, q, __longlong_as_double(0x3ec71dee623fde64LL));
+    q = horner_sc(r, q, __longlong_as_double(0x3efa01997c89e6b0LL));
+    q = horner_sc(r, q, __longlong_as_double(0x3f2a01a014761f6eLL));
+    q = horner_sc(r, q, __longlong_as_double(0x3f56c16c1852b7b0LL));
+    q = horner_sc(r, q, __longlong_as_double(0x3f81111111122322LL));
+    q = horner_sc(r, q, __longlong_as_double(0x3fa55555555502a1LL));
+    q = horner_sc(r, q, __longlong_as_double(0x3fc5555555555511LL));
+    q = horner_sc(r, q, __longlong_as_double(0x3fe000000000000bLL));
+    q = __builtin_fma(r, q, 1.0);
+    q = __builtin_fma(r, q, 1.0);
+    return __builtin_amdgcn_ldexp(q, (int)n);
+  }
   double p = r * __longlong_as_double(0x3e5ade156a5dcb37LL) + __longlong_as_double(0x3e928af3fca7ab0cLL);
   p = __builtin_fma(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
   p = __builtin_fma(r, p, __longlong_as_double(0x3efa01997c89e6b0LL));
@@ -753,6 +801,30 @@ __device__ __forceinline__ double exp_any(double h) {
   return (h != h) ? h : y;
 }
 __device__ __forceinline__ float exp_any(float h) { return expf(h); }
+
+// exp(-x) for the funnel force, once per leapfrog step: the argument is clamped to +-1100 (v_ldexp_f64 then rounds into
+// the subnormal range / overflows to inf by itself; inf for very negative x_0 is what turns a runaway chain into the
+// non-finite abort) and the sign rides on the operand modifiers.  A NaN x_0 needs no care here: it is already in every
+// energy term that contains x_0, so the rates are NaN and the attempt aborts whatever this returns.
+__device__ __forceinline__ double exp_neg(double x) {
+  const double xc = __builtin_fmin(__builtin_fmax(x, -1100.0), 1100.0);
+  const double n = __builtin_rint(xc * __longlong_as_double(0xbff71547652b82feLL));       // -x / ln 2
+  double r = __builtin_fma(n, __longlong_as_double(0xbfe62e42fefa39efLL), -xc);           // -x - n ln2 (hi, lo)
+  r = __builtin_fma(n, __longlong_as_double(0xbc7abc9e3b39803fLL), r);
+  double q = r * __longlong_as_double(0x3e5ade156a5dcb37LL) + __longlong_as_double(0x3e928af3fca7ab0cLL);
+  q = horner_sc(r, q, __longlong_as_double(0x3ec71dee623fde64LL));
+  q = horner_sc(r, q, __longlong_as_double(0x3efa01997c89e6b0LL));
+  q = horner_sc(r, q, __longlong_as_double(0x3f2a01a014761f6eLL));
+  q = horner_sc(r, q, __longlong_as_double(0x3f56c16c1852b7b0LL));
+  q = horner_sc(r, q, __longlong_as_double(0x3f81111111122322LL));
+  q = horner_sc(r, q, __longlong_as_double(0x3fa55555555502a1LL));
+  q = horner_sc(r, q, __longlong_as_double(0x3fc5555555555511LL));
+  q = horner_sc(r, q, __longlong_as_double(0x3fe000000000000bLL));
+  q = __builtin_fma(r, q, 1.0);
+  q = __builtin_fma(r, q, 1.0);
+  return __builtin_amdgcn_ldexp(q, (int)n);
+}
+__device__ __forceinline__ float exp_neg(float x) { return expf(-x); }
 
 // Transition rate exp(dH) ** .5 (markov_jump_hmc.py:341-347).  Where exp(dH) is a normal number the rate is
 // evaluated as exp(dH / 2) in one polynomial pass (within 1 ulp of the two-step value).  Where exp(dH)

@@ -90,7 +90,11 @@ def stable_digest(distribution):
     h = hashlib.sha1()
     h.update(type(distribution).__name__.encode())
     h.update(np.int64([kind, distribution.ndims]).tobytes())
-    h.update(np.ascontiguousarray(params, dtype=np.float64).tobytes())
+    if isinstance(params, tuple) and params and isinstance(params[0], str):     # user expressions + their parameters
+        for part in params:
+            h.update(part.encode() if isinstance(part, str) else np.ascontiguousarray(part, dtype=np.float64).tobytes())
+    else:
+        h.update(np.ascontiguousarray(params, dtype=np.float64).tobytes())
     return h.hexdigest()[:16]
 
 
@@ -102,6 +106,22 @@ def cache_initialization(distribution, directory, **kwargs):
     with open(path, 'wb') as cache_file:
         pickle.dump(result, cache_file)
     return path
+
+
+def load_reference_initialization(path):
+    """A cache file written by the REFERENCE (mjhmc/misc/gen_mj_init.py:54-73 under Python 2, e.g. the files it ships in
+    initializations/): returns (mjhmc_endpt, emc_var_estimate, true_var_estimate, control_endpt); older files hold only
+    the first three (control_endpt is then None)."""
+    with open(path, 'rb') as cache_file:
+        t = pickle.load(cache_file, encoding='latin1')       # Python 2 str -> bytes of the ndarray payloads
+    if len(t) == 4:
+        mj, emc_var, true_var, ctl = t
+    elif len(t) == 3:
+        (mj, emc_var, true_var), ctl = t, None
+    else:
+        raise ValueError('%s: expected a 3- or 4-tuple, got %d entries' % (path, len(t)))
+    return (np.asarray(mj, dtype=np.float64), float(emc_var), float(true_var),
+            None if ctl is None else np.asarray(ctl, dtype=np.float64))
 
 
 def load_initialization(distribution, directory):

@@ -114,3 +114,23 @@ def test_float32_graph_is_within_float32_of_the_float64_one():
     for tag in ('pot_36x25', 'pot_512x64'):
         assert rel(g[tag + '_E32'], g[tag + '_E']) < 5e-6
         assert rel(g[tag + '_g32'], g[tag + '_g']) < 2e-5
+
+
+def test_reference_written_initialisation_files_load():
+    """The cache files the reference ships (Python 2 pickles, initializations/*.pickle) through the product's loader;
+    their content must be what oracle/capture_dense_fixtures.py committed as ref_init_states.npz.  Runs where the
+    reference checkout exists (the build container); the GPU box has only the .npz."""
+    import os
+    from mjhmc_amd.misc.gen_mj_init import load_reference_initialization
+    root = '/root/reference/initializations'
+    if not os.path.isdir(root):
+        pytest.skip('no reference checkout here')
+    r = load('ref_init_states')
+    mj, emc_var, true_var, ctl = load_reference_initialization(os.path.join(root, 'ProductOfT_6123388416598428958.pickle'))
+    assert mj.shape == (36, 1000) and ctl is None and emc_var > 0 and true_var > 0
+    assert np.array_equal(mj[:, :256], r['pot36_X'])
+    mj, emc_var, true_var, ctl = load_reference_initialization(
+        os.path.join(root, 'SparseImageCode_-2828851975638192263.pickle'))
+    assert np.array_equal(mj, r['sic_mj_X']) and np.array_equal(ctl, r['sic_ctl_X'])
+    mj, _, _, _ = load_reference_initialization(os.path.join(root, 'Funnel_3713081631925750456.pickle'))
+    assert mj.shape == (10, 1000) and np.isnan(mj).any()          # the shipped funnel run diverged (SURVEY 8 a16)
