@@ -597,12 +597,13 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         break;
       }
       const int P = (int)params[0], I = (int)params[1], C = (int)params[2];
-      if (P < 1 || P > 32 || I != kSicImg || C != kSicCoeffs || ndims != P * C) {
+      if (P < 1 || P > 32 || I != kSicImg || !sic_coeffs_supported(C) || ndims != P * C) {
         rc = fail(MJHMC_ERR_UNSUPPORTED,
-                  "SPARSE_CODE device kernel is built for img_size=256, n_coeffs=1024, 1 <= n_patches <= 32");
+                  "SPARSE_CODE device kernel is built for img_size=256, n_coeffs=1024 or 512, 1 <= n_patches <= 32");
         break;
       }
       e->sic_P = P;
+      e->sic_nc = C;
       if (nparams != (size_t)5 + (size_t)I * C + (size_t)P * I) {
         rc = fail(MJHMC_ERR_INVALID, "SPARSE_CODE parameter vector has the wrong length");
         break;
@@ -619,13 +620,14 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         u += 0x7FFFu + ((u >> 16) & 1u);
         return (uint16_t)(u >> 16);
       };
-      std::vector<uint16_t> a1((size_t)64 * 2 * I * 8), a2((size_t)16 * 2 * C * 8);
-      for (int ks = 0; ks < 64; ++ks)
+      const int NB = C / 256;  // 32-row blocks per wave (8 waves share the C coefficient rows)
+      std::vector<uint16_t> a1((size_t)(C / 16) * 2 * I * 8), a2((size_t)16 * 2 * C * 8);
+      for (int ks = 0; ks < C / 16; ++ks)
         for (int h = 0; h < 2; ++h)
           for (int i = 0; i < I; ++i)
             for (int j = 0; j < 8; ++j) {
-              const int ws = ks >> 3, b = (ks >> 1) & 3, sx = ks & 1;
-              const int c = 128 * ws + 32 * b + 16 * sx + 8 * (j >> 2) + 4 * h + (j & 3);
+              const int ws = ks / (2 * NB), b = (ks >> 1) % NB, sx = ks & 1;
+              const int c = 32 * NB * ws + 32 * b + 16 * sx + 8 * (j >> 2) + 4 * h + (j & 3);
               a1[(((size_t)ks * 2 + h) * I + i) * 8 + j] = bf16_of(B[(size_t)i * C + c]);
             }
       for (int ks = 0; ks < 16; ++ks)

@@ -1,7 +1,8 @@
 // SparseImageCode (sparse-coding posterior over coefficients, mjhmc/misc/tf_distributions.py:204-272) on
 // the bf16 matrix cores: bf16 state in HBM, bf16 MFMA operands, fp32 accumulation and fp32 integrator
-// registers (BASELINE.json configs[4]).  n_coeffs = 1024, img_size = 256, P = n_patches patches per particle (the
-// reference's default is 9, tf_distributions.py:208; BASELINE configs[4] is one):
+// registers (BASELINE.json configs[4]).  img_size = 256; n_coeffs = 1024 or 512 (the two dictionaries the reference
+// accepts, tf_distributions.py:219; template parameter NB = n_coeffs / 256; the text below is written for 1024);
+// P = n_patches patches per particle (the reference's default is 9, :208; BASELINE configs[4] is one):
 //
 //   resid_p = B a_p - y_p ,  E = mean_p 1/2 |resid_p|^2 + lambda * sum log(1 + a^2)   (Cauchy prior, :259-267)
 //   dE/da_p = B^T resid_p / P + lambda * 2a / (1 + a^2)                               (or lambda * sign(a), Laplace)
@@ -36,20 +37,23 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 
 constexpr int kP = 32;
-constexpr int kC = kSicCoeffs;  // 1024
 constexpr int kI = kSicImg;     // 256
+// NB = 32-row blocks of X and V per wave = n_coeffs / 256 (4: the 1024-atom dictionary, 2: the 512-atom one)
+#define kC (256 * NB)
 
 __device__ __forceinline__ int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
+template <int NB>
 struct CTile {
-  f32x16 b[4];  // this wave's 128 coefficient rows x 32 particles
+  f32x16 b[NB];  // this wave's 32 NB coefficient rows x 32 particles
 };
 
 // bf16 state rows [*][1024]: lane (c, h) reads its 16 groups of 4 consecutive coefficients (8 bytes each)
-__device__ __forceinline__ void ctile_load(const __bf16* base, int64_t p, int w, int h, CTile& t) {
-  const __bf16* row = base + (size_t)p * kC + 128 * w + 4 * h;
+template <int NB>
+__device__ __forceinline__ void ctile_load(const __bf16* base, int64_t p, int w, int h, CTile<NB>& t) {
+  const __bf16* row = base + (size_t)p * kC + 32 * NB * w + 4 * h;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const bf16x4 v = *reinterpret_cast<const bf16x4*>(row + 32 * b + 8 * g);
@@ -58,10 +62,11 @@ __device__ __forceinline__ void ctile_load(const __bf16* base, int64_t p, int w,
     }
 }
 
-__device__ __forceinline__ void ctile_store(__bf16* base, int64_t p, int w, int h, const CTile& t) {
-  __bf16* row = base + (size_t)p * kC + 128 * w + 4 * h;
+template <int NB>
+__device__ __forceinline__ void ctile_store(__bf16* base, int64_t p, int w, int h, const CTile<NB>& t) {
+  __bf16* row = base + (size_t)p * kC + 32 * NB * w + 4 * h;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bf16x4 v;
@@ -76,8 +81,9 @@ constexpr int kYLds = 12;   // patches whose pixels fit the LDS copy (more: read
 
 // ALL of the workgroup's LDS is this one object (a second __shared__ object beside an LDS-DMA target makes hipcc
 // drain the DMA queue before LDS reads, cdna_hip_programming.md section 5)
+template <int NB>
 struct SicShared {
-  f32x4 pubA[8][4][2][64];    // 64 KB: a as B fragments, [wave][block][k-step half][lane]
+  f32x4 pubA[8][NB][2][64];   // 64 KB: a as B fragments, [wave][block][k-step half][lane]
   f32x4 pubR[8][2][64];       // 16 KB: scaled residual as B fragments
   f32x4 ring[8][kRing][64];   // 64 KB: per-wave ring of dictionary (A operand) fragments, filled by LDS-DMA
   float ys[kYLds * kI];       // 12 KB: the patches
@@ -117,7 +123,7 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 constexpr unsigned kFrag1 = 2 * kI * 16;  // bytes between consecutive GEMM1 fragments (k-steps) of a lane
-constexpr unsigned kFrag2 = 2 * kC * 16;  // bytes between consecutive GEMM2 k-steps; blocks of a k-step are 512 B apart
+#define kFrag2 (2u * kC * 16u)            // bytes between consecutive GEMM2 k-steps; blocks of a k-step are 512 B apart
 
 struct AStream {
   const char* a1;   // GEMM1 fragments: A1[k-step][h][image row][8 bf16]           (wave-uniform base)
@@ -127,20 +133,19 @@ struct AStream {
   int only1;        // the kernel runs GEMM1 only (an evaluation without gradient): the sequence is GEMM1, GEMM1, ...
 };
 
-// fragment `pos` (0..63 GEMM1 k-steps, 64..127 GEMM2 (k-step, block) pairs) into ring slot pos % kRing
+// GEMM1 fragment (k-step) `pos` < kRing into ring slot pos: the head of the stream
 __device__ __forceinline__ void astream_issue(const AStream& s, int pos) {
-  const unsigned dst = s.lds0 + (unsigned)(pos & (kRing - 1)) * 1024u;
-  if (pos < 64) glds16(s.a1 + (size_t)pos * kFrag1, s.v1, dst);
-  else glds16(s.a2 + (size_t)((pos - 64) >> 2) * kFrag2 + ((pos - 64) & 3) * 512, s.v2, dst);
+  glds16(s.a1 + (size_t)pos * kFrag1, s.v1, s.lds0 + (unsigned)pos * 1024u);
 }
 
-__device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& sh, int w, int c, int h, bool only1) {
+template <int NB>
+__device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared<NB>& sh, int w, int c, int h, bool only1) {
   AStream s;
   const size_t copy = (size_t)((blockIdx.x >> 3) % (unsigned)mdl.copies) * (size_t)(kI * kC * 2);  // blocks b, b + 8 share an XCD
   s.a1 = reinterpret_cast<const char*>(mdl.A1) + copy;
   s.a2 = reinterpret_cast<const char*>(mdl.A2) + copy;
   s.v1 = (unsigned)(h * kI + 32 * w + c) * 16u;
-  s.v2 = (unsigned)(h * kC + 128 * w + c) * 16u;
+  s.v2 = (unsigned)(h * kC + 32 * NB * w + c) * 16u;
   s.lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&sh.ring[w][0][0]));
   s.only1 = only1 ? 1 : 0;
 #pragma unroll
@@ -159,7 +164,8 @@ __device__ __forceinline__ void astream_rewind(const AStream& s) {
 }
 
 // the patches into LDS (once per kernel)
-__device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared& sh) {
+template <int NB>
+__device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared<NB>& sh) {
   if (mdl.P <= kYLds)
     for (int i = threadIdx.x; i < mdl.P * kI; i += blockDim.x) sh.ys[i] = mdl.y[i];
   __syncthreads();
@@ -203,10 +209,12 @@ __device__ __forceinline__ f32x4 frag_of(const f32x16& acc, int s, float scale) 
 }
 
 // residual of the tile at the X held in x (GEMM1).  Leaves it in `res` (fp32 accumulator layout).
-__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
-                                             int lane, int patch, const CTile& x, f32x16& res) {
+template <int NB>
+__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
+                                             int lane, int patch, const CTile<NB>& x, f32x16& res) {
+  constexpr int kSteps = 16 * NB;  // GEMM1 k-steps = fragments per wave
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NB; ++b) {
     sh.pubA[w][b][0][lane] = frag_of(x.b[b], 0, 1.0f);
     sh.pubA[w][b][1][lane] = frag_of(x.b[b], 1, 1.0f);
   }
@@ -220,7 +228,7 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
       for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
     }
   }
-  // 64 k-steps; the fragment of k-step ks is in ring slot ks % kRing, and its slot is refilled with the fragment
+  // 16 NB k-steps; the fragment of k-step ks is in ring slot ks % kRing, and its slot is refilled with the fragment
   // kRing positions further down the stream as soon as it has been read.  The LDS reads of k-step ks + 1 are issued
   // before the MFMA of k-step ks (one register set ahead), so an MFMA never waits for the LDS round trip.
   const f32x4* ring = &sh.ring[w][0][lane];
@@ -229,18 +237,18 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
   fa = ring[0];
   fb = sh.pubA[0][0][0][lane];
   auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi, bool last) {
-    // refill: wave-uniform address of the fragment that goes into slot 0; slot j gets refill + (j & 3) step + (j >> 2) step_hi
+    // refill: wave-uniform address of the fragment that goes into slot 0; slot j gets refill + (j % NB) step + (j / NB) step_hi
 #pragma unroll
     for (int j = 0; j < kRing; ++j) {
       const int ks = ch * kRing + j;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fa, fb are here; slot j has been read: it may be refilled
       __builtin_amdgcn_sched_barrier(0);
-      glds16(refill + (j & 3) * step + (j >> 2) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
+      glds16(refill + (j % NB) * step + (j / NB) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
       if (!(last && j == kRing - 1)) {
         wait_vm<kRing - 1>();  // fragment ks + 1 has landed
         const int kn = ks + 1;
         na = ring[((j + 1) & (kRing - 1)) * 64];
-        nb = sh.pubA[kn >> 3][(kn >> 1) & 3][kn & 1][lane];
+        nb = sh.pubA[kn / (2 * NB)][(kn >> 1) % NB][kn & 1][lane];
       }
       __builtin_amdgcn_sched_barrier(0);
       res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), res,
@@ -250,22 +258,24 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared& sh,
     }
   };
 #pragma unroll 1
-  for (int ch = 0; ch < 64 / kRing - 1; ++ch)
-    chunk(ch, as.a1 + (size_t)(ch + 1) * kRing * kFrag1, as.v1, kFrag1, 4 * kFrag1, false);
-  if (as.only1) chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1, true);  // the next GEMM1's first fragments
-  else chunk(64 / kRing - 1, as.a2, as.v2, 512, kFrag2, true);  // GEMM2's first: (k-step 0, blocks 0..3), (k-step 1, blocks 0..3)
+  for (int ch = 0; ch < kSteps / kRing - 1; ++ch)
+    chunk(ch, as.a1 + (size_t)(ch + 1) * kRing * kFrag1, as.v1, kFrag1, NB * kFrag1, false);
+  if (as.only1) chunk(kSteps / kRing - 1, as.a1, as.v1, kFrag1, NB * kFrag1, true);  // the next GEMM1's first fragments
+  else chunk(kSteps / kRing - 1, as.a2, as.v2, 512, kFrag2, true);  // GEMM2's first: (k-step 0, blocks 0..NB-1), (k-step 1, ...), ...
 }
 
 // acc[c][n] += sum_i B[i][c] * (scale * res[i][n]) + scale * prior'(x)   (GEMM2 into the caller's tile)
-template <bool CAUCHY>
-__device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
-                                         int lane, const f32x16& res, const CTile& x, float scale, CTile& acc) {
+template <bool CAUCHY, int NB>
+__device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
+                                         int lane, const f32x16& res, const CTile<NB>& x, float scale, CTile<NB>& acc) {
+  constexpr int kPos = 16 * NB;         // GEMM2 stream positions per wave: 16 k-steps x NB blocks
+  constexpr int kKs = kRing / NB;       // k-steps per chunk of kRing positions
   sh.pubR[w][0][lane] = frag_of(res, 0, scale * mdl.invP);  // d/da_p of the MEAN over patches
   sh.pubR[w][1][lane] = frag_of(res, 1, scale * mdl.invP);
   {  // the prior's force first (x is not read again until the drift): lambda * 2a / (1 + a^2), or lambda * sign(a)
     const float sl = scale * mdl.lambda;
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const float a = x.b[b][q];
@@ -275,34 +285,34 @@ __device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared& sh, con
   }
   __syncthreads();
   const f32x4* ring = &sh.ring[w][0][lane];
-  // stream positions 64 + 8 ch + j = (k-step 2 ch + (j >> 2), block j & 3); refilled kRing positions ahead: the same
-  // (j >> 2, block) of chunk ch + 1, or, from the last chunk, the next GEMM1's first fragments.  The dictionary fragment
+  // stream positions 8 ch + j = (k-step kKs ch + j / NB, block j % NB); refilled kRing positions ahead: the same
+  // (j / NB, block) of chunk ch + 1, or, from the last chunk, the next GEMM1's first fragments.  The dictionary fragment
   // of position + 1 is read from the ring before the MFMA of this position.
   f32x4 fa, na;
   wait_vm<kRing - 1>();
   fa = ring[0];
   auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi, bool last) {
-    f32x4 fb[2];
-    fb[0] = sh.pubR[ch][0][lane];
-    fb[1] = sh.pubR[ch][1][lane];
+    f32x4 fb[kKs];
+#pragma unroll
+    for (int t = 0; t < kKs; ++t) fb[t] = sh.pubR[(kKs * ch + t) >> 1][(kKs * ch + t) & 1][lane];
 #pragma unroll
     for (int j = 0; j < kRing; ++j) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fa (and fb) are here; slot j may be refilled
       __builtin_amdgcn_sched_barrier(0);
-      glds16(refill + (j & 3) * step + (j >> 2) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
+      glds16(refill + (j % NB) * step + (j / NB) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
       if (!(last && j == kRing - 1)) {
         wait_vm<kRing - 1>();
         na = ring[((j + 1) & (kRing - 1)) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc.b[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                             __builtin_bit_cast(bf16x8, fb[j >> 2]), acc.b[j & 3], 0, 0, 0);
+      acc.b[j % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
+                                                              __builtin_bit_cast(bf16x8, fb[j / NB]), acc.b[j % NB], 0, 0, 0);
       fa = na;
     }
   };
 #pragma unroll 1
-  for (int ch = 0; ch < 64 / kRing - 1; ++ch) chunk(ch, as.a2 + (size_t)(2 * ch + 2) * kFrag2, as.v2, 512, kFrag2, false);
-  chunk(64 / kRing - 1, as.a1, as.v1, kFrag1, 4 * kFrag1, true);  // the next GEMM1's fragments 0..7: consecutive k-steps
+  for (int ch = 0; ch < kPos / kRing - 1; ++ch) chunk(ch, as.a2 + (size_t)(kKs * (ch + 1)) * kFrag2, as.v2, 512, kFrag2, false);
+  chunk(kPos / kRing - 1, as.a1, as.v1, kFrag1, NB * kFrag1, true);  // the next GEMM1's fragments 0..7: consecutive k-steps
 }
 
 __device__ __forceinline__ float half_swap_sum(float s) {
@@ -311,7 +321,8 @@ __device__ __forceinline__ float half_swap_sum(float s) {
 }
 
 // sum of a per-column value over the columns of the caller's particle (n_patches of them, consecutive)
-__device__ __forceinline__ float group_total(SicShared& sh, int w, int c, int h, int P, int g0, float col_tot) {
+template <int NB>
+__device__ __forceinline__ float group_total(SicShared<NB>& sh, int w, int c, int h, int P, int g0, float col_tot) {
   if (P == 1) return col_tot;
   if (w == 0 && h == 0) sh.colsum[c] = col_tot;
   __syncthreads();
@@ -322,15 +333,15 @@ __device__ __forceinline__ float group_total(SicShared& sh, int w, int c, int h,
 }
 
 // E(x) per PARTICLE from the residuals at x:  mean_p 1/2 |res_p|^2 + lambda * prior(x)  (tf_distributions.py:257-270)
-template <bool CAUCHY>
-__device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, int w, int c, int h, const Col& col,
-                                            const f32x16& res, const CTile& x) {
+template <bool CAUCHY, int NB>
+__device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared<NB>& sh, int w, int c, int h, const Col& col,
+                                            const f32x16& res, const CTile<NB>& x) {
   float s = 0.f;
 #pragma unroll
   for (int q = 0; q < 16; ++q) s += 0.5f * res[q] * res[q];
   float pr = 0.f;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float a = x.b[b][q];
@@ -347,10 +358,11 @@ __device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, 
 }
 
 // sum(v^2) / 2 per PARTICLE
-__device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h, int P, const Col& col, const CTile& v) {
+template <int NB>
+__device__ __forceinline__ float sic_kinetic(SicShared<NB>& sh, int w, int c, int h, int P, const Col& col, const CTile<NB>& v) {
   float s = 0.f;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += v.b[b][q] * v.b[b][q];
   const float part = half_swap_sum(s);
@@ -363,9 +375,10 @@ __device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h,
   return group_total(sh, w, c, h, P, col.g0, tot) / 2.0f;
 }
 
-__device__ __forceinline__ void round_to_state(CTile& t) {
+template <int NB>
+__device__ __forceinline__ void round_to_state(CTile<NB>& t) {
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       // opaque: otherwise hipcc shares these conversions with the ones that published the tile as an MFMA operand two
@@ -377,35 +390,36 @@ __device__ __forceinline__ void round_to_state(CTile& t) {
 
 // L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
 // separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place.
-template <bool CAUCHY>
-__device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
-                                                int lane, const Col& col, CTile& x, CTile& v, int L, float eps,
+template <bool CAUCHY, int NB>
+__device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
+                                                int lane, const Col& col, CTile<NB>& x, CTile<NB>& v, int L, float eps,
                                                 float chalf) {
   f32x16 res;
   sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-  if (L > 0) sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, chalf, v);
+  if (L > 0) sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, chalf, v);
   else astream_rewind(as);
   for (int s = 1; s <= L; ++s) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) x.b[b] = x.b[b] + eps * v.b[b];
+    for (int b = 0; b < NB; ++b) x.b[b] = x.b[b] + eps * v.b[b];
     sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-    sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, s < L ? 2.0f * chalf : chalf, v);
+    sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, s < L ? 2.0f * chalf : chalf, v);
   }
   // the successor position is stored in bf16 (and GEMM1 already saw bf16(x)): evaluate the prior on
   // what will be stored, so EX is the energy of the stored state
   round_to_state(x);
-  return sic_energy<CAUCHY>(mdl, sh, w, c, h, col, res, x);
+  return sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, res, x);
 }
 
 // v += mix * (standard normals of this lane's dims of particle `pid`; dims patch * 1024 + ...), group by group: one
 // Box-Muller quadruple's temporaries at a time keeps this rare branch from dictating the kernel's register budget
+template <int NB>
 __device__ __forceinline__ void sic_add_normals(const RngKey& key, uint32_t pid, int patch, int w, int h, float mix,
-                                                CTile& v) {
+                                                CTile<NB>& v) {
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll 1
     for (int g4 = 0; g4 < 4; ++g4) {
-      const int d = kC * patch + 128 * w + 32 * b + 8 * g4 + 4 * h;
+      const int d = kC * patch + 32 * NB * w + 32 * b + 8 * g4 + 4 * h;
       float z0, z1, z2, z3;
       normal_pair_f32(key, pid, (uint32_t)(d >> 1), z0, z1);
       normal_pair_f32(key, pid, (uint32_t)((d >> 1) + 1), z2, z3);
@@ -423,29 +437,29 @@ __device__ __forceinline__ void sic_add_normals(const RngKey& key, uint32_t pid,
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <bool CAUCHY>
+template <bool CAUCHY, int NB>
 __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, const SicModel mdl) {
-  __shared__ SicShared sh;
+  __shared__ SicShared<NB> sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   stage_patches(mdl, sh);
   const AStream as = astream_open(mdl, sh, w, c, h, a.G == nullptr);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
-    CTile x;
+    CTile<NB> x;
     ctile_load(a.X, col.q, w, h, x);
     f32x16 res;
     sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
     if (a.G) {
-      CTile g;
+      CTile<NB> g;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
-      sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
+      sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
       if (col.alive) {
-        float* row = a.G + (size_t)col.q * kC + 128 * w + 4 * h;  // dE/dX is handed out in float32
+        float* row = a.G + (size_t)col.q * kC + 32 * NB * w + 4 * h;  // dE/dX is handed out in float32
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             f32x4 o;
@@ -455,13 +469,13 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
           }
       }
     }
-    const float ex = sic_energy<CAUCHY>(mdl, sh, w, c, h, col, res, x);
+    const float ex = sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, res, x);
     if (a.E && w == 0 && h == 0 && col.leader) a.E[col.part] = ex;
     if (a.EV) {
-      CTile v;
+      CTile<NB> v;
       if (a.V_gen) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int q = 0; q < 16; ++q) v.b[b][q] = 0.f;
         sic_add_normals(a.key, (uint32_t)(a.first_pid + col.part), col.patch, w, h, 1.0f, v);
@@ -503,9 +517,9 @@ struct FromList {
   __device__ int64_t operator()(int64_t s) const { return list[s]; }
 };
 
-template <bool CAUCHY>
+template <bool CAUCHY, int NB>
 __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, const SicModel mdl) {
-  __shared__ SicShared sh;
+  __shared__ SicShared<NB> sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
@@ -515,12 +529,12 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
   const AStream as = astream_open(mdl, sh, w, c, h, false);
   for (int64_t tile = blockIdx.x; tile * ppt < ncold; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, (int64_t)ncold, FromList{a.cold_list});  // the last tile repeats an entry
-    CTile x, v;
+    CTile<NB> x, v;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
-    const float ex = sic_trajectory<CAUCHY>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
+    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);  // the same rounding the jump kernel applies to the forward proposal
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (w == 0 && h == 0 && col.leader) a.Hwork[col.part] = ex + ev;
@@ -531,9 +545,9 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
 
 // MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
 // the reference's sparse-coding experiments, search/control_sp_img/control_objective.py:10)
-template <bool CAUCHY, bool REPLAY, int MODE>
+template <bool CAUCHY, bool REPLAY, int MODE, int NB>
 __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, const SicModel mdl) {
-  __shared__ SicShared sh;
+  __shared__ SicShared<NB> sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
@@ -547,10 +561,10 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
     const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
     const float H0 = EX0 + EV0;
     const float Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.f;
-    CTile x, v;
+    CTile<NB> x, v;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
-    const float EXL = sic_trajectory<CAUCHY>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float EXL = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
     const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
@@ -594,11 +608,11 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
         ctile_load(a.V_in, col.q, w, h, v);
       } else {  // accepted L F: flip
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
+        for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
       }
       if (k & 2) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
+        for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
       }
       refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
     } else {
@@ -608,18 +622,18 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
       }
       if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v.b[b] = -v.b[b];
+        for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
       }
       refresh = (k == 2);
     }
     const bool tile_refreshes = __ballot(refresh) != 0ull;
     if (refresh) {  // HMCState.R (hmc_state.py:121-129)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v.b[b] = v.b[b] * a.r_keep;
+      for (int b = 0; b < NB; ++b) v.b[b] = v.b[b] * a.r_keep;
       if constexpr (REPLAY) {
-        const __bf16* zrow = a.noise + (size_t)col.q * kC + 128 * w + 4 * h;
+        const __bf16* zrow = a.noise + (size_t)col.q * kC + 32 * NB * w + 4 * h;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const bf16x4 z = *reinterpret_cast<const bf16x4*>(zrow + 32 * b + 8 * g4);
@@ -655,33 +669,33 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
 }
 
 // HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
-template <bool CAUCHY>
+template <bool CAUCHY, int NB>
 __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, const SicModel mdl) {
-  __shared__ SicShared sh;
+  __shared__ SicShared<NB> sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   stage_patches(mdl, sh);
   const AStream as = astream_open(mdl, sh, w, c, h, false);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
-    CTile x, v;
+    CTile<NB> x, v;
     ctile_load(a.X, col.q, w, h, x);
     ctile_load(a.V, col.q, w, h, v);
-    const float ex = sic_trajectory<CAUCHY>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (a.G) {  // dE/dX of the stored end point
       f32x16 res;
       sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-      CTile g;
+      CTile<NB> g;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
-      sic_kick<CAUCHY>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
+      sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
       if (col.alive) {
-        float* row = a.G + (size_t)col.q * kC + 128 * w + 4 * h;
+        float* row = a.G + (size_t)col.q * kC + 32 * NB * w + 4 * h;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             f32x4 o;
@@ -711,44 +725,54 @@ static int sic_cus() {
   return std::max(1, cus);
 }
 
-template <bool CAUCHY, int MODE>
+template <bool CAUCHY, int MODE, int NB>
 static void sic_launch_mode(const SicJumpArgs& a, const SicModel& mdl, unsigned grid, hipStream_t st) {
   const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);
-  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE>), dim3(grid), dim3(512), 0, st, a, mdl);
-  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE>), dim3(grid), dim3(512), 0, st, a, mdl);
+  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
 }
 
-template <bool CAUCHY>
+template <bool CAUCHY, int NB>
 static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
     (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
     hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
                        a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
-    hipLaunchKernelGGL(sic_flf_kernel<CAUCHY>, dim3(grid), dim3(512), 0, st, a, mdl);
-    sic_launch_mode<CAUCHY, kModeMJHMC>(a, mdl, grid, st);
+    hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+    sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
   } else if (a.mode == kModeCT) {
-    sic_launch_mode<CAUCHY, kModeCT>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeCT, NB>(a, mdl, grid, st);
   } else {
-    sic_launch_mode<CAUCHY, kModeControl>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeControl, NB>(a, mdl, grid, st);
   }
 }
 
+// the prior (Cauchy / Laplace) and the dictionary width (1024 / 512 atoms) select the instantiation
+#define SIC_DISPATCH(CALL)                                   \
+  do {                                                       \
+    if (mdl.nc == 1024) {                                    \
+      if (mdl.cauchy) CALL(true, 4); else CALL(false, 4);    \
+    } else {                                                 \
+      if (mdl.cauchy) CALL(true, 2); else CALL(false, 2);    \
+    }                                                        \
+  } while (0)
+
 void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-  if (mdl.cauchy) sic_launch_jump_t<true>(a, mdl, st);
-  else sic_launch_jump_t<false>(a, mdl, st);
+#define SIC_JUMP(C, NBV) sic_launch_jump_t<C, NBV>(a, mdl, st)
+  SIC_DISPATCH(SIC_JUMP);
 }
 
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-  if (mdl.cauchy) hipLaunchKernelGGL(sic_eval_kernel<true>, dim3(grid), dim3(512), 0, st, a, mdl);
-  else hipLaunchKernelGGL(sic_eval_kernel<false>, dim3(grid), dim3(512), 0, st, a, mdl);
+#define SIC_EVAL(C, NBV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
+  SIC_DISPATCH(SIC_EVAL);
 }
 
 void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-  if (mdl.cauchy) hipLaunchKernelGGL(sic_leap_kernel<true>, dim3(grid), dim3(512), 0, st, a, mdl);
-  else hipLaunchKernelGGL(sic_leap_kernel<false>, dim3(grid), dim3(512), 0, st, a, mdl);
+#define SIC_LEAP(C, NBV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
+  SIC_DISPATCH(SIC_LEAP);
 }
 
 }  // namespace mjhmc

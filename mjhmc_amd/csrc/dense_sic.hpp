@@ -7,18 +7,20 @@
 
 namespace mjhmc {
 
-constexpr int kSicCoeffs = 1024;  // n_coeffs (state dims, one patch per particle)
 constexpr int kSicImg = 256;      // img_size
+// n_coeffs: 1024 or 512, the dictionaries the reference accepts (tf_distributions.py:219)
+inline bool sic_coeffs_supported(int nc) { return nc == 1024 || nc == 512; }
 
 struct SicModel {
-  const void* A1;   // bf16 [64 k-steps][2 halves][256 image rows][8]: B[i][c] in GEMM1's fragment k-order
-  const void* A2;   // bf16 [16 k-steps][2 halves][1024 coeffs][8]:    B[i][c] in GEMM2's fragment k-order
+  const void* A1;   // bf16 [nc/16 k-steps][2 halves][256 image rows][8]: B[i][c] in GEMM1's fragment k-order
+  const void* A2;   // bf16 [16 k-steps][2 halves][nc coeffs][8]:         B[i][c] in GEMM2's fragment k-order
   const float* y;   // [n_patches][256] the patches
   float lambda;
   int cauchy;
-  int P;            // n_patches: a particle is P consecutive 1024-coefficient rows, one per patch (tf_distributions.py:228-229)
+  int P;            // n_patches: a particle is P consecutive nc-coefficient rows, one per patch (tf_distributions.py:228-229)
   float invP;       // the reconstruction error is the MEAN over patches (tf_distributions.py:259-260)
   int copies;       // identical copies of A1 / A2 laid out back to back
+  int nc;           // n_coeffs: 1024 or 512
 };
 constexpr int kSicCopies = 1;
 

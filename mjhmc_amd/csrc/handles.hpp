@@ -52,8 +52,10 @@ struct mjhmc_energy {
   int sic_cauchy = 1;
   int sic_P = 1;  // n_patches
   int sic_copies = 1;
+  int sic_nc = 1024;  // n_coeffs
   SicModel sic_model() const {
-    return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy, sic_P, 1.0f / (float)sic_P, sic_copies};
+    return SicModel{sic[0], sic[1], (const float*)sic[2], sic_lambda, sic_cauchy, sic_P, 1.0f / (float)sic_P, sic_copies,
+                    sic_nc};
   }
   bool is_sic() const { return ep.kind == MJHMC_E_SPARSE_CODE; }
   bool is_dense() const { return is_pot() || is_sic(); }

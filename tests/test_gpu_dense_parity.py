@@ -319,3 +319,70 @@ def test_sic_several_patches_iterations_vs_oracle(P, N):
         _resync(s, o)
     out = s.sample(3)                                                # ring slots of P * 1024-wide rows
     assert out.shape == (P * 1024, 3 * N) and np.array_equal(out[:, -N:], s.state.X)
+
+
+# ---------------------------------------------------------------------------------------------
+# the 512-atom dictionary (the reference accepts n_basis in [1024, 512], tf_distributions.py:219)
+# ---------------------------------------------------------------------------------------------
+def _sic512(P, n, cauchy, X0):
+    from mjhmc_amd.misc.distributions import SparseImageCode
+    B, imgs, a0 = sic_problem(3, n_patches=P, n_coeffs=512)
+    return SparseImageCode(n_patches=P, n_batches=n, cauchy=cauchy, n_basis=512, basis=B, imgs=imgs, init=X0), B, imgs, a0
+
+
+@pytest.mark.parametrize('P,n,cauchy', [(1, 40, True), (1, 5, False), (9, 4, True)])
+def test_sic_512_atoms_single_evaluation(P, n, cauchy):
+    from oracle import autograd_energies as ag
+    B, imgs, a0 = sic_problem(3, n_patches=P, n_coeffs=512)
+    X = a0[:, None] + 0.3 * np.random.RandomState(8).randn(P * 512, n)
+    d, B, imgs, _ = _sic512(P, n, cauchy, X)
+    E, G = d.E(X), d.dEdX(X)
+    assert E.shape == (1, n) and G.shape == (P * 512, n)
+    o = orc.SparseImageCode(B, imgs[:, :P].T, lmbda=0.01, cauchy=cauchy, operand_rounding=to_bf16)
+    Xb = to_bf16(X)
+    assert rel(E[0], o.E_val(Xb)[0]) < 2e-5 and rel(G, o.dEdX_val(Xb)) < 2e-4
+    # the reference's forward graph (per column) under autograd, at bf16 tolerance
+    Ea, ga = ag.sparse_image_code_per_column(B, imgs[:, :P].T, 0.01, cauchy, X)
+    assert rel(E[0], Ea) < 4e-3 and rel(G, ga) < 2e-2
+
+
+@pytest.mark.parametrize('P,N', [(1, 70), (9, 7)])
+def test_sic_512_atoms_iterations_vs_oracle(P, N):
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    B, imgs, a0 = sic_problem(3, n_patches=P, n_coeffs=512)
+    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(P).randn(P * 512, N))
+    d, B, imgs, _ = _sic512(P, N, True, X0)
+    en = orc.SparseImageCode(B, imgs[:, :P].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+    kw = dict(epsilon=0.0625, beta=0.2, num_leapfrog_steps=6, resample=False)
+    s = MarkovJumpHMC(distribution=d, seed=52, **kw)
+    o = orc.MarkovJumpHMC(en, X0, rng=orc.PhiloxRNG(52, np.arange(N)), state_rounding=to_bf16, **kw)
+    assert np.abs(s.state.V - o.state.V).max() < 3e-2
+    _resync(s, o)
+    for t in range(4):
+        check_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='sic512 P=%d it %d' % (P, t))
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        _resync(s, o)
+    out = s.sample(3)
+    assert out.shape == (P * 512, 3 * N) and np.array_equal(out[:, -N:], s.state.X)
+
+
+def test_sic_512_atoms_control_arm_and_leapfrog():
+    from mjhmc_amd.samplers.markov_jump_hmc import ControlHMC
+    N = 40
+    B, imgs, a0 = sic_problem(3, n_coeffs=512)
+    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(2).randn(512, N))
+    d, B, imgs, _ = _sic512(1, N, True, X0)
+    en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+    kw = dict(epsilon=0.0625, beta=0.3, num_leapfrog_steps=5)
+    s = ControlHMC(distribution=d, seed=9, **kw)
+    o = orc.ControlHMC(en, X0, rng=orc.PhiloxRNG(9, np.arange(N)), state_rounding=to_bf16, **kw)
+    _resync(s, o)
+    for t in range(3):
+        check_control_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='sic512 control it %d' % t)
+        _resync(s, o)
+    # HMCState.L() on a snapshot
+    Z = s.state.copy().L()
+    Zo = o.state.clone().L()
+    assert np.abs(Z.X - Zo.X).max() <= np.abs(Zo.X).max() / 128
+    scale = float(np.abs(Zo.H()).max())
+    assert np.abs(Z.EX - Zo.EX).max() <= 5e-4 * scale and np.abs(Z.EV - Zo.EV).max() <= 5e-4 * scale
