@@ -54,6 +54,7 @@ typedef enum {
  *                                               ProductOfT    mjhmc/misc/distributions.py:373-433
  *   SPARSE_CODE {n_patches, img, n_coeffs, lambda, cauchy, B[img*n_coeffs], Y[n_patches*img]}
  *                                               SparseImageCode mjhmc/misc/tf_distributions.py:204-272
+ *                                               (img = 256; n_coeffs = 1024 or 512, :219; 1 <= n_patches <= 32)
  */
 typedef enum {
   MJHMC_E_ISO_GAUSS = 0,
@@ -219,7 +220,8 @@ int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double*
  * (n_steps = num_leapfrog_steps) of mjhmc/samplers/hmc_state.py:86-100, in the reference's literal operation order
  * (half kicks not merged, every product rounded before its sum).  X, V and the outputs are (ndims, n) float64 C order
  * (EX_out / EV_out: n values); EX_out, EV_out, dEdX_out may be NULL.  X_out / V_out may alias X / V.
- * Elementwise energies only (PRODUCT_OF_T / SPARSE_CODE integrate inside their tile kernels): MJHMC_ERR_UNSUPPORTED. */
+ * PRODUCT_OF_T / SPARSE_CODE run their tile kernels' integrator (float32 / bfloat16 state, half kicks between drifts
+ * merged; figures/poe_fig.py:58-76 integrates snapshots of a ProductOfT sampler this way). */
 int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V, int64_t n, double eps, int n_steps,
                    double* X_out, double* V_out, double* EX_out, double* EV_out, double* dEdX_out);
 

@@ -1139,7 +1139,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   if (compact) {
     if (!s->flf_list) {
       HIPCHK(hipMalloc((void**)&s->flf_list, (size_t)s->Npad * sizeof(int)));
-      HIPCHK(hipMalloc(&s->Hpre, (size_t)s->Npad * ssize(s)));
+      HIPCHK(hipMalloc(&s->Hpre, (size_t)2 * s->Npad * ssize(s)));
     }
     if (s->flf_cap < n_iter) {  // [n_iter] cold counts, then [n_iter] R-mover counts
       if (s->flf_counts) HIPCHK(hipFree(s->flf_counts));
@@ -1304,13 +1304,22 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         sic_launch_jump(sa, s->en->sic_model(), s->stream);
       }
     } else {
+      // Compacted passes around the jump kernel (big batches with several particles per wave):
+      //   [cold list of iteration 0]  { inverse-L pass i (+ the momentum refresh iteration i-1 left pending) ; jump i ;
+      //   cold list of iteration i+1 }  ...  [R list + refresh of the last iteration]
+      // -- three launches per iteration.  The R-movers of an iteration are all on the next iteration's cold list (an R
+      // move clears the cache), so their refresh rides in that inverse-L pass; only the call's last iteration needs
+      // the stand-alone refresh.  The state every iteration hands on is complete before anything reads it.
+      T* hpre = (T*)s->Hpre + (size_t)(i & 1) * s->Npad;
+      const dim3 list_grid((unsigned)((s->N + kColdChunk - 1) / kColdChunk));
       if (compact) {
-        hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)),
-                           dim3(1024), 0, s->stream, ColdCache<T>{a.Hflf_in, (T*)s->Hpre}, s->N, s->ctl, s->flf_list, s->flf_counts + i);
+        if (i == 0)
+          hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, list_grid, dim3(1024), 0, s->stream,
+                             ColdCache<T>{a.Hflf_in, hpre}, s->N, s->ctl, s->flf_list, s->flf_counts);
         FlfArgs<T> fa;
         fa.X = a.X_in;
-        fa.V = a.V_in;
-        fa.H_out = (T*)s->Hpre;
+        fa.V = const_cast<T*>(a.V_in);
+        fa.H_out = hpre;
         fa.list = s->flf_list;
         fa.count = s->flf_counts + i;
         fa.ctl = s->ctl;
@@ -1321,19 +1330,31 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         fa.L = a.L;
         fa.eps = a.eps;
         fa.chalf = a.chalf;
+        fa.pending_r = i > 0 ? 1 : 0;
+        fa.trans = s->trans;
+        fa.EV = const_cast<T*>(a.EV_in);
+        fa.first_pid = s->first_pid;
+        fa.r_keep = a.r_keep;
+        fa.r_mix = a.r_mix;
+        const uint64_t tick_prev = tick - 1;
+        fa.key_prev = RngKey{a.key.k0, a.key.k1, (uint32_t)(tick_prev & 0xFFFFFFFFu), (uint32_t)(tick_prev >> 32)};
         TRY(dispatch_flf<T>(s->en->ep.kind, fa, s->en->ep, s->sh.E, s->N, s->stream));
-        a.Hflf_in = (const T*)s->Hpre;  // every cache reads as warm in the jump kernel
-        a.defer_r = 1;                  // and the momentum refresh of the R-movers follows as a compacted pass
+        a.Hflf_in = hpre;  // every cache reads as warm in the jump kernel
+        a.defer_r = 1;     // and the R-movers keep their old momentum for now
       }
       if (s->en->is_user()) {
         if constexpr (sizeof(T) == 8) TRY(user_launch_jump(s->en, a, s->stream));
       } else {
         TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
       }
-      if (compact) {
-        int* r_count = s->flf_counts + n_iter + i;
-        hipLaunchKernelGGL(compact_list_kernel<MovedBy>, dim3((unsigned)((s->N + kColdChunk - 1) / kColdChunk)), dim3(1024),
-                           0, s->stream, MovedBy{s->trans, 2}, s->N, s->ctl, s->flf_list, r_count);
+      if (compact && i + 1 < n_iter) {
+        hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, list_grid, dim3(1024), 0, s->stream,
+                           ColdCache<T>{a.Hflf_out, (T*)s->Hpre + (size_t)((i + 1) & 1) * s->Npad}, s->N, s->ctl, s->flf_list,
+                           s->flf_counts + i + 1);
+      } else if (compact) {
+        int* r_count = s->flf_counts + n_iter;
+        hipLaunchKernelGGL(compact_list_kernel<MovedBy>, list_grid, dim3(1024), 0, s->stream, MovedBy{s->trans, 2}, s->N, s->ctl,
+                           s->flf_list, r_count);
         RefreshArgs<T> ra;
         ra.V_in = a.V_in;
         ra.V_out = a.V_out;

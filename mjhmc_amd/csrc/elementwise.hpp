@@ -335,6 +335,7 @@ template <typename T>
 struct FunnelNealF {
   static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = true;
+  static constexpr int kWavesRow64 = 3;  // JumpWaves
   T inv_s2;      // 1/scale^2
   T half_dm1;    // (D-1)/2
   struct Ctx {
@@ -381,6 +382,7 @@ template <typename T>
 struct FunnelRefF {
   static constexpr bool kLinearIso = false;
   static constexpr bool kFuse = true;
+  static constexpr int kWavesRow64 = 3;  // JumpWaves
   T inv_s2;
   T dm1;  // D-1
   struct Ctx {
@@ -483,7 +485,7 @@ struct EvalArgs {
 template <typename T>
 struct FlfArgs {
   const T* X;         // [N][pitch] pre-move state
-  const T* V;
+  T* V;               // read; rows of particles with a pending momentum refresh are rewritten first (pending_r)
   T* H_out;           // [N]: H() of the inverse-L proposal, written for the listed particles only
   const int* list;    // particle indices with a cold cache
   const int* count;   // how many
@@ -491,6 +493,15 @@ struct FlfArgs {
   int D, pitch, CH, logG;
   int L;
   T eps, chalf;
+  // != 0: the PREVIOUS iteration of this mjhmc_iterate call left its R-movers (trans == 2) with their old momentum
+  // (JumpArgs::defer_r).  They are all on this list -- an R move clears the cache -- so their HMCState.R is applied
+  // here, with the previous iteration's RNG tick, before the inverse-L trajectory starts from the refreshed momentum.
+  int pending_r;
+  const uint8_t* trans;
+  T* EV;              // [N] kinetic energy of the pre-move state: rewritten for the refreshed particles
+  int64_t first_pid;
+  T r_keep, r_mix;
+  RngKey key_prev;
 };
 
 // stand-alone leapfrog operator (see mjhmc_leap_kernel)
@@ -1153,8 +1164,19 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
 // iteration (plus the ring snapshots when samples are recorded).  Iteration `it` uses RNG tick key.tick + it
 // and tallies into stats[4 * it ..]; the first iteration that meets a non-finite rate is reported through
 // Control::inv_iter and the host re-runs the launch up to that iteration (the input buffers are untouched).
+// waves per SIMD the register allocator is asked to make room for.  Vector-pipe-bound energies whose 8-element
+// float64 instance sits a register or two above an occupancy step ask for that step (funnel: 169 -> 168 VGPRs = three
+// waves per SIMD instead of two, C4 -3 %); everything else takes the build-wide value.
+template <class En, typename T, int E, typename = void>
+struct JumpWaves {
+  static constexpr int value = MJHMC_JUMP_WAVES;
+};
+template <class En, typename T, int E>
+struct JumpWaves<En, T, E, decltype((void)En::kWavesRow64)> {
+  static constexpr int value = (sizeof(T) * E == 64 && sizeof(T) == 8) ? En::kWavesRow64 : MJHMC_JUMP_WAVES;
+};
 template <class En, typename T, int E, int MODE, bool REPLAY, bool FULLROW, int WPP = 0, bool FUSED = false>
-__global__ __launch_bounds__(256, MJHMC_JUMP_WAVES) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
+__global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_kernel(const JumpArgs<T> a, const En en) {
   static_assert(!(FUSED && REPLAY), "recorded random numbers are replayed one iteration per launch");
   if (a.ctl->failed) {  // an earlier attempt of this batch was rolled back: do nothing
     // ... unless the failure belongs to THIS fused launch (another workgroup met it first): this workgroup must still run,
@@ -1526,29 +1548,52 @@ template <class En, typename T, int E>
 __global__ __launch_bounds__(256) void mjhmc_flf_kernel(const FlfArgs<T> a, const En en) {
   if (a.ctl->failed) return;
   const int n_cold = *a.count;
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int G = 1 << a.logG;
-  if ((((int64_t)blockIdx.x * 256) >> a.logG) >= n_cold) return;  // whole block beyond the list
-  const int64_t idx = tid >> a.logG;
-  const bool live = idx < n_cold;
-  const int64_t p = a.list[live ? idx : 0];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int ppb = 256 >> a.logG;  // particles per pass of a block
+  using Vec = typename VecOf<T>::type;
+  constexpr int C = E / VecOf<T>::n;
+  __shared__ Vec stash[4][C][64];
   LaneMap m;
-  m.j = (int)(tid & (G - 1));
+  m.j = (int)(threadIdx.x & (G - 1));
   m.G = G;
   m.D = a.D;
   m.CH = a.CH;
-  m.lane0 = (int)((threadIdx.x & 63) & ~(G - 1));
+  m.lane0 = lane & ~(G - 1);
   m.wpp = 0;
-  T x[E], v[E];
-  load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
-  load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
   const auto lc = en.template local<E>(m);
+  // the grid is sized for a typical list, not for the worst case: blocks walk the list
+  for (int64_t first = (int64_t)blockIdx.x * ppb; first < n_cold; first += (int64_t)gridDim.x * ppb) {
+    const int64_t idx = first + (threadIdx.x >> a.logG);
+    const bool live = idx < n_cold;
+    const int64_t p = a.list[live ? idx : 0];
+    T x[E], v[E];
+    load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
+    load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
+    if (a.pending_r) {
+      const bool r = live && a.trans[p] == 2;
+      if (__ballot(r) != 0ull) {  // HMCState.R of the previous iteration (hmc_state.py:121-129)
+        stash_put<T, E>(stash[wib], lane, v);
+        refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key_prev, (uint32_t)(a.first_pid + p), m, a.r_keep,
+                                   a.r_mix);
+        T vr[E];
+        stash_get<T, E>(stash[wib], lane, vr);
+        const T evr = kinetic<T, E>(vr, m);
+        if (r) {
 #pragma unroll
-  for (int e = 0; e < E; ++e) v[e] = -v[e];
-  trajectory<En, T, E, false>(en, lc, m, x, v, a.L, a.eps, a.chalf);
-  const T ev = kinetic<T, E>(v, m);
-  const T ex = en.energy(x, m, lc);
-  if (live && m.j == 0) a.H_out[p] = ex + ev;
+          for (int e = 0; e < E; ++e) v[e] = vr[e];
+          store_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
+          if (m.j == 0) a.EV[p] = evr;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = -v[e];
+    trajectory<En, T, E, false>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+    const T ev = kinetic<T, E>(v, m);
+    const T ex = en.energy(x, m, lc);
+    if (live && m.j == 0) a.H_out[p] = ex + ev;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1562,15 +1607,11 @@ template <typename T, int E>
 __global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T> a) {
   if (a.ctl->failed) return;
   const int n = *a.count;
-  if ((((int64_t)blockIdx.x * 256) >> a.logG) >= n) return;
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int G = 1 << a.logG;
-  const int64_t idx = tid >> a.logG;
-  const bool live = idx < n;
-  const int64_t p = a.list[live ? idx : 0];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int ppb = 256 >> a.logG;
   LaneMap m;
-  m.j = (int)(tid & (G - 1));
+  m.j = (int)(threadIdx.x & (G - 1));
   m.G = G;
   m.D = a.D;
   m.CH = a.CH;
@@ -1579,23 +1620,29 @@ __global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T>
   using Vec = typename VecOf<T>::type;
   constexpr int C = E / VecOf<T>::n;
   __shared__ Vec stash[4][C][64];
-  T v[E];
-  load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
-  stash_put<T, E>(stash[wib], lane, v);
-  refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key, (uint32_t)(a.first_pid + p), m, a.r_keep, a.r_mix);
-  stash_get<T, E>(stash[wib], lane, v);
-  const T ev = kinetic<T, E>(v, m);
-  if (live) {
-    store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
-    if (m.j == 0) a.EV_out[p] = ev;
+  for (int64_t first = (int64_t)blockIdx.x * ppb; first < n; first += (int64_t)gridDim.x * ppb) {
+    const int64_t idx = first + (threadIdx.x >> a.logG);
+    const bool live = idx < n;
+    const int64_t p = a.list[live ? idx : 0];
+    T v[E];
+    load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
+    stash_put<T, E>(stash[wib], lane, v);
+    refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key, (uint32_t)(a.first_pid + p), m, a.r_keep, a.r_mix);
+    stash_get<T, E>(stash[wib], lane, v);
+    const T ev = kinetic<T, E>(v, m);
+    if (live) {
+      store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+      if (m.j == 0) a.EV_out[p] = ev;
+    }
   }
 }
 
 #ifndef __HIPCC_RTC__
+constexpr int64_t kListGrid = 256 * 16;  // workgroups of the compacted-list passes (256 CUs x 8 resident + a second round)
 template <typename T>
 inline void launch_refresh(const RefreshArgs<T>& a, int E, int64_t n_max, hipStream_t st) {
   const int64_t threads = n_max << a.logG;
-  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  const dim3 grid((unsigned)std::min<int64_t>((threads + 255) / 256, kListGrid)), block(256);  // blocks walk the list
   constexpr int VEC = VecOf<T>::n;
   if (E == VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, VEC>), grid, block, 0, st, a);
   else if (E == 4 * VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 4 * VEC>), grid, block, 0, st, a);
@@ -1788,8 +1835,9 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
 
 template <class En, typename T, int E>
 inline void launch_flf_t(const FlfArgs<T>& a, const En& en, int64_t n_max, hipStream_t st) {
-  const int64_t threads = n_max << a.logG;  // grid for the worst case; blocks beyond the list return at once
-  hipLaunchKernelGGL((mjhmc_flf_kernel<En, T, E>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, en);
+  const int64_t threads = n_max << a.logG;  // worst case; typical lists are a few per cent of it: blocks walk the list
+  hipLaunchKernelGGL((mjhmc_flf_kernel<En, T, E>), dim3((unsigned)std::min<int64_t>((threads + 255) / 256, kListGrid)),
+                     dim3(256), 0, st, a, en);
 }
 
 template <class En, typename T, int E>

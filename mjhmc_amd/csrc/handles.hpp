@@ -85,7 +85,7 @@ struct mjhmc_sampler {
   int* flf_list = nullptr;     // [Npad]
   int* flf_counts = nullptr;   // [flf_cap] one counter per attempt of the current mjhmc_iterate call
   int flf_cap = 0;
-  void* Hpre = nullptr;        // [Npad] H_flf with the cold entries filled in
+  void* Hpre = nullptr;        // [2][Npad] H_flf with the cold entries filled in (iterations alternate between the halves)
   int vcur = 0, scur = 0;
   void* EX[2] = {nullptr, nullptr};
   void* EV[2] = {nullptr, nullptr};
