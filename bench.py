@@ -273,6 +273,33 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
             unfused_ms = t_u['jump_kernel_ms'] / max(t_u['n_jump_launches'], 1)
         finally:
             del os.environ['MJHMC_NO_FUSE']
+    # The C-ABI boundary hands over HOST buffers in the reference's (ndims, nparticles) layout; the device keeps rows
+    # per particle.  What that costs (re-tile kernel + PCIe, pageable host memory), outside `value`: a state read,
+    # and a batch of 10 stacked samples = 10 iterations into the device ring + one download of the ring.
+    boundary = None
+    if world == 1 and key == rig.head:
+        esz = {'float64': 8, 'float32': 4, 'bfloat16': 2}[w['dtype']]
+        t_b = time.perf_counter()
+        Xh = smp.read(_lib.F_X)
+        t_read = time.perf_counter() - t_b
+        nbytes_host = Xh.nbytes
+        del Xh
+        n_s = 10
+        smp.ring_alloc(n_s)
+        t_b = time.perf_counter()
+        smp.iterate(n_s, ring_slot0=0)
+        smp.sync()
+        t_it = time.perf_counter() - t_b
+        t_b = time.perf_counter()
+        ring = smp.ring_read(0, n_s, stacked=False)
+        t_dl = time.perf_counter() - t_b
+        boundary = {'state_read_ms': t_read * 1e3, 'state_read_GBps': nbytes_host / t_read / 1e9,
+                    'state_bytes_device': int(w['D']) * n_rank * esz, 'state_bytes_host_f64': int(nbytes_host),
+                    'sample10': {'iterate_ms': t_it * 1e3, 'download_ms': t_dl * 1e3, 'host_bytes': int(ring.nbytes),
+                                 'download_GBps': ring.nbytes / t_dl / 1e9,
+                                 'particle_steps_per_s_incl_download': float(w['D']) * n_rank * w['L'] * n_s / (t_it + t_dl)},
+                    'what': 'host-buffer-inclusive (re-tile + PCIe) figures of the C-ABI boundary; never part of `value`'}
+        del ring
     smp.close()
     if rank != 0:
         return None
@@ -339,7 +366,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
             roof = {'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': hbm['achieved'] / HBM_PEAK_GBS, 'traffic': traffic,
                     'kernel': 'mjhmc_jump_kernel' if n_rank < 16384 or w['D'] * esize >= 2048 else
-                              'mjhmc_jump_kernel + the compacted passes of one iteration (cold list, inverse-L, R list, refresh)',
+                              'mjhmc_jump_kernel + the compacted passes of one iteration (inverse-L pass with the pending refresh, cold list)',
                     'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'iterations_per_launch': 1.0,
                     'algorithmic_bytes_per_launch': abytes, 'valu': valu}
     per_step = np.array(call_s) * 1e3 / steps
@@ -354,6 +381,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
                    'L_move_fraction': agg[0] / float(n_rank * iters), 'cold_fraction': cold_frac},
         'roofline': roof,
     }
+    if boundary is not None:
+        out['boundary'] = boundary
     if world == 1 and cpu_seconds > 0:
         out['cpu_baseline'] = cpu_baseline(w, cpu_seconds)
         out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
@@ -403,6 +432,7 @@ def main():
     rig = Rig(args)
     keys = ['c2', 'c3', 'c4', 'c5'] if args.workload == 'all' else [args.workload]
     head = keys[0]
+    rig.head = head
     results = {}
     for key in keys:
         # the dense workloads run ~10-20 ms per iteration: a batch of K of them is already long
@@ -425,6 +455,8 @@ def main():
         }
         if 'cpu_baseline' in h:
             out['cpu_baseline'] = h['cpu_baseline']
+        if 'boundary' in h:
+            out['boundary'] = h['boundary']
         if gather_info is not None:
             out['config'] = dict(out['config'], sample_gather=gather_info)
         if len(keys) > 1:
