@@ -133,39 +133,52 @@ __device__ __forceinline__ void a_chunk_load(const float* mlane, int chunk, type
   for (int q = 0; q < 16; ++q) dst[q] = *reinterpret_cast<const V*>(base + (size_t)(NB * ((q & 3) + 8 * (q >> 2))) * DIM);
 }
 
+// B operands (published tiles) are read one group of four k-pairs AHEAD of the MFMAs that use them: with one wave per
+// SIMD an LDS read issued right before its MFMA stalls the matrix pipe for the whole LDS round trip.  The four waves'
+// images are contiguous, [chunk][q4][lane] x float4: group t = 4 chunk + q4.
+// (Measured and dropped: issuing the next chunk's sixteen A loads one per MFMA group, from a scalar base, instead of
+// in front of the chunk -- 1.5 % slower.)
 template <int NB>
-__device__ __forceinline__ void chunk_mfma(const PubWave<NB>* pub, int chunk, int lane,
-                                           const typename VecN<NB>::type (&a)[16], Tile<NB>& acc) {
-  const f32x4(*blk)[64] = pub[chunk / NB].v[chunk % NB];
+__device__ __forceinline__ void chunk_mfma(const f32x4* bbase, int chunk, int lane, const typename VecN<NB>::type (&a)[16],
+                                           f32x4& bnext, Tile<NB>& acc) {
+  constexpr int NG = 16 * NB;  // groups per GEMM
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
-    const f32x4 b4 = blk[q4][lane];
+    const f32x4 b4 = bnext;
+    const int t = 4 * chunk + q4 + 1;
+    bnext = bbase[(size_t)(t < NG ? t : NG - 1) * 64 + lane];  // (the last one is a harmless re-read)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
 #pragma unroll
       for (int r = 0; r < NB; ++r)
         acc.b[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<NB>(a[4 * q4 + qq], r), b4[qq], acc.b[r], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
+// a0 enters holding chunk 0 of M (loaded before the previous epilogue, see AReg) and leaves holding chunk 0 of Mnext:
+// the next GEMM's first A rows cross the epilogue and the barrier
 template <int NB>
-__device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const PubWave<NB>* pub, int w, int c, int h,
-                                         int lane, Tile<NB>& acc) {
+__device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const float* __restrict__ Mnext, const PubWave<NB>* pub,
+                                         int w, int c, int h, int lane, typename VecN<NB>::type (&a0)[16], Tile<NB>& acc) {
   constexpr int DIM = 128 * NB, NCH = 4 * NB;
-  const float* mlane = M + (size_t)(4 * NB * h) * DIM + 32 * NB * w + NB * c;
-  typename VecN<NB>::type a0[16], a1[16];
-  a_chunk_load<NB>(mlane, 0, a0);
+  const size_t lane_off = (size_t)(4 * NB * h) * DIM + 32 * NB * w + NB * c;
+  const float* mlane = M + lane_off;
+  const f32x4* bbase = &pub[0].v[0][0][0];
+  typename VecN<NB>::type a1[16];
+  f32x4 bnext = bbase[lane];
 #pragma unroll 1
   for (int chunk = 0; chunk < NCH; chunk += 2) {
     a_chunk_load<NB>(mlane, chunk + 1, a1);
     __builtin_amdgcn_sched_barrier(0);
-    chunk_mfma<NB>(pub, chunk, lane, a0, acc);
+    chunk_mfma<NB>(bbase, chunk, lane, a0, bnext, acc);
+    // one code path (a select, no branch: two paths made hipcc copy the 64 accumulator registers every chunk)
+    const bool more = chunk + 2 < NCH;
+    a_chunk_load<NB>(more ? mlane : Mnext + lane_off, more ? chunk + 2 : 0, a0);
     __builtin_amdgcn_sched_barrier(0);
-    a_chunk_load<NB>(mlane, chunk + 2 < NCH ? chunk + 2 : NCH - 1, a0);  // (the last one is a harmless re-read)
-    __builtin_amdgcn_sched_barrier(0);
-    chunk_mfma<NB>(pub, chunk + 1, lane, a1, acc);
-    __builtin_amdgcn_sched_barrier(0);
+    chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
   }
 }
 
@@ -174,7 +187,9 @@ __device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const PubW
 // leapfrog step issues no global load at all.  This is the size of the reference's own ProductOfT experiments
 // (36 dims, <= 1000 particles): a handful of tiles, one per CU, where nothing else could hide the A-row latency.
 template <int NB>
-struct AReg {};
+struct AReg {  // NB > 1: chunk 0 of the matrix the NEXT GEMM reads (the GEMMs alternate W1, W2T, W1, ...), loaded ahead
+  typename VecN<NB>::type a0[16];
+};
 template <>
 struct AReg<1> {
   float w1[4][16];
@@ -191,11 +206,13 @@ __device__ __forceinline__ void areg_load(const PotModel& mdl, int w, int c, int
       a_chunk_load<1>(m1, chunk, ar.w1[chunk]);
       a_chunk_load<1>(m2, chunk, ar.w2[chunk]);
     }
+  } else {
+    a_chunk_load<NB>(mdl.W1 + (size_t)(4 * NB * h) * (128 * NB) + 32 * NB * w + NB * c, 0, ar.a0);
   }
 }
 
 template <int NB, bool SECOND>
-__device__ __forceinline__ void gemm_any(const PotModel& mdl, const AReg<NB>& ar, const PubWave<NB>* pub, int w, int c,
+__device__ __forceinline__ void gemm_any(const PotModel& mdl, AReg<NB>& ar, const PubWave<NB>* pub, int w, int c,
                                          int h, int lane, Tile<NB>& acc) {
   if constexpr (NB == 1) {
     // k-rows at or beyond ndims (== nbasis) are padding: X, phi(U) and the matrix rows are exactly zero there, so the
@@ -216,7 +233,7 @@ __device__ __forceinline__ void gemm_any(const PotModel& mdl, const AReg<NB>& ar
       }
     }
   } else {
-    gemm_dim<NB>(SECOND ? mdl.W2T : mdl.W1, pub, w, c, h, lane, acc);
+    gemm_dim<NB>(SECOND ? mdl.W2T : mdl.W1, SECOND ? mdl.W1 : mdl.W2T, pub, w, c, h, lane, ar.a0, acc);
   }
 }
 
@@ -250,7 +267,7 @@ struct Shared {
 // a wave can only reach the next publish of a buffer after every wave has passed the barrier that
 // follows its last read of it).
 template <int NB>
-__device__ __forceinline__ void pot_gradient(const PotModel& mdl, const AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
+__device__ __forceinline__ void pot_gradient(const PotModel& mdl, AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
                                              int lane, const Tile<NB>& x, Tile<NB>& g, bool want_energy,
                                              float* energy_out) {
   publish<NB>(sh.pub[0][w], lane, x);
@@ -276,7 +293,7 @@ __device__ __forceinline__ void pot_gradient(const PotModel& mdl, const AReg<NB>
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float uu = u.b[r][q];
-      u.b[r][q] = uu / (1.0f + uu * uu);               // phi(u); the factor (nu+1)/nu lives in W2T
+      u.b[r][q] = uu * __builtin_amdgcn_rcpf(1.0f + uu * uu);   // phi(u) (v_rcp_f32: 1 ulp); the factor (nu+1)/nu lives in W2T
     }
   publish<NB>(sh.pub[1][w], lane, u);
   __syncthreads();
@@ -309,7 +326,7 @@ __device__ __forceinline__ float pot_kinetic(Shared<NB>& sh, int w, int c, int h
 // L leapfrog steps (hmc_state.py:86-100); g enters as dE/dX at x, leaves as dE/dX at the new x.
 // Returns E(x_new) through *ex (the last gradient evaluation already has u(x_new)).
 template <int NB>
-__device__ __forceinline__ void pot_trajectory(const PotModel& mdl, const AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
+__device__ __forceinline__ void pot_trajectory(const PotModel& mdl, AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
                                                int lane, Tile<NB>& x, Tile<NB>& v, Tile<NB>& g, int L, float eps,
                                                float chalf, float* ex) {
   for (int s = 0; s < L; ++s) {
