@@ -69,7 +69,7 @@ struct LaneMap {
   int CH;     // 16-byte chunks per particle row (pitch / VEC)
   int lane0;  // wave lane index of the group's lane 0
   int wpp;    // lane mapping known at compile time: 1 = the wavefront is one particle (G == 64), 3 = a quad per particle
-              // (G == 4); 0 = G is a run-time value
+              // (G == 4), 6 = half a wavefront per particle (G == 32); 0 = G is a run-time value
 };
 
 template <typename T, int E>
@@ -137,6 +137,10 @@ __device__ __forceinline__ float readlane_v(float v, int r) {
 template <typename T>
 __device__ __forceinline__ T group_lane(T v, const LaneMap& m, int r) {
   if (m.wpp == 1) return readlane_v(v, r);  // v_readlane: no LDS-crossbar round trip
+  if (m.wpp == 6) {                         // half a wavefront per particle: both halves' lane r, then this lane's half
+    const T lo = readlane_v(v, r), hi = readlane_v(v, 32 + r);
+    return m.lane0 ? hi : lo;
+  }
   if (m.wpp == 3) {                         // lane r of the quad: one DPP quad_perm broadcast
     switch (r) {
       case 0: return dpp_mov<0x00>(v);
@@ -1188,9 +1192,10 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
-  constexpr bool BD = (WPP == 5);  // block-level decide: needs all four waves of the workgroup in lockstep per iteration
+  constexpr bool BD = (WPP == 5 || WPP == 6);  // block-level decide: needs all four waves of the workgroup in lockstep per iteration
+  constexpr int kBdPpw = WPP == 6 ? 2 : 1;     // particles per wave of the block-decide forms
   static_assert(!BD || (FUSED && MODE == kModeMJHMC), "block-level decide exists for fused MJHMC launches");
-  const int logG = (WPP == 1 || BD) ? 6 : (WPP == 3 ? 2 : a.logG);
+  const int logG = WPP == 6 ? 5 : ((WPP == 1 || BD) ? 6 : (WPP == 3 ? 2 : a.logG));
   const int G = 1 << logG;
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block, scalar
@@ -1205,7 +1210,7 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
   m.D = a.D;
   m.CH = a.CH;
   m.lane0 = lane & ~(G - 1);
-  m.wpp = BD ? 1 : WPP;
+  m.wpp = WPP == 6 ? 6 : (BD ? 1 : WPP);
   constexpr int VEC = VecOf<T>::n;
   const uint32_t lane_off = ((uint32_t)gi * a.pitch + m.j * VEC) * (uint32_t)sizeof(T);
   const uint32_t chunk_stride = (uint32_t)(G * VEC * sizeof(T));
@@ -1225,7 +1230,7 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
   __shared__ Vec stash[4][2][C][64];
   Vec(*stash_x)[64] = stash[wib][0];
   Vec(*stash_v)[64] = stash[wib][1];
-  __shared__ double bd_e[BD ? kMaxFuse : 1][4][3];  // unit exponentials [iteration][particle of wave q][L, R, F clock]
+  __shared__ double bd_e[BD ? kMaxFuse : 1][4 * kBdPpw][3];  // unit exponentials [iteration][particle of the block][L, R, F clock]
 
   T nx[E], nv[E];
   SlotScalars<T> ns;
@@ -1284,13 +1289,14 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
       mq.G = 4;
       mq.lane0 = lane & ~3;
       mq.wpp = 3;
-      for (int r = wib * 16 + (lane >> 2); r - (lane >> 2) < 4 * n_it; r += 64) {  // r = 4 * iteration + particle
-        const int it = r >> 2, q = r & 3;
+      constexpr int kNpb = 4 * kBdPpw;  // particles the block's four waves hold
+      for (int r = wib * 16 + (lane >> 2); r - (lane >> 2) < kNpb * n_it; r += 64) {  // r = kNpb * iteration + particle
+        const int it = r / kNpb, q = r % kNpb;
         RngKey kt = a.key;
         const uint32_t lo = kt.tick_lo + (uint32_t)it;
         kt.tick_hi += lo < kt.tick_lo ? 1u : 0u;
         kt.tick_lo = lo;
-        const double e = decide_draw(kt, mq, (uint32_t)(a.first_pid + slot0 + q));
+        const double e = decide_draw(kt, mq, (uint32_t)(a.first_pid + slot0 * kBdPpw + q));
         if (it < n_it && (lane & 3) < 3) bd_e[it][q][lane & 3] = e;
       }
       __syncthreads();
@@ -1329,7 +1335,8 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
     r_applied = false;
     if constexpr (MODE == kModeMJHMC) {
       if constexpr (BD) {
-        const double e_pre = bd_e[it][wib][lane < 2 ? lane : 2];  // lane 0: L clock, lane 1: R clock, others: F clock
+        // lane 0 of the particle's group: L clock, lane 1: R clock, others: F clock
+        const double e_pre = bd_e[it][kBdPpw * wib + (kBdPpw == 2 ? (lane >> 5) : 0)][m.j < 2 ? m.j : 2];
         decide<T, false, true>(a, key, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad, e_pre);
       } else {
         decide<T, REPLAY>(a, key, m, H0, HL, Hflf, alive ? p : 0, pid, k, dwell, bad);
@@ -1807,6 +1814,7 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   if constexpr (En::kFuse) if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
     if (a.mode == kModeMJHMC) {
       if (full && a.logG == 6 && !std::getenv("MJHMC_NO_BLOCK_DECIDE")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 5, true>(a, en, st);
+      else if (full && a.logG == 5 && !std::getenv("MJHMC_NO_BLOCK_DECIDE")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 6, true>(a, en, st);
       else if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1, true>(a, en, st);
       else if (full && a.logG == 2 && !std::getenv("MJHMC_NO_QUAD")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3, true>(a, en, st);
       else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, 0, true>(a, en, st);

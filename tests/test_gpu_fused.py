@@ -33,6 +33,8 @@ def _stats_tuple(st):
 
 @pytest.mark.parametrize('kind,D,N,mode_name,n_iter', [
     ('E_ISO_GAUSS', 512, 130, 'MODE_MJHMC', 7),      # wave per particle
+    ('E_ISO_GAUSS', 256, 131, 'MODE_MJHMC', 9),      # half a wave per particle, clocks drawn up front (WPP = 6); odd slot count
+    ('E_DIAG_GAUSS', 256, 64, 'MODE_MJHMC', 66),     # the same across the 64-iteration launch boundary
     ('E_ISO_GAUSS', 64, 500, 'MODE_MJHMC', 70),      # crosses the 64-iteration launch boundary
     ('E_ISO_GAUSS', 40, 129, 'MODE_MJHMC', 5),       # ragged rows (predicated chunks)
     ('E_ISO_GAUSS', 2, 100, 'MODE_MJHMC', 9),
