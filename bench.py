@@ -54,7 +54,8 @@ WORKLOADS = {
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
 }
-DTYPE_TAG = {'float64': 'f64', 'float32': 'f32', 'bfloat16': 'bf16 state / f32 accumulate'}
+DTYPE_TAG = {'float64': 'f64', 'float32': 'f32 state and force (the reference: f64 state arrays around its f32 Theano force)',
+             'bfloat16': 'bf16 state / f32 accumulate'}
 
 
 def pot_model(D):

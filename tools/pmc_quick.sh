@@ -16,7 +16,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(out + '/g*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'][:60]
+        k = r['Kernel_Name'][:230]
         a = agg[k][r['Counter_Name']]
         a[0] += float(r['Counter_Value']); a[1] += 1
 with open(out + '/summary.txt', 'w') as fo:
