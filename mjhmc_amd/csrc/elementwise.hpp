@@ -117,13 +117,49 @@ __device__ __forceinline__ float swap32_sum(float v) {
 // permlane swaps cost more than the wave-uniform branches they replace.)
 template <typename T>
 __device__ __forceinline__ T group_sum(T v, int G) {
+  if (G > 32) v = swap32_sum(v);       // other half of the wave FIRST (the order group_sum_pair reproduces)
   if (G > 1) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
   if (G > 2) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
   if (G > 4) v += dpp_mov<0x141>(v);   // row_half_mirror      : other quad of the 8
   if (G > 8) v += dpp_mov<0x140>(v);   // row_mirror           : other 8 of the row
   if (G > 16) v = swap16_sum(v);       // other row of the pair
-  if (G > 32) v = swap32_sum(v);       // other half of the wave
   return v;
+}
+
+// v_permlane32_swap on every dword of the pair: afterwards a = [a.lower half | b.lower half], b = [a.upper | b.upper]
+__device__ __forceinline__ void swap32_pair(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap32_pair(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+  a = __int_as_float(r[0]);
+  b = __int_as_float(r[1]);
+}
+
+// group_sum of TWO values at once.  With a wavefront per particle the two reductions share their ladder: one half-wave
+// swap leaves a's pair sums in lanes 0..31 and b's in lanes 32..63, five levels reduce both inside their halves, one
+// more swap hands each total to the other half -- 24 vector instructions in float64 instead of 44, and bit for bit
+// what two group_sum calls return (same pairing at every level).
+template <typename T>
+__device__ __forceinline__ void group_sum_pair(T a, T b, int G, T& ta, T& tb) {
+  if (G == 64) {
+    swap32_pair(a, b);  // a = [a_l | b_l], b = [a_{l+32} | b_{l+32}]
+    T c = a + b;
+    c += dpp_mov<0xB1>(c);
+    c += dpp_mov<0x4E>(c);
+    c += dpp_mov<0x141>(c);
+    c += dpp_mov<0x140>(c);
+    c = swap16_sum(c);
+    ta = c;
+    tb = c;
+    swap32_pair(ta, tb);  // ta = [total a | total a], tb = [total b | total b]
+  } else {
+    ta = group_sum(a, G);
+    tb = group_sum(b, G);
+  }
 }
 
 // value held by lane `r` of the caller's group
@@ -209,12 +245,19 @@ struct IsoGaussF {
   __device__ __forceinline__ T grad(T xe, int, int, const Ctx&, const Local<E>&) const {
     return xe * inv_s2;
   }
+  // energy = energy_scale(group_sum(energy_lane)): lets the kernels reduce it together with the kinetic energy
+  static constexpr bool kLaneEnergy = true;
   template <int E>
-  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
+  __device__ __forceinline__ T energy_lane(const T (&x)[E], const LaneMap&, const Local<E>&) const {
     T s = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) s = __builtin_fma(x[e], x[e], s);  // padded x are 0; sums are compared at 1e-10, not bitwise
-    return group_sum(s, m.G) * inv_two_s2;
+    return s;
+  }
+  __device__ __forceinline__ T energy_scale(T total) const { return total * inv_two_s2; }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>& lc) const {
+    return energy_scale(group_sum(energy_lane<E>(x, m, lc), m.G));
   }
 };
 
@@ -245,12 +288,18 @@ struct DiagGaussF {
   __device__ __forceinline__ T grad(T xe, int e, int, const Ctx&, const Local<E>& lc) const {
     return lc.j[e] * xe;
   }
+  static constexpr bool kLaneEnergy = true;
   template <int E>
-  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>& lc) const {
+  __device__ __forceinline__ T energy_lane(const T (&x)[E], const LaneMap&, const Local<E>& lc) const {
     T s = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) s = __builtin_fma(x[e], lc.j[e] * x[e], s);
-    return group_sum(s, m.G) / T(2);
+    return s;
+  }
+  __device__ __forceinline__ T energy_scale(T total) const { return total / T(2); }
+  template <int E>
+  __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>& lc) const {
+    return energy_scale(group_sum(energy_lane<E>(x, m, lc), m.G));
   }
 };
 
@@ -698,6 +747,34 @@ __device__ __forceinline__ T kinetic(const T (&v)[E], const LaneMap& m) {
 #pragma unroll
   for (int e = 0; e < E; ++e) s = __builtin_fma(v[e], v[e], s);
   return group_sum(s, m.G) / T(2);  // hmc_state.py:50
+}
+
+// EV = kinetic(v) and EX = en.energy(x) of one state, the same bits as the two calls; energies that are a scaled group
+// sum (kLaneEnergy) share one reduction ladder with the kinetic energy
+template <class En, typename = void>
+struct HasLaneEnergy {
+  static constexpr bool value = false;
+};
+template <class En>
+struct HasLaneEnergy<En, decltype((void)En::kLaneEnergy)> {
+  static constexpr bool value = true;
+};
+template <class En, typename T, int E, class LC>
+__device__ __forceinline__ void state_energies(const En& en, const LC& lc, const LaneMap& m, const T (&x)[E], const T (&v)[E],
+                                               T& EX, T& EV) {
+  if constexpr (HasLaneEnergy<En>::value) {
+    T sv = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) sv = __builtin_fma(v[e], v[e], sv);
+    const T sx = en.template energy_lane<E>(x, m, lc);
+    T tv, tx;
+    group_sum_pair(sv, sx, m.G, tv, tx);
+    EV = tv / T(2);
+    EX = en.energy_scale(tx);
+  } else {
+    EV = kinetic<T, E>(v, m);
+    EX = en.energy(x, m, lc);
+  }
 }
 
 // momentum-refresh noise for this lane's dims (hmc_state.py:125): replayed or counter RNG
@@ -1316,8 +1393,8 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = -v[e];
       trajectory<En, T, E, REPLAY>(en, lc, m, x, v, a.L, a.eps, a.chalf);
-      const T ev = kinetic<T, E>(v, m);
-      const T ex = en.energy(x, m, lc);
+      T ex, ev;
+      state_energies<En, T, E>(en, lc, m, x, v, ex, ev);
       Hflf = ex + ev;
       stash_get<T, E>(stash_x, lane, x);
       stash_get<T, E>(stash_v, lane, v);
@@ -1325,8 +1402,8 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
 
     // forward proposal L
     trajectory<En, T, E, REPLAY>(en, lc, m, x, v, a.L, a.eps, a.chalf);
-    const T EVL = kinetic<T, E>(v, m);
-    const T EXL = en.energy(x, m, lc);
+    T EXL, EVL;
+    state_energies<En, T, E>(en, lc, m, x, v, EXL, EVL);
     const T HL = EXL + EVL;
 
     bool bad = false;
