@@ -181,3 +181,48 @@ def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
     _same_state(a, b, _lib)
     assert [_stats_tuple(s) for s in stats_a] == [_stats_tuple(s) for s in stats_b]
     assert sum(s.n_cold for s in stats_a) > 0 and stats_a[0].n_cold == N        # first iteration: every cache is cold
+
+
+def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
+    """A non-finite rate in iteration i > 0 of a multi-iteration call through the compacted passes: the call stops
+    there and the state is the one iteration i-1 handed on -- INCLUDING the momentum refresh of its R-movers, which
+    rides in the inverse-L pass of iteration i (api.hip, iterate_t) -- exactly as without the compacted passes.
+    (Gaussian force with fusing switched off: its energy error grows as particles drift outwards, which gives late
+    first failures; see test_fused_failure_in_the_middle_of_a_launch.)"""
+    from mjhmc_amd import _lib
+    D, N = 24, 20000
+    monkeypatch.setenv('MJHMC_NO_FUSE', '1')
+    s_thr = np.sqrt(709.0 / (0.011 * D))
+    mid = 0
+    for scale in np.linspace(0.45, 0.9, 46) * s_thr:
+        (a, b), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale))
+        for s in (a, b):
+            s.set_hparams(0.5, 5, 0.1, 1.0, 0.5)
+        monkeypatch.delenv('MJHMC_NO_COMPACT', raising=False)
+        st_a, done_a = a.iterate(12)
+        monkeypatch.setenv('MJHMC_NO_COMPACT', '1')
+        st_b, done_b = b.iterate(12)
+        monkeypatch.delenv('MJHMC_NO_COMPACT', raising=False)
+        assert done_a == done_b, scale
+        # dwelling times / transitions are only defined once the retry has succeeded (see the fused test above)
+        _same_state(a, b, _lib, fields=('X', 'V', 'EX', 'EV', 'HFLF'))
+        assert [_stats_tuple(s) for s in st_a[:done_a]] == [_stats_tuple(s) for s in st_b[:done_b]]
+        if 0 < done_a < 12:
+            mid += 1
+            assert st_a[done_a].nonfinite == 1 and st_b[done_b].nonfinite == 1
+            # the retry protocol continues identically from the rolled-back state
+            for s in (a, b):
+                s.set_hparams(0.25, 10, 0.1, 1.0, 0.5)
+                s.reset_flf_cache()
+            sa, da = a.iterate(3)
+            monkeypatch.setenv('MJHMC_NO_COMPACT', '1')
+            sb, db = b.iterate(3)
+            monkeypatch.delenv('MJHMC_NO_COMPACT', raising=False)
+            assert da == db
+            _same_state(a, b, _lib, fields=('X', 'V', 'EX', 'EV', 'HFLF') if da < 3 else FIELDS)
+        a.close()
+        b.close()
+        if mid >= 2 or done_a == 0:
+            break
+    if mid == 0:
+        pytest.skip('no initial scale with a first failure in the middle of the batch')
