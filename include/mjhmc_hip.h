@@ -133,6 +133,20 @@ int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr,
                              const double* params, size_t nparams, const char* include_dir, mjhmc_energy** out);
 /* compile-only check of a pair of expressions (needs no device): 0, or MJHMC_ERR_INVALID with the compiler's log */
 int mjhmc_expr_check(int ndims, const char* energy_expr, const char* grad_expr, const char* include_dir);
+/* The same for energies that are separable GIVEN a few per-particle statistics (coupled coordinates):
+ *     S[k] = sum_d stat_k(x_d, d; p)                 stat_exprs: the stat_k separated by ';' (NULL / "": none)
+ *     E(x) = energy0_expr(S; p) + sum_d energy_expr(x_d, d, S; p)          (energy0_expr may be NULL: 0)
+ *     dE/dx_d = grad_expr(x_d, d, S; p)              with the chain-rule terms through S written out by the caller
+ * e.g. Neal's funnel (mjhmc/misc/tf_distributions.py:143-147), scale p[0], D = ndims:
+ *     stats  "d == 0 ? x : 0.0; d == 0 ? 0.0 : x*x"
+ *     energy "0.0"      energy0 "S[0]*S[0]/(2*p[0]*p[0]) + 0.5*exp(-S[0])*S[1] + 0.5*(p[1]-1)*S[0]"      (p[1] = D)
+ *     grad   "d == 0 ? x/(p[0]*p[0]) - 0.5*exp(-x)*S[1] + 0.5*(p[1]-1) : x*exp(-S[0])"
+ * The statistics are recomputed at every force evaluation (one group reduction each). */
+int mjhmc_energy_create_expr_coupled(mjhmc_ctx* ctx, int ndims, const char* stat_exprs, const char* energy_expr,
+                                     const char* energy0_expr, const char* grad_expr, const double* params, size_t nparams,
+                                     const char* include_dir, mjhmc_energy** out);
+int mjhmc_expr_check_coupled(int ndims, const char* stat_exprs, const char* energy_expr, const char* energy0_expr,
+                             const char* grad_expr, const char* include_dir);
 int mjhmc_energy_destroy(mjhmc_energy* e);
 
 /* One evaluation of E_val / dEdX_val (mjhmc/misc/distributions.py:66-81) on n columns.

@@ -48,6 +48,11 @@ PROTOTYPES = {
     'mjhmc_energy_create_expr': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, _P, ctypes.c_size_t,
                                                 ctypes.c_char_p, ctypes.POINTER(_P)]),
     'mjhmc_expr_check': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]),
+    'mjhmc_energy_create_expr_coupled': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                                        ctypes.c_char_p, _P, ctypes.c_size_t, ctypes.c_char_p,
+                                                        ctypes.POINTER(_P)]),
+    'mjhmc_expr_check_coupled': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                                ctypes.c_char_p, ctypes.c_char_p]),
     'mjhmc_energy_destroy': (ctypes.c_int, [_P]),
     'mjhmc_eval': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _P, _P]),
     'mjhmc_sampler_create': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _P, _P,

@@ -667,8 +667,9 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
   return 0;
 }
 
-int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr, const char* grad_expr,
-                             const double* params, size_t nparams, const char* include_dir, mjhmc_energy** out) {
+int mjhmc_energy_create_expr_coupled(mjhmc_ctx* ctx, int ndims, const char* stat_exprs, const char* energy_expr,
+                                     const char* energy0_expr, const char* grad_expr, const double* params, size_t nparams,
+                                     const char* include_dir, mjhmc_energy** out) {
   if (!ctx || !out || !energy_expr || !grad_expr || !include_dir) return fail(MJHMC_ERR_INVALID, "NULL argument");
   if (ndims < 1) return fail(MJHMC_ERR_INVALID, "ndims must be >= 1");
   if (nparams && !params) return fail(MJHMC_ERR_INVALID, "params is NULL");
@@ -681,7 +682,7 @@ int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr,
   std::memset(&e->ep, 0, sizeof(e->ep));
   e->ep.kind = MJHMC_E_USER_EXPR;
   e->ep.ndims = ndims;
-  const int rc = user_energy_build(e, energy_expr, grad_expr, include_dir, params, nparams, sh.E);
+  const int rc = user_energy_build(e, energy_expr, grad_expr, stat_exprs, energy0_expr, include_dir, params, nparams, sh.E);
   if (rc) {
     std::string keep = g_err;
     mjhmc_energy_destroy(e);
@@ -692,7 +693,13 @@ int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr,
   return 0;
 }
 
-int mjhmc_expr_check(int ndims, const char* energy_expr, const char* grad_expr, const char* include_dir) {
+int mjhmc_energy_create_expr(mjhmc_ctx* ctx, int ndims, const char* energy_expr, const char* grad_expr,
+                             const double* params, size_t nparams, const char* include_dir, mjhmc_energy** out) {
+  return mjhmc_energy_create_expr_coupled(ctx, ndims, nullptr, energy_expr, nullptr, grad_expr, params, nparams, include_dir, out);
+}
+
+int mjhmc_expr_check_coupled(int ndims, const char* stat_exprs, const char* energy_expr, const char* energy0_expr,
+                             const char* grad_expr, const char* include_dir) {
   if (!energy_expr || !grad_expr || !include_dir) return fail(MJHMC_ERR_INVALID, "NULL argument");
   if (ndims < 1) return fail(MJHMC_ERR_INVALID, "ndims must be >= 1");
   Shape sh;
@@ -700,8 +707,13 @@ int mjhmc_expr_check(int ndims, const char* energy_expr, const char* grad_expr, 
   std::vector<char> code;
   std::vector<std::string> lowered;
   std::string err;
-  const int rc = user_expr_compile(user_expr_source(energy_expr, grad_expr), include_dir, sh.E, &code, &lowered, &err);
+  const int rc = user_expr_compile(user_expr_source(energy_expr, grad_expr, stat_exprs ? stat_exprs : "", energy0_expr ? energy0_expr : ""),
+                                   include_dir, sh.E, &code, &lowered, &err);
   return rc ? fail(rc, err) : 0;
+}
+
+int mjhmc_expr_check(int ndims, const char* energy_expr, const char* grad_expr, const char* include_dir) {
+  return mjhmc_expr_check_coupled(ndims, nullptr, energy_expr, nullptr, grad_expr, include_dir);
 }
 
 int mjhmc_energy_destroy(mjhmc_energy* e) {

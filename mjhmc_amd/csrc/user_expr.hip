@@ -4,7 +4,8 @@
 //
 //     E(x) = sum_d  e(x_d, d; p)        dE/dx_d = g(x_d, d; p)
 //
-// (`x` the coordinate, `d` its index, `p[k]` float64 parameters), and this file compiles the engine's own kernel templates
+// (`x` the coordinate, `d` its index, `p[k]` float64 parameters; optionally coupled through per-particle statistics
+// S[k] = sum_d s_k(x_d, d; p), see user_expr_source), and this file compiles the engine's own kernel templates
 // (elementwise.hpp: mjhmc_jump_kernel, mjhmc_eval_kernel, mjhmc_leap_kernel) around them with hipRTC, at energy
 // creation, for gfx950.  The resulting energy runs through exactly the code paths of the built-in elementwise
 // energies: same lane mapping, same jump / accept logic, same counter RNG, all three sampler families, replay mode.
@@ -65,30 +66,76 @@ Rtc& rtc() {
 
 }  // namespace
 
-std::string user_expr_source(const std::string& energy_expr, const std::string& grad_expr) {
+// `stats`: expressions s_k(x, d; p) separated by ';' (empty: none).  Their per-particle sums S[k] = sum_d s_k(x_d, d) are
+// available to the other expressions, which makes the family
+//     E(x) = e0(S; p) + sum_d e(x_d, d, S; p),      dE/dx_d = g(x_d, d, S; p)
+// -- separable GIVEN a handful of global statistics (Neal's funnel, mean-field couplings, radial energies).  The caller
+// supplies g with the chain-rule terms through S written out.
+static std::vector<std::string> split_stats(const std::string& stats) {
+  std::vector<std::string> out;
+  std::string cur;
+  for (char ch : stats) {
+    if (ch == ';') {
+      out.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(ch);
+    }
+  }
+  bool blank = true;
+  for (char ch : cur) blank = blank && (ch == ' ' || ch == '\t' || ch == '\n');
+  if (!blank) out.push_back(cur);
+  return out;
+}
+
+std::string user_expr_source(const std::string& energy_expr, const std::string& grad_expr, const std::string& stats,
+                             const std::string& energy0_expr) {
+  const std::vector<std::string> st = split_stats(stats);
+  const int K = (int)st.size();
+  const std::string e0 = energy0_expr.empty() ? "0.0" : energy0_expr;
   std::string s;
   s += "#include \"elementwise.hpp\"\n";
   s += "namespace mjhmc {\n";
-  s += "// E(x) = sum_d e(x_d, d; p), dE/dx_d = g(x_d, d; p): the caller's expressions\n";
+  s += "// E(x) = e0(S) + sum_d e(x_d, d, S; p), dE/dx_d = g(x_d, d, S; p), S[k] = sum_d s_k(x_d, d; p): the caller's expressions\n";
   s += "struct UserExprF {\n";
   s += "  static constexpr bool kLinearIso = false;\n";
   s += "  static constexpr bool kFuse = true;\n";
   s += "  const double* p;  // parameters, device memory\n";
   s += "  int D;\n";
-  s += "  using Ctx = NoCtx;\n";
   s += "  template <int E> using Local = NoLocal<E>;\n";
   s += "  template <int E> __device__ __forceinline__ Local<E> local(const LaneMap&) const { return {}; }\n";
-  s += "  template <int E> __device__ __forceinline__ Ctx prep(const double (&)[E], const LaneMap&) const { return {}; }\n";
-  s += "  __device__ __forceinline__ double e_of(double x, int d) const { (void)d; return (double)(" + energy_expr + "); }\n";
-  s += "  __device__ __forceinline__ double g_of(double x, int d) const { (void)d; return (double)(" + grad_expr + "); }\n";
-  s += "  template <int E> __device__ __forceinline__ double grad(double xe, int, int d, const Ctx&, const Local<E>&) const {\n";
-  s += "    return d < D ? g_of(xe, d) : 0.0;  // padded elements keep x = v = 0\n";
+  if (K == 0) {
+    s += "  struct Ctx { const double* S = nullptr; };\n";
+    s += "  template <int E> __device__ __forceinline__ Ctx prep(const double (&)[E], const LaneMap&) const { return {}; }\n";
+  } else {
+    s += "  struct Ctx { double S[" + std::to_string(K) + "]; };\n";
+    for (int k = 0; k < K; ++k)
+      s += "  __device__ __forceinline__ double s" + std::to_string(k) + "_of(double x, int d) const { (void)d; (void)x; return (double)(" +
+           st[(size_t)k] + "); }\n";
+    s += "  template <int E> __device__ __forceinline__ Ctx prep(const double (&x)[E], const LaneMap& m) const {\n";
+    s += "    Ctx c;\n";
+    for (int k = 0; k < K; ++k) {
+      const std::string ks = std::to_string(k);
+      s += "    { double a = 0.0;\n";
+      s += "#pragma unroll\n";
+      s += "      for (int e = 0; e < E; ++e) { const int d = dim_of<double, E>(m, e); a += d < m.D ? s" + ks + "_of(x[e], d) : 0.0; }\n";
+      s += "      c.S[" + ks + "] = group_sum(a, m.G); }\n";
+    }
+    s += "    return c;\n";
+    s += "  }\n";
+  }
+  s += "  __device__ __forceinline__ double e_of(double x, int d, const double* S) const { (void)d; (void)S; return (double)(" + energy_expr + "); }\n";
+  s += "  __device__ __forceinline__ double g_of(double x, int d, const double* S) const { (void)d; (void)S; return (double)(" + grad_expr + "); }\n";
+  s += "  __device__ __forceinline__ double e0_of(const double* S) const { (void)S; return (double)(" + e0 + "); }\n";
+  s += "  template <int E> __device__ __forceinline__ double grad(double xe, int, int d, const Ctx& c, const Local<E>&) const {\n";
+  s += "    return d < D ? g_of(xe, d, c.S) : 0.0;  // padded elements keep x = v = 0\n";
   s += "  }\n";
   s += "  template <int E> __device__ __forceinline__ double energy(const double (&x)[E], const LaneMap& m, const Local<E>&) const {\n";
+  s += "    const Ctx c = prep<E>(x, m);\n";
   s += "    double s = 0.0;\n";
   s += "#pragma unroll\n";
-  s += "    for (int e = 0; e < E; ++e) { const int d = dim_of<double, E>(m, e); s += d < m.D ? e_of(x[e], d) : 0.0; }\n";
-  s += "    return group_sum(s, m.G);\n";
+  s += "    for (int e = 0; e < E; ++e) { const int d = dim_of<double, E>(m, e); s += d < m.D ? e_of(x[e], d, c.S) : 0.0; }\n";
+  s += "    return group_sum(s, m.G) + e0_of(c.S);\n";
   s += "  }\n";
   s += "};\n";
   s += "}  // namespace mjhmc\n";
@@ -154,15 +201,16 @@ int user_expr_compile(const std::string& src, const std::string& include_dir, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-int user_energy_build(mjhmc_energy* e, const char* energy_expr, const char* grad_expr, const char* include_dir,
-                      const double* params, size_t nparams, int E) {
+int user_energy_build(mjhmc_energy* e, const char* energy_expr, const char* grad_expr, const char* stats,
+                      const char* energy0_expr, const char* include_dir, const double* params, size_t nparams, int E) {
   UserEnergy* u = new UserEnergy();
   e->user = u;
   u->E = E;
   std::vector<char> code;
   std::vector<std::string> lowered;
   std::string err;
-  const int rc = user_expr_compile(user_expr_source(energy_expr, grad_expr), include_dir, E, &code, &lowered, &err);
+  const int rc = user_expr_compile(user_expr_source(energy_expr, grad_expr, stats ? stats : "", energy0_expr ? energy0_expr : ""),
+                                   include_dir, E, &code, &lowered, &err);
   if (rc) return mjhmc_fail(rc, err);
   HIPCHK(hipModuleLoadData(&u->module, code.data()));
   for (int mode = 0; mode < 3; ++mode)

@@ -19,13 +19,14 @@ struct UserEnergy {
 };
 
 // the translation unit handed to hipRTC, and the kernel instantiations requested from it (6 jump kernels, eval, leap)
-std::string user_expr_source(const std::string& energy_expr, const std::string& grad_expr);
+std::string user_expr_source(const std::string& energy_expr, const std::string& grad_expr, const std::string& stats = "",
+                             const std::string& energy0_expr = "");
 std::vector<std::string> user_expr_kernel_names(int E);
 int user_expr_compile(const std::string& src, const std::string& include_dir, int E, std::vector<char>* code,
                       std::vector<std::string>* lowered, std::string* err);
 
-int user_energy_build(mjhmc_energy* e, const char* energy_expr, const char* grad_expr, const char* include_dir,
-                      const double* params, size_t nparams, int E);
+int user_energy_build(mjhmc_energy* e, const char* energy_expr, const char* grad_expr, const char* stats,
+                      const char* energy0_expr, const char* include_dir, const double* params, size_t nparams, int E);
 void user_energy_free(mjhmc_energy* e);
 int user_launch_jump(const mjhmc_energy* e, const mjhmc::JumpArgs<double>& a, hipStream_t st);
 int user_launch_eval(const mjhmc_energy* e, const mjhmc::EvalArgs<double>& a, hipStream_t st);

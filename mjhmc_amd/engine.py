@@ -70,19 +70,23 @@ class DeviceEnergy(object):
         self.handle = h
 
     @classmethod
-    def from_expr(cls, ctx, ndims, energy_expr, grad_expr, params=()):
-        """A separable energy E(x) = sum_d energy_expr(x_d), dE/dx_d = grad_expr(x_d) given as C expressions of
-        ``x`` (coordinate), ``d`` (its index) and ``p[k]`` (float64 parameters); compiled with hipRTC around the
-        engine's kernel templates (mjhmc_energy_create_expr, include/mjhmc_hip.h)."""
+    def from_expr(cls, ctx, ndims, energy_expr, grad_expr, params=(), stats=(), energy0_expr=None):
+        """An energy given as C expressions of ``x`` (coordinate), ``d`` (its index), ``p[k]`` (float64 parameters) and,
+        when ``stats`` are given, ``S[k]`` (per-particle sums of the stat expressions):
+            E(x) = energy0_expr(S) + sum_d energy_expr(x_d, d, S),   dE/dx_d = grad_expr(x_d, d, S);
+        compiled with hipRTC around the engine's kernel templates (mjhmc_energy_create_expr[_coupled],
+        include/mjhmc_hip.h)."""
         self = cls.__new__(cls)
         self.ctx = ctx
         self.kind = _lib.E_USER_EXPR
         self.ndims = int(ndims)
         self.params = np.ascontiguousarray(np.atleast_1d(np.asarray(params, dtype=np.float64)).ravel())
+        stats = [stats] if isinstance(stats, str) else list(stats)
         h = ctypes.c_void_p()
-        check(ctx.lib.mjhmc_energy_create_expr(ctx.handle, self.ndims, str(energy_expr).encode(), str(grad_expr).encode(),
-                                               ptr(self.params) if self.params.size else None, self.params.size,
-                                               _lib.KERNEL_HEADERS.encode(), ctypes.byref(h)))
+        check(ctx.lib.mjhmc_energy_create_expr_coupled(
+            ctx.handle, self.ndims, ';'.join(str(t) for t in stats).encode() if stats else None, str(energy_expr).encode(),
+            str(energy0_expr).encode() if energy0_expr else None, str(grad_expr).encode(),
+            ptr(self.params) if self.params.size else None, self.params.size, _lib.KERNEL_HEADERS.encode(), ctypes.byref(h)))
         self.handle = h
         return self
 

@@ -45,7 +45,7 @@ class Distribution(object):
         """DeviceEnergy for this distribution on ``device`` (cached)."""
         if self._dev is None or self._dev.ctx.device != device:
             kind, params = self.device_energy()
-            if kind == _lib.E_USER_EXPR:                   # params = (energy_expr, grad_expr, float64 parameters)
+            if kind == _lib.E_USER_EXPR:                   # params = (energy_expr, grad_expr, float64 parameters, stats, energy0_expr)
                 self._dev = engine.DeviceEnergy.from_expr(engine.context(device), self.ndims, *params)
             else:
                 self._dev = engine.DeviceEnergy(engine.context(device), kind, self.ndims, params)
@@ -145,7 +145,10 @@ class LambdaDistribution(Distribution):
     * ``device_expr=(energy_expr, grad_expr)`` [+ ``device_params``]: C expressions of one coordinate for a separable
       energy ``E(x) = sum_d energy_expr(x_d)``, ``dE/dx_d = grad_expr(x_d)`` with ``x`` the coordinate, ``d`` its
       index and ``p[k]`` the float64 ``device_params``; the engine's kernels are compiled around them with hipRTC
-      (mjhmc_energy_create_expr).  When callables are given as well they are checked against the compiled energy;
+      (mjhmc_energy_create_expr).  When callables are given as well they are checked against the compiled energy.
+      Coupled coordinates: ``device_expr=dict(stats=[...], energy=..., energy0=..., grad=...)`` -- the ``stats``
+      expressions are summed over a particle's coordinates into ``S[k]``, which the other expressions may use:
+      ``E = energy0(S) + sum_d energy(x_d, d, S)``, ``dE/dx_d = grad(x_d, d, S)`` (mjhmc_energy_create_expr_coupled);
     * ``device_energy=(kind, params)``: one of the built-in device energies by name.
     """
 
@@ -158,8 +161,15 @@ class LambdaDistribution(Distribution):
         self._functor = device_energy
         self._checked = False
         if device_expr is not None:
-            e_expr, g_expr = device_expr
-            self._functor = (_lib.E_USER_EXPR, (str(e_expr), str(g_expr), np.asarray(device_params, dtype=np.float64)))
+            if isinstance(device_expr, dict):              # coupled through per-particle statistics S[k]
+                e_expr, g_expr = device_expr['energy'], device_expr['grad']
+                stats = device_expr.get('stats', ())
+                stats = [stats] if isinstance(stats, str) else [str(t) for t in stats]
+                e0 = device_expr.get('energy0')
+            else:
+                (e_expr, g_expr), stats, e0 = device_expr, [], None
+            self._functor = (_lib.E_USER_EXPR, (str(e_expr), str(g_expr), np.asarray(device_params, dtype=np.float64),
+                                                stats, None if e0 is None else str(e0)))
         elif self._functor is None:
             self._functor = _recognise(energy_func, energy_grad_func, self.init.shape[0])
             self._checked = True

@@ -92,6 +92,10 @@ def stable_digest(distribution):
     h.update(np.int64([kind, distribution.ndims]).tobytes())
     if isinstance(params, tuple) and params and isinstance(params[0], str):     # user expressions + their parameters
         for part in params:
+            if part is None:
+                continue
+            if isinstance(part, (list, tuple)):
+                part = ';'.join(str(t) for t in part)
             h.update(part.encode() if isinstance(part, str) else np.ascontiguousarray(part, dtype=np.float64).tobytes())
     else:
         h.update(np.ascontiguousarray(params, dtype=np.float64).tobytes())

@@ -84,6 +84,13 @@ def test_user_expression_energies_compile_without_a_device(lib):
     assert lib.mjhmc_expr_check(700, b"0.5*x*x + p[0]*cos(x)", b"x - p[0]*sin(x)", inc) == 0, lib.mjhmc_last_error()
     rc = lib.mjhmc_expr_check(4, b"0.5*x*y", b"x", inc)
     assert rc == -1 and b"undeclared identifier 'y'" in lib.mjhmc_last_error()
+    # coordinates coupled through per-particle statistics S[k] (Neal's funnel as expressions)
+    assert lib.mjhmc_expr_check_coupled(
+        32, b"d == 0 ? x : 0.0; d == 0 ? 0.0 : x*x", b"0.0",
+        b"S[0]*S[0]/(2*p[0]*p[0]) + 0.5*exp(-S[0])*S[1] + 0.5*(p[1]-1)*S[0]",
+        b"d == 0 ? x/(p[0]*p[0]) - 0.5*exp(-x)*S[1] + 0.5*(p[1]-1) : x*exp(-S[0])", inc) == 0, lib.mjhmc_last_error()
+    rc = lib.mjhmc_expr_check_coupled(8, b"x*x", b"S[0]*x", None, b"S[1]*x + T", inc)
+    assert rc == -1 and b"undeclared identifier 'T'" in lib.mjhmc_last_error()
 
 
 def test_host_side_under_address_sanitizer(tmp_path):

@@ -476,6 +476,43 @@ def test_lambda_distribution_with_device_expressions(cls_name, D, N):
     assert close(Z.X, Zo.X) and close(Z.V, Zo.V) and close(Z.EX, Zo.EX)
 
 
+FUNNEL_EXPR = dict(stats=["d == 0 ? x : 0.0", "d == 0 ? 0.0 : x*x"], energy="0.0",
+                   energy0="S[0]*S[0]/(2*p[0]*p[0]) + 0.5*exp(-S[0])*S[1] + 0.5*(p[1]-1)*S[0]",
+                   grad="d == 0 ? x/(p[0]*p[0]) - 0.5*exp(-x)*S[1] + 0.5*(p[1]-1) : x*exp(-S[0])")
+
+
+@pytest.mark.parametrize('cls_name,D,N', [('MarkovJumpHMC', 32, 70), ('MarkovJumpHMC', 10, 200), ('ControlHMC', 32, 40)])
+def test_lambda_distribution_with_coupled_expressions(cls_name, D, N):
+    """Coordinates coupled through per-particle statistics S[k] (mjhmc_energy_create_expr_coupled): Neal's funnel
+    written as user expressions must follow the oracle's FunnelNeal -- and the built-in FUNNEL_NEAL functor."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import LambdaDistribution, Funnel
+    rs = np.random.RandomState(D + N)
+    x0 = 1.5 * rs.randn(N)
+    X0 = np.vstack([x0, np.exp(x0 / 2) * rs.randn(D - 1, N)])
+    en = orc.FunnelNeal(3.0)
+    d = LambdaDistribution(energy_func=en.E_val, energy_grad_func=en.dEdX_val, init=X0, name='funnel as expressions',
+                           device_expr=FUNNEL_EXPR, device_params=[3.0, float(D)])
+    assert close(d.E(X0)[0], en.E_val(X0)[0]) and close(d.dEdX(X0), en.dEdX_val(X0))
+    builtin = Funnel(ndims=D, nbatch=N, scale=3.0)
+    assert close(d.E(X0)[0], builtin.E(X0)[0]) and close(d.dEdX(X0), builtin.dEdX(X0))
+    kw = dict(epsilon=0.05, beta=0.3, num_leapfrog_steps=6)
+    extra = dict(resample=False) if cls_name != 'ControlHMC' else {}
+    s = getattr(M, cls_name)(distribution=d, seed=77, **kw, **extra)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(77, np.arange(N)), **kw, **extra)
+    for t in range(6):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        if cls_name == 'MarkovJumpHMC':
+            assert np.array_equal(s._dev.read(8), o.last_transition), t
+            assert close(s.dwelling_times, o.dwelling_times), t
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), t
+        assert close(s.state.EX, o.state.EX) and close(s.state.EV, o.state.EV), t
+        assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count), t
+    out = s.sample(4)
+    assert out.shape == (D, 4 * N) and np.isfinite(out).all()
+
+
 def test_lambda_distribution_checks_the_expressions_against_the_callables():
     from mjhmc_amd import _lib
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
