@@ -743,6 +743,10 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   for (auto& e : s->ev_total)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : s->ev_k) (void)hipEventDestroy(e);
+  for (auto& e : s->ev_half)
+    if (e) (void)hipEventDestroy(e);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return 0;
@@ -802,7 +806,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       if (e->is_dense()) {
         if (!s->Hwork) {
           HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * sizeof(float)));
-          HIPCHK(hipMalloc((void**)&s->cold_list, (s->Npad + 1) * sizeof(int)));
+          HIPCHK(hipMalloc((void**)&s->cold_list, (s->Npad + 2) * sizeof(int)));  // list + one counter per half
         }
       }
       HIPCHK(hipMalloc(&s->EX[i], s->Npad * ssize(s)));
@@ -969,6 +973,58 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
 // the state buffers of one parity and writes the other, so its input survives it: when some particle meets a
 // non-finite rate at iteration f (the reference aborts the WHOLE batch there, markov_jump_hmc.py:376-389) the
 // launch that contains f is run again for the iterations before f and the call returns n_done = f.
+// A big dense MJHMC batch is launched as TWO halves on two streams.  Every kernel of the dense path is a persistent grid
+// of one workgroup per CU, so a launch ends with a partial round (ProductOfT C3: 3125 tiles = 12.2 rounds of 256, then
+// the inverse-L pass of ~250 tiles another partial one: 14 rounds where 13.2 would do).  With two halves the inverse-L
+// pass of one half's NEXT iteration (cold list + pass: they only read the state and fill the H_flf work vector) runs
+// while the other half's jump kernel is still in its last rounds:
+//     stream h:  jump(i, h) . record J_h . inverse-L(i+1, h) . wait J_other . jump(i+1, h) ...
+// The state-changing kernels keep their order: a half's jump kernel of iteration i+1 starts only after BOTH halves'
+// jump kernels of iteration i are done, so the failure / roll-back rules are the ones of a single stream; the failure
+// flag and the tallies are shared.  Results cannot depend on the split (per-particle work, RNG keyed by the global
+// particle id; tests/test_gpu_dense_parity.py::test_split_launches_equal_single_launches).
+// Measured (A/B in one process, MJHMC_NO_SPLIT=1): C5 10.61 -> 10.18 ms per iteration, C3 19.57 -> 19.1-19.4.  Two
+// free-running samplers of half the batch each gain more (C3 -7.8 %, C5 -5.5 %): what is lost here is the wait between
+// the halves, which the roll-back contract of mjhmc_iterate (state after `done` iterations) requires.
+template <class A, typename S>
+static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pitch, int which) {
+  A h = a;
+  h.X_in = a.X_in + (size_t)start * pitch;
+  h.V_in = a.V_in + (size_t)start * pitch;
+  h.X_out = a.X_out + (size_t)start * pitch;
+  h.V_out = a.V_out + (size_t)start * pitch;
+  h.EX_in = a.EX_in + start;
+  h.EV_in = a.EV_in + start;
+  h.Hflf_in = a.Hflf_in + start;
+  h.Hwork = a.Hwork + start;
+  h.EX_out = a.EX_out + start;
+  h.EV_out = a.EV_out + start;
+  h.Hflf_out = a.Hflf_out + start;
+  h.dwell = a.dwell + start;
+  h.dwell_ring = a.dwell_ring + start;
+  h.trans = a.trans + start;
+  h.cold_list = a.cold_list + start;
+  h.cold_count = a.cold_count + which;
+  h.N = n;
+  h.Npad = npad;
+  h.first_pid = a.first_pid + start;
+  return h;
+}
+
+// one event per (iteration, half): an event object is never re-recorded while a wait on it may still be pending
+static int ensure_second_stream(mjhmc_sampler* s, int n_iter) {
+  if (!s->stream2) {
+    HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+  }
+  while ((int)s->ev_half.size() < 2 * n_iter) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));  // default flags: the record is a marker of its own in the stream (see half_args)
+    s->ev_half.push_back(e);
+  }
+  return 0;
+}
+
 template <typename T>
 static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
   const size_t mb = mat_bytes(s);
@@ -1162,16 +1218,36 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)2 * n_iter * sizeof(int), s->stream));
   }
 
+  // big dense batches: two halves on two streams (half_args)
+  int64_t split_at = 0;
+  if (s->en->is_dense() && s->mode == MJHMC_MODE_MJHMC && !replay_normal && !replay_exp && !replay_unif &&
+      !std::getenv("MJHMC_NO_SPLIT")) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      cus = std::max(1, cus);
+    }
+    const int ppt = s->en->is_sic() ? sic_particles_per_tile(s->en->sic_P) : 32;
+    const int64_t unit = 64 * (int64_t)ppt;  // whole tiles and whole 64-particle row groups on both sides
+    if ((s->N + ppt - 1) / ppt >= 2 * (int64_t)cus) split_at = (s->Npad / 2) / unit * unit;
+    if (split_at <= 0 || split_at >= s->N) split_at = 0;
+    if (split_at) TRY(ensure_second_stream(s, n_iter));
+  }
+
   std::vector<void*> xout(n_iter);
   void* xin = s->Xcur;
   HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i = 0; i < n_iter; ++i) {
     void* xo;
     double* dring = s->dwell_scratch;
+    bool ring_moved = false;
     if (ring_slot0 >= 0) {
       xo = (char*)s->ring + (size_t)(ring_slot0 + i) * mb;
       dring = s->dwell_ring + (size_t)(ring_slot0 + i) * s->Npad;
       if (xo == xin) {  // the live state sits in the slot about to be overwritten: move it out first
+        ring_moved = true;
         void* spare = s->Xbuf[0];
         HIPCHK(hipMemcpyAsync(spare, xin, mb, hipMemcpyDeviceToDevice, s->stream));
         xin = spare;
@@ -1189,6 +1265,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     if (replay_unif)
       HIPCHK(hipMemcpyAsync(s->runif, replay_unif + (size_t)i * (2 * s->N + 1), (2 * s->N + 1) * sizeof(double),
                             hipMemcpyHostToDevice, s->stream));
+    if (split_at && (i == 0 || ring_moved)) {  // the second stream continues from everything the first has been given so far
+      HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+      HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    }
     JumpArgs<T> a;
     a.X_in = (const T*)xin;
     a.V_in = (const T*)s->Vbuf[vi];
@@ -1272,7 +1352,41 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.r_mix = a.r_mix;
         pa.p_r = a.p_r;
         pa.key = a.key;
-        pot_launch_jump(pa, s->en->pot_model(), s->stream);
+        if (split_at > 0) {
+          PotJumpArgs h[2];
+          h[0] = half_args<PotJumpArgs, float>(pa, 0, split_at, split_at, (size_t)s->sh.pitch, 0);
+          h[0].G_in = pa.G_in;
+          h[0].G_out = pa.G_out;
+          h[0].ntiles = split_at / 32;
+          h[1] = half_args<PotJumpArgs, float>(pa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
+          h[1].G_in = pa.G_in + (size_t)split_at * s->sh.pitch;
+          h[1].G_out = pa.G_out + (size_t)split_at * s->sh.pitch;
+          h[1].ntiles = (s->Npad - split_at) / 32;
+          hipStream_t st[2] = {s->stream, s->stream2};
+          const PotModel mdl = s->en->pot_model();
+          if (i == 0)
+            for (int k = 0; k < 2; ++k) pot_launch_flf(h[k], mdl, st[k]);
+          // (both waits before either launch: a cross-stream wait was seen to cover everything the other stream had been
+          // given by the time of the call, not just the event's record)
+          if (i > 0)
+            for (int k = 0; k < 2; ++k)
+              HIPCHK(hipStreamWaitEvent(st[k], s->ev_half[2 * (i - 1) + (k ^ 1)], 0));  // the other half's jump kernel of iteration i-1
+          for (int k = 0; k < 2; ++k) pot_launch_jump_only(h[k], mdl, st[k]);
+          for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_half[2 * i + k], st[k]));
+          if (i + 1 < n_iter)
+            for (int k = 0; k < 2; ++k) {  // iteration i+1 reads what this one writes
+              PotJumpArgs nx = h[k];
+              nx.X_in = h[k].X_out;
+              nx.V_in = h[k].V_out;
+              nx.G_in = h[k].G_out;
+              nx.Hflf_in = h[k].Hflf_out;
+              nx.stats = h[k].stats + 4;
+              nx.iter = h[k].iter + 1;
+              pot_launch_flf(nx, mdl, st[k]);
+            }
+        } else {
+          pot_launch_jump(pa, s->en->pot_model(), s->stream);
+        }
       }
     } else if (s->en->is_sic()) {
       if constexpr (sizeof(T) == 4) {
@@ -1313,7 +1427,36 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         sa.r_mix = a.r_mix;
         sa.p_r = a.p_r;
         sa.key = a.key;
-        sic_launch_jump(sa, s->en->sic_model(), s->stream);
+        if (split_at > 0) {
+          SicJumpArgs h[2];
+          h[0] = half_args<SicJumpArgs, __bf16>(sa, 0, split_at, split_at, (size_t)s->sh.pitch, 0);
+          h[0].ntiles = split_at / ppt;
+          h[1] = half_args<SicJumpArgs, __bf16>(sa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
+          h[1].ntiles = (s->N - split_at + ppt - 1) / ppt;
+          hipStream_t st[2] = {s->stream, s->stream2};
+          const SicModel mdl = s->en->sic_model();
+          if (i == 0)
+            for (int k = 0; k < 2; ++k) sic_launch_flf(h[k], mdl, st[k]);
+          // (both waits before either launch: a cross-stream wait was seen to cover everything the other stream had been
+          // given by the time of the call, not just the event's record)
+          if (i > 0)
+            for (int k = 0; k < 2; ++k)
+              HIPCHK(hipStreamWaitEvent(st[k], s->ev_half[2 * (i - 1) + (k ^ 1)], 0));  // the other half's jump kernel of iteration i-1
+          for (int k = 0; k < 2; ++k) sic_launch_jump_only(h[k], mdl, st[k]);
+          for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_half[2 * i + k], st[k]));
+          if (i + 1 < n_iter)
+            for (int k = 0; k < 2; ++k) {  // iteration i+1 reads what this one writes
+              SicJumpArgs nx = h[k];
+              nx.X_in = h[k].X_out;
+              nx.V_in = h[k].V_out;
+              nx.Hflf_in = h[k].Hflf_out;
+              nx.stats = h[k].stats + 4;
+              nx.iter = h[k].iter + 1;
+              sic_launch_flf(nx, mdl, st[k]);
+            }
+        } else {
+          sic_launch_jump(sa, s->en->sic_model(), s->stream);
+        }
       }
     } else {
       // Compacted passes around the jump kernel (big batches with several particles per wave):
@@ -1385,6 +1528,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         launch_refresh<T>(ra, s->sh.E, s->N, s->stream);
       }
     }
+    if (split_at && i + 1 == n_iter) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_half[2 * i + 1], 0));  // the read-back follows both halves
     HIPCHK(hipGetLastError());
     xin = xo;
   }

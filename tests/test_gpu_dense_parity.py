@@ -386,3 +386,47 @@ def test_sic_512_atoms_control_arm_and_leapfrog():
     assert np.abs(Z.X - Zo.X).max() <= np.abs(Zo.X).max() / 128
     scale = float(np.abs(Zo.H()).max())
     assert np.abs(Z.EX - Zo.EX).max() <= 5e-4 * scale and np.abs(Z.EV - Zo.EV).max() <= 5e-4 * scale
+
+
+# ---------------------------------------------------------------------------------------------
+# big dense batches are launched as two halves on two streams (api.hip: half_args): invisible in the results
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('what', ['pot36', 'sic_p1', 'sic_p9'])
+def test_split_launches_equal_single_launches(what, monkeypatch):
+    from mjhmc_amd import engine, _lib
+    ctx = engine.context(0)
+    if what == 'pot36':
+        D, N, dtype = 36, 20000, 'float32'
+        W, lognu = ref_init_weights(D, D)
+        params = np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)])
+        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, params)
+        X0 = np.random.RandomState(3).randn(D, N)
+        hp = (0.1, 6, 0.1)
+    else:
+        P, N = (1, 17000) if what == 'sic_p1' else (9, 6100)
+        B, imgs, a0 = sic_problem(0, n_patches=P)
+        D, dtype = P * 1024, 'bfloat16'
+        params = np.concatenate([[float(P), 256.0, 1024.0, 0.01, 1.0], B.ravel(), imgs[:, :P].T.ravel()])
+        en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, D, params)
+        X0 = a0[:, None] + 0.2 * np.random.RandomState(4).randn(D, N)
+        hp = (0.0625, 3, 0.1)
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype) for _ in range(2)]
+    fields = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
+    all_stats = [[], []]
+    for n_it in (1, 3, 2):
+        for k, s in enumerate(pair):
+            s.set_hparams(hp[0], hp[1], hp[2], 1.0)
+            if k == 1:
+                monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+            else:
+                monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+            st, done = s.iterate(n_it)
+            assert done == n_it
+            all_stats[k] += [(t.l, t.f, t.r, t.n_cold, t.E_evals, t.dEdX_evals) for t in st]
+        monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+        for f in fields:
+            fa, fb = pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f))
+            assert np.array_equal(fa, fb, equal_nan=True), (what, n_it, f)
+    assert all_stats[0] == all_stats[1]
+    for s in pair:
+        s.close()
