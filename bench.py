@@ -172,6 +172,7 @@ class Rig(object):
         from mjhmc_amd import engine
         self.ctx = engine.context(self.local_rank)
         self.comm = None
+        self.comm_note = None
         if self.world > 1:
             # RCCL (and gloo) print a banner on stdout when a communicator comes up; stdout carries the ONE JSON line
             sys.stdout.flush()
@@ -192,7 +193,15 @@ class Rig(object):
             self.comm = Comm()
         else:
             from mjhmc_amd.parallel import RcclComm
-            self.comm = RcclComm(self.rank, self.world, device=self.local_rank)
+            try:
+                self.comm = RcclComm(self.rank, self.world, device=self.local_rank)
+            except Exception as exc:  # e.g. librccl not loadable: the timing needs only a barrier and a MAX -- keep the line
+                self.comm_note = 'RCCL communicator failed (%s); barrier / MAX through torch.distributed gloo' % repr(exc)[:200]
+                sys.stderr.write('rank %d: %s\n' % (self.rank, self.comm_note))
+                import torch.distributed as dist
+                from mjhmc_amd.parallel import Comm
+                dist.init_process_group('gloo')
+                self.comm = Comm()
 
     def barrier(self, smp):
         smp.sync()
@@ -460,6 +469,8 @@ def main():
             out['boundary'] = h['boundary']
         if gather_info is not None:
             out['config'] = dict(out['config'], sample_gather=gather_info)
+        if rig.comm_note:
+            out['config'] = dict(out['config'], comm_note=rig.comm_note)
         if len(keys) > 1:
             out['workloads'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world, scaling=args.scaling)
                                 for k, v in results.items()}
