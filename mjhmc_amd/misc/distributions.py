@@ -306,6 +306,16 @@ class TestGaussian(Distribution):
         return hash((self.ndims, self.sigma))
 
 
+class TFGaussian(TestGaussian):
+    """The reference's TensorFlow twin of TestGaussian (mjhmc/misc/tf_distributions.py:179-201; float32 there because the
+    placeholder is, `state_dtype='float32'` selects the same here); extra keyword arguments (``device``, ...) are the
+    TensorFlow plumbing of the reference and are accepted and ignored."""
+
+    def __init__(self, ndims=2, nbatch=100, sigma=1., state_dtype='float64', **kwargs):
+        self.state_dtype = state_dtype
+        super(TFGaussian, self).__init__(ndims=ndims, nbatch=nbatch, sigma=sigma)
+
+
 class Funnel(Distribution):
     """Neal's funnel (mjhmc/misc/tf_distributions.py:142-177).
 

@@ -182,3 +182,54 @@ class DeviceHMCState(object):
 
     def reset_flf_cache(self):
         self.parent._dev.reset_flf_cache()
+
+    # -- the reference's state operators on the LIVE state (hmc_state.py:62-148: there `sampler.state` is the HMCState
+    #    itself, so `sampler.state.L()` moves the sampler).  Here: snapshot, operate, write X and V back -- the write
+    #    re-derives EX / EV / dE/dX on the device and clears the inverse-L cache, as a move does.
+    def _apply(self, op):
+        Z = self.copy()
+        op(Z)
+        self.parent.state = Z
+        return self
+
+    def leapfrog(self):
+        self._apply(lambda Z: Z.leapfrog())
+
+    def L(self):
+        return self._apply(lambda Z: Z.L())
+
+    def F(self):
+        return self._apply(lambda Z: Z.F())
+
+    def FLF(self):
+        return self._apply(lambda Z: Z.FLF())
+
+    def R(self):
+        return self._apply(lambda Z: Z.R())
+
+    def update(self, idx, Z):
+        """replace batch elements idx with state from Z"""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size:
+            self._apply(lambda S: S.update(idx, Z))
+
+    def _write_h_flf(self, h):
+        cols = slice(None) if getattr(self.parent, '_plan', None) is None else slice(*self.parent._plan.span(self.parent._comm.rank))
+        self.parent._dev.write(_lib.F_HFLF, np.ascontiguousarray(h[cols], dtype=np.float64))
+
+    def cache_flf_state(self, idx, Z):
+        """The device keeps H() of the cached inverse-L state, which is all the sampler ever reads of it
+        (markov_jump_hmc.py:367): columns idx take Z's."""
+        h = self.H_flf[0].copy()
+        h[idx] = np.asarray(Z.H())[0, idx]
+        self._write_h_flf(h)
+
+    def clear_flf_cache(self, idx):
+        h = self.H_flf[0].copy()
+        h[idx] = np.nan
+        self._write_h_flf(h)
+
+    @property
+    def cached_flf_state(self):
+        """Not materialised on the device (only its energy is: ``H_flf``)."""
+        return None
