@@ -330,7 +330,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
         roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
                 'traffic': measured_traffic(key, 1),
                 'kernel': ('pot_jump_kernel + pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel + sic_flf_kernel')
-                          + ' (one sampling iteration = both launches)',
+                          + ' (one sampling iteration = both kernels, launched as two half-batches on two streams)',
                 'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'algorithmic_flops_per_launch': flops,
                 'hbm': {'algorithmic_bytes_per_launch': 6.0 * w['D'] * esize * n_rank,
                         'achieved': 6.0 * w['D'] * esize * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s',

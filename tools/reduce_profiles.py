@@ -29,6 +29,17 @@ def counters(path):
     return out
 
 
+def launches_per_iteration(path, kernel):
+    """Big dense batches run as two halves on two streams (api.hip: half_args): the main kernel is then dispatched once per
+    half and iteration, from two queues."""
+    queues = set()
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if kernel in row['Kernel_Name']:
+                queues.add(row.get('Queue_Id'))
+    return max(1, len(queues))
+
+
 def find(d, suffix):
     for dirpath, _, files in os.walk(d):
         for fn in files:
@@ -66,7 +77,7 @@ def main():
                 per[c] = sum(big) / max(len(big), 1)
                 n_units = len(big)
             else:
-                n_units = len(main)
+                n_units = len(main) / float(launches_per_iteration(p, MAIN[w]))
                 per[c] = sum(ours) / n_units            # every kernel of an iteration, per iteration
             # keep a trimmed copy of the pass: our kernels only
             with open(p) as f, open(os.path.join(dst, '%s_pmc_%s.csv' % (w, c.lower())), 'w') as g:
