@@ -986,6 +986,12 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
 // Measured (A/B in one process, MJHMC_NO_SPLIT=1): C5 10.61 -> 10.18 ms per iteration, C3 19.57 -> 19.1-19.4.  Two
 // free-running samplers of half the batch each gain more (C3 -7.8 %, C5 -5.5 %): what is lost here is the wait between
 // the halves, which the roll-back contract of mjhmc_iterate (state after `done` iterations) requires.
+// Also measured and dropped: one tile per workgroup with the inverse-L passes on a third, high-priority stream.  The
+// dispatcher hands free CUs to the pending workgroups of the OLDEST dispatch first (a later kernel only fills what the
+// older one cannot use; a persistent grid of one workgroup per CU shuts out even a one-block memset until a workgroup
+// exits); priorities do let the inverse-L pass slip in, but the machine still drains at every iteration boundary --
+// jump(i+1) of either half must wait for both jump(i) -- which is the round that is lost.  Removing it needs one
+// iteration of skew between the halves, i.e. a third state buffer for the roll-back.
 template <class A, typename S>
 static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pitch, int which) {
   A h = a;
