@@ -743,9 +743,10 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   for (auto& e : s->ev_total)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : s->ev_k) (void)hipEventDestroy(e);
-  for (auto& e : s->ev_half)
-    if (e) (void)hipEventDestroy(e);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  for (void* q : s->ick)
+    if (q) (void)hipFree(q);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -973,25 +974,21 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
 // the state buffers of one parity and writes the other, so its input survives it: when some particle meets a
 // non-finite rate at iteration f (the reference aborts the WHOLE batch there, markov_jump_hmc.py:376-389) the
 // launch that contains f is run again for the iterations before f and the call returns n_done = f.
-// A big dense MJHMC batch is launched as TWO halves on two streams.  Every kernel of the dense path is a persistent grid
-// of one workgroup per CU, so a launch ends with a partial round (ProductOfT C3: 3125 tiles = 12.2 rounds of 256, then
-// the inverse-L pass of ~250 tiles another partial one: 14 rounds where 13.2 would do).  With two halves the inverse-L
-// pass of one half's NEXT iteration (cold list + pass: they only read the state and fill the H_flf work vector) runs
-// while the other half's jump kernel is still in its last rounds:
-//     stream h:  jump(i, h) . record J_h . inverse-L(i+1, h) . wait J_other . jump(i+1, h) ...
-// The state-changing kernels keep their order: a half's jump kernel of iteration i+1 starts only after BOTH halves'
-// jump kernels of iteration i are done, so the failure / roll-back rules are the ones of a single stream; the failure
-// flag and the tallies are shared.  Results cannot depend on the split (per-particle work, RNG keyed by the global
+// A big dense MJHMC batch is launched as TWO halves on two streams that run FREELY for the whole mjhmc_iterate call.
+// Every kernel of the dense path is a persistent grid of one workgroup per CU, so a launch ends with a partial round
+// (ProductOfT C3: 3125 tiles = 12.2 rounds of 256, then the inverse-L pass of ~250 tiles another partial one: 14 rounds
+// where 13.2 would do) and the machine drains at every launch boundary.  Two independent halves fill each other's
+// tails and never drain together.  Results cannot depend on the split (per-particle work, RNG keyed by the global
 // particle id; tests/test_gpu_dense_parity.py::test_split_launches_equal_single_launches).
-// Measured (A/B in one process, MJHMC_NO_SPLIT=1): C5 10.61 -> 10.18 ms per iteration, C3 19.57 -> 19.1-19.4.  Two
-// free-running samplers of half the batch each gain more (C3 -7.8 %, C5 -5.5 %): what is lost here is the wait between
-// the halves, which the roll-back contract of mjhmc_iterate (state after `done` iterations) requires.
-// Also measured and dropped: one tile per workgroup with the inverse-L passes on a third, high-priority stream.  The
-// dispatcher hands free CUs to the pending workgroups of the OLDEST dispatch first (a later kernel only fills what the
-// older one cannot use; a persistent grid of one workgroup per CU shuts out even a one-block memset until a workgroup
-// exits); priorities do let the inverse-L pass slip in, but the machine still drains at every iteration boundary --
-// jump(i+1) of either half must wait for both jump(i) -- which is the round that is lost.  Removing it needs one
-// iteration of skew between the halves, i.e. a third state buffer for the roll-back.
+// What the halves must NOT do is meet a non-finite rate while one of them is iterations ahead of the other: the
+// roll-back contract of mjhmc_iterate is "the state after `done` iterations", and with two state buffers an iteration
+// f+1 of the half that ran ahead has overwritten its own state of iteration f-1.  So a multi-iteration call first
+// copies the state aside (one device-to-device copy per call, < 0.2 % of it), and if the flag comes up it puts the copy
+// back and runs the call again the single-stream way, which stops at the failing iteration exactly as it always did.
+// Measured: two free-running samplers of half the batch each gain 7.8 % (C3) / 5.5 % (C5) over one; halves that met at
+// every iteration boundary (the first form of this) kept 1.5 % / 4 %: the dispatcher hands free CUs to the pending
+// workgroups of the OLDEST dispatch first, a persistent grid of one workgroup per CU shuts out even a one-block memset
+// until a workgroup exits, and a boundary at which both halves wait for each other is a drain again.
 template <class A, typename S>
 static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pitch, int which) {
   A h = a;
@@ -1017,16 +1014,24 @@ static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pi
   return h;
 }
 
-// one event per (iteration, half): an event object is never re-recorded while a wait on it may still be pending
-static int ensure_second_stream(mjhmc_sampler* s, int n_iter) {
-  if (!s->stream2) {
-    HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-  }
-  while ((int)s->ev_half.size() < 2 * n_iter) {
-    hipEvent_t e;
-    HIPCHK(hipEventCreate(&e));  // default flags: the record is a marker of its own in the stream (see half_args)
-    s->ev_half.push_back(e);
+static int ensure_second_stream(mjhmc_sampler* s) {
+  if (s->stream2) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  return 0;
+}
+
+// the state a multi-iteration split call starts from, copied aside / put back (the layout of mjhmc_checkpoint, own buffers)
+static int split_state_copy(mjhmc_sampler* s, bool restore) {
+  const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
+  const int nck = s->en->is_pot() ? 7 : 6;
+  const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
+  void* live[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell, s->Gbuf[s->vcur]};
+  for (int i = 0; i < nck; ++i) {
+    if (!s->ick[i]) HIPCHK(hipMalloc(&s->ick[i], sizes[i]));
+    if (restore) HIPCHK(hipMemcpyAsync(live[i], s->ick[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
+    else HIPCHK(hipMemcpyAsync(s->ick[i], live[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
   }
   return 0;
 }
@@ -1183,7 +1188,8 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
 
 template <typename T>
 static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
-                     const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
+                     const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done,
+                     bool allow_split = true) {
   // Fused launches: always for the Gaussian forces (one iteration is HBM-bound), for the other elementwise energies
   // while the batch is small (launch-/latency-bound) -- big batches of those take the compacted passes below instead.
   const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
@@ -1226,8 +1232,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
 
   // big dense batches: two halves on two streams (half_args)
   int64_t split_at = 0;
-  if (s->en->is_dense() && s->mode == MJHMC_MODE_MJHMC && !replay_normal && !replay_exp && !replay_unif &&
-      !std::getenv("MJHMC_NO_SPLIT")) {
+  if (allow_split && s->en->is_dense() && s->mode == MJHMC_MODE_MJHMC && !replay_normal && !replay_exp && !replay_unif &&
+      ring_slot0 < 0 && !std::getenv("MJHMC_NO_SPLIT")) {
     static int cus = 0;
     if (cus == 0) {
       int dev = 0;
@@ -1239,7 +1245,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     const int64_t unit = 64 * (int64_t)ppt;  // whole tiles and whole 64-particle row groups on both sides
     if ((s->N + ppt - 1) / ppt >= 2 * (int64_t)cus) split_at = (s->Npad / 2) / unit * unit;
     if (split_at <= 0 || split_at >= s->N) split_at = 0;
-    if (split_at) TRY(ensure_second_stream(s, n_iter));
+    if (split_at) {
+      TRY(ensure_second_stream(s));
+      if (n_iter > 1) TRY(split_state_copy(s, false));
+    }
   }
 
   std::vector<void*> xout(n_iter);
@@ -1248,12 +1257,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   for (int i = 0; i < n_iter; ++i) {
     void* xo;
     double* dring = s->dwell_scratch;
-    bool ring_moved = false;
     if (ring_slot0 >= 0) {
       xo = (char*)s->ring + (size_t)(ring_slot0 + i) * mb;
       dring = s->dwell_ring + (size_t)(ring_slot0 + i) * s->Npad;
       if (xo == xin) {  // the live state sits in the slot about to be overwritten: move it out first
-        ring_moved = true;
         void* spare = s->Xbuf[0];
         HIPCHK(hipMemcpyAsync(spare, xin, mb, hipMemcpyDeviceToDevice, s->stream));
         xin = spare;
@@ -1271,7 +1278,21 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     if (replay_unif)
       HIPCHK(hipMemcpyAsync(s->runif, replay_unif + (size_t)i * (2 * s->N + 1), (2 * s->N + 1) * sizeof(double),
                             hipMemcpyHostToDevice, s->stream));
-    if (split_at && (i == 0 || ring_moved)) {  // the second stream continues from everything the first has been given so far
+    if (const char* poison = std::getenv("MJHMC_DEBUG_POISON")) {
+      // test hook "iteration:particle": that particle's kinetic energy reads NaN in that iteration of the call -> its rates
+      // are not finite -> the whole-batch abort of markov_jump_hmc.py:376-389, at a chosen point of a multi-iteration call
+      int pit = -1;
+      long long pp = -1;
+      if (std::sscanf(poison, "%d:%lld", &pit, &pp) == 2 && pit == i && pp >= 0 && pp < s->N) {
+        static const double nan64 = __builtin_nan("");
+        static const float nan32 = __builtin_nanf("");
+        hipStream_t pst = (split_at && pp >= split_at) ? s->stream2 : s->stream;
+        if (split_at && i == 0 && pst == s->stream2) HIPCHK(hipStreamSynchronize(s->stream));  // (the fork below comes later)
+        HIPCHK(hipMemcpyAsync((char*)s->EV[si] + (size_t)pp * ssize(s), sizeof(T) == 8 ? (const void*)&nan64 : (const void*)&nan32,
+                              ssize(s), hipMemcpyHostToDevice, pst));
+      }
+    }
+    if (split_at && i == 0) {  // the second stream starts from everything the first has been given so far
       HIPCHK(hipEventRecord(s->ev_fork, s->stream));
       HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
     }
@@ -1368,28 +1389,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
           h[1].G_in = pa.G_in + (size_t)split_at * s->sh.pitch;
           h[1].G_out = pa.G_out + (size_t)split_at * s->sh.pitch;
           h[1].ntiles = (s->Npad - split_at) / 32;
-          hipStream_t st[2] = {s->stream, s->stream2};
-          const PotModel mdl = s->en->pot_model();
-          if (i == 0)
-            for (int k = 0; k < 2; ++k) pot_launch_flf(h[k], mdl, st[k]);
-          // (both waits before either launch: a cross-stream wait was seen to cover everything the other stream had been
-          // given by the time of the call, not just the event's record)
-          if (i > 0)
-            for (int k = 0; k < 2; ++k)
-              HIPCHK(hipStreamWaitEvent(st[k], s->ev_half[2 * (i - 1) + (k ^ 1)], 0));  // the other half's jump kernel of iteration i-1
-          for (int k = 0; k < 2; ++k) pot_launch_jump_only(h[k], mdl, st[k]);
-          for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_half[2 * i + k], st[k]));
-          if (i + 1 < n_iter)
-            for (int k = 0; k < 2; ++k) {  // iteration i+1 reads what this one writes
-              PotJumpArgs nx = h[k];
-              nx.X_in = h[k].X_out;
-              nx.V_in = h[k].V_out;
-              nx.G_in = h[k].G_out;
-              nx.Hflf_in = h[k].Hflf_out;
-              nx.stats = h[k].stats + 4;
-              nx.iter = h[k].iter + 1;
-              pot_launch_flf(nx, mdl, st[k]);
-            }
+          pot_launch_jump(h[0], s->en->pot_model(), s->stream);
+          pot_launch_jump(h[1], s->en->pot_model(), s->stream2);
         } else {
           pot_launch_jump(pa, s->en->pot_model(), s->stream);
         }
@@ -1439,27 +1440,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
           h[0].ntiles = split_at / ppt;
           h[1] = half_args<SicJumpArgs, __bf16>(sa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
           h[1].ntiles = (s->N - split_at + ppt - 1) / ppt;
-          hipStream_t st[2] = {s->stream, s->stream2};
-          const SicModel mdl = s->en->sic_model();
-          if (i == 0)
-            for (int k = 0; k < 2; ++k) sic_launch_flf(h[k], mdl, st[k]);
-          // (both waits before either launch: a cross-stream wait was seen to cover everything the other stream had been
-          // given by the time of the call, not just the event's record)
-          if (i > 0)
-            for (int k = 0; k < 2; ++k)
-              HIPCHK(hipStreamWaitEvent(st[k], s->ev_half[2 * (i - 1) + (k ^ 1)], 0));  // the other half's jump kernel of iteration i-1
-          for (int k = 0; k < 2; ++k) sic_launch_jump_only(h[k], mdl, st[k]);
-          for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_half[2 * i + k], st[k]));
-          if (i + 1 < n_iter)
-            for (int k = 0; k < 2; ++k) {  // iteration i+1 reads what this one writes
-              SicJumpArgs nx = h[k];
-              nx.X_in = h[k].X_out;
-              nx.V_in = h[k].V_out;
-              nx.Hflf_in = h[k].Hflf_out;
-              nx.stats = h[k].stats + 4;
-              nx.iter = h[k].iter + 1;
-              sic_launch_flf(nx, mdl, st[k]);
-            }
+          sic_launch_jump(h[0], s->en->sic_model(), s->stream);
+          sic_launch_jump(h[1], s->en->sic_model(), s->stream2);
         } else {
           sic_launch_jump(sa, s->en->sic_model(), s->stream);
         }
@@ -1534,7 +1516,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         launch_refresh<T>(ra, s->sh.E, s->N, s->stream);
       }
     }
-    if (split_at && i + 1 == n_iter) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_half[2 * i + 1], 0));  // the read-back follows both halves
+    if (split_at && i + 1 == n_iter) {  // the read-back follows both halves
+      HIPCHK(hipEventRecord(s->ev_join, s->stream2));
+      HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    }
     HIPCHK(hipGetLastError());
     xin = xo;
   }
@@ -1544,6 +1529,15 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   HIPCHK(hipMemcpyAsync(&hc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipMemcpyAsync(hs.data(), s->stats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
+
+  if (hc.failed && split_at && n_iter > 1) {
+    // a non-finite rate somewhere in the free-running halves: back to the state the call started from, and once more
+    // on one stream -- that run stops at the failing iteration with the state, tallies and RNG position of a call that
+    // was never split (nothing of this attempt has been committed: parities, Xcur and the tick are still the call's)
+    TRY(split_state_copy(s, true));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return iterate_t<T>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done, false);
+  }
 
   const int done = hc.failed ? hc.failed_iter : n_iter;
   const int attempts = hc.failed ? done + 1 : n_iter;

@@ -643,33 +643,6 @@ void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) 
   else launch_jump_nb<4>(a, mdl, st);
 }
 
-// the two stages of an MJHMC iteration on their own (api.hip launches big batches as two halves whose inverse-L passes
-// overlap the other half's jump kernel): cold list + inverse-L pass, and the jump kernel alone
-static unsigned split_grid(int64_t ntiles) {
-  // (one tile per workgroup, MJHMC_SPLIT_WIDE=1, was measured too: no better than the persistent grids)
-  static const bool persistent = std::getenv("MJHMC_SPLIT_WIDE") == nullptr;
-  return (unsigned)(persistent ? std::min<int64_t>(ntiles, resident_cus()) : ntiles);
-}
-template <int NB>
-static void launch_flf_nb(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
-  const unsigned grid = split_grid(a.ntiles);
-  (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-  hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
-                     a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
-  hipLaunchKernelGGL(pot_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
-}
-void pot_launch_flf(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
-  if (mdl.dim == 128) launch_flf_nb<1>(a, mdl, st);
-  else if (mdl.dim == 256) launch_flf_nb<2>(a, mdl, st);
-  else launch_flf_nb<4>(a, mdl, st);
-}
-void pot_launch_jump_only(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
-  const unsigned grid = split_grid(a.ntiles);
-  if (mdl.dim == 128) launch_jump_mode<1, kModeMJHMC>(a, mdl, grid, st);
-  else if (mdl.dim == 256) launch_jump_mode<2, kModeMJHMC>(a, mdl, grid, st);
-  else launch_jump_mode<4, kModeMJHMC>(a, mdl, grid, st);
-}
-
 void pot_launch_leap(const PotLeapArgs& a, const PotModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus());
   if (mdl.dim == 128) hipLaunchKernelGGL(pot_leap_kernel<1>, dim3(grid), dim3(256), 0, st, a, mdl);

@@ -195,9 +195,6 @@ __device__ __forceinline__ void normal_pair_f32(const RngKey& k, uint32_t pid, u
 }
 
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
-// MJHMC mode, the two stages separately: cold list + inverse-L pass; the jump kernel alone
-void pot_launch_flf(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
-void pot_launch_jump_only(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_eval(const PotEvalArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_leap(const PotLeapArgs& a, const PotModel& mdl, hipStream_t st);
 

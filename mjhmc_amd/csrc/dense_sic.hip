@@ -764,34 +764,6 @@ void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) 
   SIC_DISPATCH(SIC_JUMP);
 }
 
-// the two stages of an MJHMC iteration on their own (see pot_launch_flf)
-static unsigned split_grid(int64_t ntiles) {
-  // (one tile per workgroup, MJHMC_SPLIT_WIDE=1, was measured too: no better than the persistent grids)
-  static const bool persistent = std::getenv("MJHMC_SPLIT_WIDE") == nullptr;
-  return (unsigned)(persistent ? std::min<int64_t>(ntiles, sic_cus()) : ntiles);
-}
-template <bool CAUCHY, int NB>
-static void sic_launch_flf_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-  const unsigned grid = split_grid(a.ntiles);
-  (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-  hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork, a.N,
-                     a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
-  hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
-}
-void sic_launch_flf(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-#define SIC_FLF(C, NBV) sic_launch_flf_t<C, NBV>(a, mdl, st)
-  SIC_DISPATCH(SIC_FLF);
-}
-template <bool CAUCHY, int NB>
-static void sic_launch_jump_only_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-  const unsigned grid = split_grid(a.ntiles);
-  sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
-}
-void sic_launch_jump_only(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-#define SIC_JUMP_ONLY(C, NBV) sic_launch_jump_only_t<C, NBV>(a, mdl, st)
-  SIC_DISPATCH(SIC_JUMP_ONLY);
-}
-
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
 #define SIC_EVAL(C, NBV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)

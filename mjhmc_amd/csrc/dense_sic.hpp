@@ -80,8 +80,6 @@ struct SicEvalArgs {
 };
 
 void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st);
-void sic_launch_flf(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st);        // MJHMC: cold list + inverse-L pass
-void sic_launch_jump_only(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st);  // MJHMC: the jump kernel alone
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st);
 void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st);
 // particles per 32-column tile: a tile holds whole particles (P columns each)

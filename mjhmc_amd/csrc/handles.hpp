@@ -76,7 +76,8 @@ struct mjhmc_sampler {
   Shape sh;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second half of a big dense batch (iterate_t: split launches)
-  std::vector<hipEvent_t> ev_half;             // [2 * iteration + half]: "this half's jump kernel of that iteration is done"
+  hipEvent_t ev_join = nullptr;                // "the second stream's half of this call is done"
+  void* ick[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the split schedule's own checkpoint (as ck[])
   hipEvent_t ev_fork = nullptr;                // "everything the first stream has been given so far"
   void* Xbuf[2] = {nullptr, nullptr};
   void* Vbuf[2] = {nullptr, nullptr};

@@ -430,3 +430,60 @@ def test_split_launches_equal_single_launches(what, monkeypatch):
     assert all_stats[0] == all_stats[1]
     for s in pair:
         s.close()
+
+
+@pytest.mark.parametrize('what,poison', [('sic_p1', '4:300'), ('sic_p1', '6:16000'), ('pot36', '3:19000'), ('pot36', '0:5')])
+def test_split_launches_failure_in_the_middle_of_a_call(what, poison, monkeypatch):
+    """A non-finite rate while the two halves of a big dense batch run freely: the call must end exactly like a call
+    that was never split -- same `done`, same state, same tallies of the good iterations -- (api.hip: the state copy
+    taken at the start of the call is put back and the call re-run on one stream).  The failure is placed with the
+    library's test hook MJHMC_DEBUG_POISON=iteration:particle (that particle's kinetic energy reads NaN there)."""
+    from mjhmc_amd import engine, _lib
+    ctx = engine.context(0)
+    if what == 'pot36':
+        D, N, dtype = 36, 20000, 'float32'
+        W, lognu = ref_init_weights(D, D)
+        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)]))
+        X0 = np.random.RandomState(3).randn(D, N)
+        hp = (0.1, 6, 0.1)
+    else:
+        N, dtype = 17000, 'bfloat16'
+        B, imgs, a0 = sic_problem(0)
+        en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, 1024,
+                                 np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), imgs[:, :1].T.ravel()]))
+        X0 = a0[:, None] + 0.2 * np.random.RandomState(4).randn(1024, N)
+        hp = (0.0625, 3, 0.1)
+    it = int(poison.split(':')[0])
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype) for _ in range(2)]
+    res = []
+    monkeypatch.setenv('MJHMC_DEBUG_POISON', poison)
+    for k, s in enumerate(pair):
+        s.set_hparams(hp[0], hp[1], hp[2], 1.0)
+        if k == 1:
+            monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+        else:
+            monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+        st, done = s.iterate(8)
+        res.append((done, [(t.l, t.f, t.r, t.n_cold, t.E_evals, t.dEdX_evals) for t in st[:done]], st[done].nonfinite))
+    monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+    monkeypatch.delenv('MJHMC_DEBUG_POISON', raising=False)
+    assert res[0] == res[1] and res[0][0] == it and res[0][2] == 1
+    fields = ('X', 'V', 'EX', 'EV', 'HFLF')
+    for f in fields:
+        fa, fb = pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f))
+        assert np.array_equal(fa, fb, equal_nan=True), f
+    # the poisoned value is part of the committed state (it was an input of the failing iteration): heal it, then the
+    # retry protocol continues identically in both forms
+    for s in pair:
+        s.write(_lib.F_V, s.read(_lib.F_V))            # re-derives EV
+        s.set_hparams(hp[0] / 2, 2 * hp[1], hp[2], 1.0)
+        s.reset_flf_cache()
+    a, da = pair[0].iterate(3)
+    monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+    b, db = pair[1].iterate(3)
+    monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+    assert da == db == 3
+    for f in fields + ('DWELL', 'TRANS'):
+        assert np.array_equal(pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f)), equal_nan=True), f
+    for s in pair:
+        s.close()
