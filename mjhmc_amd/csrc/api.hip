@@ -743,6 +743,8 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   for (auto& e : s->ev_total)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : s->ev_k) (void)hipEventDestroy(e);
+  for (auto& e : s->part_events) (void)hipEventDestroy(e);
+  for (auto& q : s->part_streams) (void)hipStreamDestroy(q);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   for (void* q : s->ick)
@@ -1064,6 +1066,26 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     void* xin;
     void* xout;
   };
+  int64_t split_at = 0;  // particles per part
+  int n_parts = 3;       // C2: 2 / 3 / 4 / 8 parts measured 0.0803 / 0.0779 / 0.0803 / 0.0782 ms per iteration, unsplit 0.0855
+  bool allow_split_now = true;  // (the recovery launch runs on one stream)
+  if (n_iter <= kMaxFuse && ring_slot0 < 0 && s->mode == MJHMC_MODE_MJHMC && !std::getenv("MJHMC_NO_SPLIT")) {
+    if (const char* np = std::getenv("MJHMC_SPLIT_PARTS")) n_parts = std::max(2, std::min(8, std::atoi(np)));
+    const int64_t nslots = s->Npad >> (6 - s->sh.logG);
+    if (nslots >= 8 * 4096) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part
+    if (split_at <= 0 || split_at * (n_parts - 1) >= s->N) split_at = 0;
+    if (split_at) {
+      TRY(ensure_second_stream(s));
+      while ((int)s->part_streams.size() < n_parts - 1) {
+        hipStream_t q;
+        hipEvent_t e;
+        HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->part_streams.push_back(q);
+        s->part_events.push_back(e);
+      }
+    }
+  }
   auto launch = [&](const Launch& l, long long* stats) -> int {
     JumpArgs<T> a;
     a.X_in = (const T*)l.xin;
@@ -1113,7 +1135,44 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     const uint64_t tick = s->tick + (uint64_t)l.i0;
     a.key = RngKey{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), (uint32_t)(tick & 0xFFFFFFFFu),
                    (uint32_t)(tick >> 32)};
-    TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+    if (split_at > 0 && allow_split_now) {
+      // several parts on as many streams: a launch is a persistent grid of one slot (here: up to 64 iterations of a
+      // particle) per wave and pass, so it ends with a partial pass (C2: 100 000 slots on 4096 resident waves = 24.4
+      // passes, 25 paid), and its workgroups all sit in the same phase of their slots at the same time; the parts'
+      // workgroups start on the CUs the earlier parts leave and run out of step with them.  One fused launch per call
+      // only: the recovery protocol below relies on the inputs of the failing launch being intact.
+      HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+      for (int k = 0; k < n_parts; ++k) {
+        const int64_t start = (int64_t)k * split_at, stop = (k + 1 == n_parts) ? a.N : start + split_at;
+        JumpArgs<T> h = a;
+        const size_t po = (size_t)start * a.pitch;
+        h.X_in = a.X_in + po;
+        h.V_in = a.V_in + po;
+        h.X_out = a.X_out + po;
+        h.V_out = a.V_out + po;
+        h.EX_in = a.EX_in + start;
+        h.EV_in = a.EV_in + start;
+        h.EX_out = a.EX_out + start;
+        h.EV_out = a.EV_out + start;
+        h.Hflf_in = a.Hflf_in + start;
+        h.Hflf_out = a.Hflf_out + start;
+        h.dwell = a.dwell + start;
+        h.dwell_ring = a.dwell_ring + start;
+        h.trans = a.trans + start;
+        h.first_pid = a.first_pid + start;
+        h.N = stop - start;
+        h.Npad = (k + 1 == n_parts) ? a.Npad - start : split_at;
+        hipStream_t q = k == 0 ? s->stream : s->part_streams[(size_t)k - 1];
+        if (k > 0) HIPCHK(hipStreamWaitEvent(q, s->ev_fork, 0));
+        TRY(dispatch_jump<T>(s->en->ep.kind, h, s->en->ep, s->sh.E, q));
+        if (k > 0) {
+          HIPCHK(hipEventRecord(s->part_events[(size_t)k - 1], q));
+          HIPCHK(hipStreamWaitEvent(s->stream, s->part_events[(size_t)k - 1], 0));
+        }
+      }
+    } else {
+      TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
+    }
     HIPCHK(hipGetLastError());
     return 0;
   };
@@ -1122,6 +1181,16 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     return (in != s->Xbuf[0]) ? s->Xbuf[0] : s->Xbuf[1];
   };
 
+  if (const char* poison = std::getenv("MJHMC_DEBUG_POISON")) {  // test hook, see iterate_t (fused launches: iteration 0 only)
+    int pit = -1;
+    long long pp = -1;
+    if (std::sscanf(poison, "%d:%lld", &pit, &pp) == 2 && pit == 0 && pp >= 0 && pp < s->N) {
+      static const double nan64 = __builtin_nan("");
+      static const float nan32 = __builtin_nanf("");
+      HIPCHK(hipMemcpyAsync((char*)s->EV[s->scur] + (size_t)pp * ssize(s), sizeof(T) == 8 ? (const void*)&nan64 : (const void*)&nan32,
+                            ssize(s), hipMemcpyHostToDevice, s->stream));
+    }
+  }
   std::vector<Launch> launches;
   HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i0 = 0; i0 < n_iter; i0 += kMaxFuse) {
@@ -1158,6 +1227,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
       long long* redo_stats = s->stats + 4 * (size_t)n_iter;
       HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
       HIPCHK(hipMemsetAsync(redo_stats, 0, (size_t)kMaxFuse * 4 * sizeof(long long), s->stream));
+      allow_split_now = false;
       TRY(launch(l, redo_stats));
       Control rc;
       std::vector<long long> rs((size_t)l.K * 4);

@@ -76,6 +76,8 @@ struct mjhmc_sampler {
   Shape sh;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second half of a big dense batch (iterate_t: split launches)
+  std::vector<hipStream_t> part_streams;   // further parts of a split fused launch (iterate_fused_t)
+  std::vector<hipEvent_t> part_events;
   hipEvent_t ev_join = nullptr;                // "the second stream's half of this call is done"
   void* ick[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the split schedule's own checkpoint (as ck[])
   hipEvent_t ev_fork = nullptr;                // "everything the first stream has been given so far"

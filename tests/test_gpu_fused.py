@@ -226,3 +226,41 @@ def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
             break
     if mid == 0:
         pytest.skip('no initial scale with a first failure in the middle of the batch')
+
+
+@pytest.mark.parametrize('kind,D,N', [('E_ISO_GAUSS', 512, 33000), ('E_DIAG_GAUSS', 64, 263000)])
+def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch):
+    """A big fused launch runs as two halves on two streams (api.hip, iterate_fused_t): invisible in the results, and a
+    non-finite rate in either half ends the call like an unsplit one."""
+    from mjhmc_amd import _lib
+    params = list(10.0 ** np.linspace(-1, 0, D)) if kind == 'E_DIAG_GAUSS' else [1.0]
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params)
+    for s in (a, b):
+        s.set_hparams(0.1, 4, 0.1, 1.0, 0.5)
+    for n_it in (6, 1, 3):
+        monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+        sa, da = a.iterate(n_it)
+        monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+        sb, db = b.iterate(n_it)
+        monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+        assert da == db == n_it
+        assert [_stats_tuple(t) for t in sa] == [_stats_tuple(t) for t in sb]
+        _same_state(a, b, _lib)
+    for poison in ('0:7', '0:%d' % (N - 3)):                       # first half, second half
+        monkeypatch.setenv('MJHMC_DEBUG_POISON', poison)
+        sa, da = a.iterate(5)
+        monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+        sb, db = b.iterate(5)
+        monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+        monkeypatch.delenv('MJHMC_DEBUG_POISON', raising=False)
+        assert da == db == 0 and sa[0].nonfinite == 1 and sb[0].nonfinite == 1
+        _same_state(a, b, _lib, fields=('X', 'V', 'EX', 'EV', 'HFLF'))
+        for s in (a, b):
+            s.write(_lib.F_V, s.read(_lib.F_V))                    # heals the poisoned EV
+            s.reset_flf_cache()
+        sa, da = a.iterate(4)
+        monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+        sb, db = b.iterate(4)
+        monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+        assert da == db == 4
+        _same_state(a, b, _lib)
