@@ -1302,6 +1302,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
 
   // big dense batches: two halves on two streams (half_args)
   int64_t split_at = 0;
+  // (The elementwise compacted passes -- C4 -- were tried as 2 / 3 / 4 free-running parts the same way: 0.2727 ms per
+  // iteration unsplit, 0.2729 / 0.2744 / 0.310 split: their kernels leave room for each other already.)
   if (allow_split && s->en->is_dense() && s->mode == MJHMC_MODE_MJHMC && !replay_normal && !replay_exp && !replay_unif &&
       ring_slot0 < 0 && !std::getenv("MJHMC_NO_SPLIT")) {
     static int cus = 0;
