@@ -74,8 +74,8 @@ def main():
             fused = w == 'c2'
             if fused:      # fused launches only (the bench also runs a few one-iteration launches for the secondary figure)
                 big = [v for k, vals in cs.items() if MAIN[w] in k and k.rstrip().endswith('true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)') for v in vals]
-                per[c] = sum(big) / max(len(big), 1)
-                n_units = len(big)
+                n_units = max(len(big), 1) / float(launches_per_iteration(p, 'true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)'))
+                per[c] = sum(big) / n_units            # a fused launch runs as several parts on as many streams
             else:
                 n_units = len(main) / float(launches_per_iteration(p, MAIN[w]))
                 per[c] = sum(ours) / n_units            # every kernel of an iteration, per iteration
@@ -108,10 +108,11 @@ def main():
                 for cname, per_k in counters(p).items():
                     vals = [v for k, vs in per_k.items() if MAIN[w] in k and (w != 'c2' or 'true>(' in k) for v in vs]
                     if vals:
-                        sq[cname] = (sum(vals) / len(vals), len(vals))
+                        parts = launches_per_iteration(p, 'true>(' if w == 'c2' else MAIN[w])
+                        sq[cname] = (sum(vals) / (len(vals) / float(parts)), int(len(vals) / parts))
         if sq:
             with open(os.path.join(dst, '%s_pmc_sq.txt' % w), 'w') as g:
-                g.write('rocprofv3 --pmc passes (tools/profile_round.sh), dominant kernel %s, average per launch\n' % MAIN[w])
+                g.write('rocprofv3 --pmc passes (tools/profile_round.sh), dominant kernel %s, average per launch (all parts / halves of a split launch together)\n' % MAIN[w])
                 for k in sorted(sq):
                     g.write('%s %.6g  (over %d launches)\n' % (k, sq[k][0], sq[k][1]))
                 if 'SQ_INSTS_VALU' in sq and 'GRBM_GUI_ACTIVE' in sq:
