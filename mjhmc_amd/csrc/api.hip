@@ -1069,7 +1069,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   int64_t split_at = 0;  // particles per part
   int n_parts = 3;       // C2: 2 / 3 / 4 / 8 parts measured 0.0803 / 0.0779 / 0.0803 / 0.0782 ms per iteration, unsplit 0.0855
   bool allow_split_now = true;  // (the recovery launch runs on one stream)
-  if (n_iter <= kMaxFuse && ring_slot0 < 0 && s->mode == MJHMC_MODE_MJHMC && !std::getenv("MJHMC_NO_SPLIT")) {
+  if (ring_slot0 < 0 && s->mode == MJHMC_MODE_MJHMC && !std::getenv("MJHMC_NO_SPLIT")) {
     if (const char* np = std::getenv("MJHMC_SPLIT_PARTS")) n_parts = std::max(2, std::min(8, std::atoi(np)));
     const int64_t nslots = s->Npad >> (6 - s->sh.logG);
     if (nslots >= 8 * 4096) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part
@@ -1139,8 +1139,9 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
       // several parts on as many streams: a launch is a persistent grid of one slot (here: up to 64 iterations of a
       // particle) per wave and pass, so it ends with a partial pass (C2: 100 000 slots on 4096 resident waves = 24.4
       // passes, 25 paid), and its workgroups all sit in the same phase of their slots at the same time; the parts'
-      // workgroups start on the CUs the earlier parts leave and run out of step with them.  One fused launch per call
-      // only: the recovery protocol below relies on the inputs of the failing launch being intact.
+      // workgroups start on the CUs the earlier parts leave and run out of step with them.  The parts meet at the end of
+      // every fused launch (once per 64 iterations): the recovery protocol below relies on the inputs of the failing
+      // launch being intact, i.e. on no part having started the next launch.
       HIPCHK(hipEventRecord(s->ev_fork, s->stream));
       for (int k = 0; k < n_parts; ++k) {
         const int64_t start = (int64_t)k * split_at, stop = (k + 1 == n_parts) ? a.N : start + split_at;

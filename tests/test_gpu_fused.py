@@ -237,7 +237,7 @@ def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch):
     (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params)
     for s in (a, b):
         s.set_hparams(0.1, 4, 0.1, 1.0, 0.5)
-    for n_it in (6, 1, 3):
+    for n_it in (6, 1, 70 if D == 512 else 3):                     # 70: two fused launches, the parts meet in between
         monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
         sa, da = a.iterate(n_it)
         monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
