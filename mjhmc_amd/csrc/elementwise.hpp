@@ -1234,11 +1234,11 @@ __device__ __forceinline__ void decide_ct(const JumpArgs<T>& a, const RngKey& ke
 // ladder, group exchanges as quad_perm broadcasts instead of ds_bpermute (C4 -3 %, isotropic 32 x 10^6 fused -8 %).
 // WPP = 5 (FUSED MJHMC launches, G == 64): as WPP = 1, with the unit exponentials of all the launch's waiting-time
 // draws made UP FRONT.  They depend on (particle id, tick) only, and the Philox + log chain behind them is ~130 of
-// decide()'s ~190 vector instructions, which a wave-per-particle kernel otherwise spends on three useful lanes.  The
-// four waves of a workgroup walk four consecutive particles; at the top of a slot they fill an LDS table
-// [iteration][particle][clock] with every lane working on a different (particle, iteration, clock) -- 16 pairs per
-// vector pass instead of one -- and the iterations then run decide() from the table (same functions on the same
-// inputs: identical bits), with no barrier inside the iteration loop.
+// decide()'s ~190 vector instructions, which a wave-per-particle kernel otherwise spends on three useful lanes.  At the
+// top of a slot the wave fills its own stripe of an LDS table [iteration][clock], every quad of lanes working on a
+// different iteration -- 16 draws per vector pass instead of one -- and the iterations then run decide() from the
+// table (same functions on the same inputs: identical bits); no barrier is involved.
+// WPP = 6: the same with half a wavefront per particle (G == 32, two particles per slot).
 // FUSED = true: the launch runs a.n_fuse (<= kMaxFuse) consecutive sampling iterations per particle.  The
 // chains are independent, so between iterations nothing has to leave the wave: X, V, EX, EV, H_flf stay in
 // registers / the LDS stash, HBM sees one read and one write of the state per LAUNCH instead of per
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
   // before the current slot's trajectories start, so HBM latency hides behind the fp64 work.
-  constexpr bool BD = (WPP == 5 || WPP == 6);  // block-level decide: needs all four waves of the workgroup in lockstep per iteration
+  constexpr bool BD = (WPP == 5 || WPP == 6);  // the waiting-time draws of a slot's iterations are made up front (clock table in LDS)
   constexpr int kBdPpw = WPP == 6 ? 2 : 1;     // particles per wave of the block-decide forms
   static_assert(!BD || (FUSED && MODE == kModeMJHMC), "block-level decide exists for fused MJHMC launches");
   const int logG = WPP == 6 ? 5 : ((WPP == 1 || BD) ? 6 : (WPP == 3 ? 2 : a.logG));
@@ -1323,13 +1323,13 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
   // one slot ahead, which frees the second register set (one more wave per SIMD)
   if (!FUSED && wave < nslots) fetch(wave);
 
-  // BD: the workgroup's four waves walk the slots together (slot0 + wave), so that every wave meets every barrier;
-  // a wave without a slot of its own re-runs the last one and stores nothing
-  const int64_t slot_first = BD ? (int64_t)blockIdx.x * 4 : wave;
+  // (BD: every wave fills the clock table of its OWN slot -- a slot has n_it pairs, enough to keep all sixteen quads of
+  // the wave busy -- so the waves of a workgroup need no barrier and walk their slots independently like everyone else)
+  const int64_t slot_first = wave;
 #pragma unroll 1
   for (int64_t slot0 = slot_first; slot0 < nslots; slot0 += W) {
-    const bool have = !BD || slot0 + wib < nslots;
-    const int64_t slot = BD ? (have ? slot0 + wib : nslots - 1) : slot0;
+    const bool have = true;
+    const int64_t slot = slot0;
     const int64_t p = slot * ppw + gi;
     const bool alive = have && p < a.N;
     if constexpr (FUSED) fetch(slot);
@@ -1360,23 +1360,22 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
     T EXn, EVn, Hc;
     bool tally_cold = false, r_applied = false;
     if constexpr (BD) {
-      __syncthreads();  // every wave is done with the previous slot's table
+      // this wave's stripe of the table: [iteration][wave * kBdPpw + particle of the slot][clock]; written and read by this
+      // wave only (LDS operations of a wave execute in order)
       LaneMap mq = m;   // a quad of lanes per (particle, iteration) pair: lane 0 L clock, 1 R clock, 2 F clock
       mq.j = lane & 3;
       mq.G = 4;
       mq.lane0 = lane & ~3;
       mq.wpp = 3;
-      constexpr int kNpb = 4 * kBdPpw;  // particles the block's four waves hold
-      for (int r = wib * 16 + (lane >> 2); r - (lane >> 2) < kNpb * n_it; r += 64) {  // r = kNpb * iteration + particle
-        const int it = r / kNpb, q = r % kNpb;
+      for (int r = lane >> 2; r - (lane >> 2) < kBdPpw * n_it; r += 16) {  // r = kBdPpw * iteration + particle of the slot
+        const int it = r / kBdPpw, q = r % kBdPpw;
         RngKey kt = a.key;
         const uint32_t lo = kt.tick_lo + (uint32_t)it;
         kt.tick_hi += lo < kt.tick_lo ? 1u : 0u;
         kt.tick_lo = lo;
-        const double e = decide_draw(kt, mq, (uint32_t)(a.first_pid + slot0 * kBdPpw + q));
-        if (it < n_it && (lane & 3) < 3) bd_e[it][q][lane & 3] = e;
+        const double e = decide_draw(kt, mq, (uint32_t)(a.first_pid + slot * kBdPpw + q));
+        if (it < n_it && (lane & 3) < 3) bd_e[it][kBdPpw * wib + q][lane & 3] = e;
       }
-      __syncthreads();
     }
 #pragma unroll 1
     for (int it = 0; it < n_it; ++it) {
