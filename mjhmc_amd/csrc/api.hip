@@ -749,6 +749,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   for (void* q : s->ick)
     if (q) (void)hipFree(q);
+  if (s->h_pin) (void)hipHostFree(s->h_pin);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -1038,6 +1039,25 @@ static int split_state_copy(mjhmc_sampler* s, bool restore) {
   return 0;
 }
 
+// failure flag + tallies of a call, read back through pinned host memory (a pageable destination makes each of the two
+// small copies a synchronous staged transfer: ~20 us of every mjhmc_iterate call) and handed out after ONE stream sync
+static int read_back_call(mjhmc_sampler* s, const void* stats_dev, size_t stats_bytes, Control* hc, long long* hs) {
+  const size_t need = 64 + stats_bytes;
+  if (s->h_pin_cap < need) {
+    if (s->h_pin) HIPCHK(hipHostFree(s->h_pin));
+    s->h_pin = nullptr;
+    s->h_pin_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&s->h_pin, need * 2, hipHostMallocDefault));
+    s->h_pin_cap = need * 2;
+  }
+  HIPCHK(hipMemcpyAsync(s->h_pin, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(s->h_pin + 64, stats_dev, stats_bytes, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  std::memcpy(hc, s->h_pin, sizeof(Control));
+  std::memcpy(hs, s->h_pin + 64, stats_bytes);
+  return 0;
+}
+
 template <typename T>
 static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
   const size_t mb = mat_bytes(s);
@@ -1210,9 +1230,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
-  HIPCHK(hipMemcpyAsync(&hc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipMemcpyAsync(hs.data(), s->stats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
+  TRY(read_back_call(s, s->stats, hs.size() * sizeof(long long), &hc, hs.data()));
 
   int done = n_iter, attempts = n_iter, committed = (int)launches.size();
   void* xlive = launches.back().xout;
@@ -1599,9 +1617,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
-  HIPCHK(hipMemcpyAsync(&hc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipMemcpyAsync(hs.data(), s->stats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
+  TRY(read_back_call(s, s->stats, hs.size() * sizeof(long long), &hc, hs.data()));
 
   if (hc.failed && split_at && n_iter > 1) {
     // a non-finite rate somewhere in the free-running halves: back to the state the call started from, and once more

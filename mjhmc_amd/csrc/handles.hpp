@@ -76,6 +76,8 @@ struct mjhmc_sampler {
   Shape sh;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second half of a big dense batch (iterate_t: split launches)
+  char* h_pin = nullptr;          // pinned host staging of the per-call read-back (failure flag + tallies)
+  size_t h_pin_cap = 0;
   std::vector<hipStream_t> part_streams;   // further parts of a split fused launch (iterate_fused_t)
   std::vector<hipEvent_t> part_events;
   hipEvent_t ev_join = nullptr;                // "the second stream's half of this call is done"
