@@ -330,19 +330,25 @@ template <int NB>
 __device__ __forceinline__ void pot_trajectory(const PotModel& mdl, AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
                                                int lane, Tile<NB>& x, Tile<NB>& v, Tile<NB>& g, int L, float eps,
                                                float chalf, float* ex) {
-  for (int s = 0; s < L; ++s) {
-#pragma unroll
-    for (int r = 0; r < NB; ++r)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        v.b[r][q] = v.b[r][q] + chalf * g.b[r][q];
-        x.b[r][q] = x.b[r][q] + eps * v.b[r][q];
-      }
-    pot_gradient<NB>(mdl, ar, sh, w, c, h, lane, x, g, s == L - 1, ex);
+  // the closing half kick of a step and the opening one of the next use the same gradient: one kick of twice the size
+  // (float32 roundings differ from the reference's float64-state sequence either way; mjhmc/fast/hmc.py:6-98 merges too)
+  if (L > 0) {
 #pragma unroll
     for (int r = 0; r < NB; ++r)
 #pragma unroll
       for (int q = 0; q < 16; ++q) v.b[r][q] = v.b[r][q] + chalf * g.b[r][q];
+  }
+  for (int s = 0; s < L; ++s) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x.b[r][q] = x.b[r][q] + eps * v.b[r][q];
+    pot_gradient<NB>(mdl, ar, sh, w, c, h, lane, x, g, s == L - 1, ex);
+    const float ck = s == L - 1 ? chalf : 2.0f * chalf;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v.b[r][q] = v.b[r][q] + ck * g.b[r][q];
   }
 }
 
