@@ -228,7 +228,9 @@ def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
         pytest.skip('no initial scale with a first failure in the middle of the batch')
 
 
-@pytest.mark.parametrize('kind,D,N', [('E_ISO_GAUSS', 512, 33000), ('E_DIAG_GAUSS', 64, 263000)])
+@pytest.mark.parametrize('kind,D,N', [('E_ISO_GAUSS', 512, 33000), ('E_DIAG_GAUSS', 64, 263000),
+                                      ('E_ISO_GAUSS', 24, 530003),      # a quad of lanes per particle
+                                      ('E_ISO_GAUSS', 40, 270001)])     # ragged rows (predicated chunks)
 def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch):
     """A big fused launch runs as two halves on two streams (api.hip, iterate_fused_t): invisible in the results, and a
     non-finite rate in either half ends the call like an unsplit one."""
