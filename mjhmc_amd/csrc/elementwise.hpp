@@ -928,41 +928,6 @@ __device__ __forceinline__ double jump_rate(double dH) {
   return exp_normal(0.5 * dH);
 }
 
-// -log(u) for u in (0, 1), the unit exponential behind draw_from (utils.py:42): fdlibm's e_log.c scheme
-// (error < 1 ulp) without its special cases -- u53() never returns 0 or 1 and its smallest value 2^-54 is a
-// normal number.  About half the vector instructions and half the dependent-chain length of the library log
-// (which carries double-double intermediates).  (Feeding the coefficients from scalar registers through inline
-// asm saved more instructions but cost ~30 VGPRs and an occupancy step: measured slower.)
-__device__ __forceinline__ double neg_log_unit(double u) {
-  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
-  double m = __builtin_amdgcn_frexp_mant(u);  // [0.5, 1)
-  int k = __builtin_amdgcn_frexp_exp(u);
-  const bool low = m < __longlong_as_double(0x3fe6a09e667f3bcdLL);  // sqrt(1/2)
-  m = low ? m + m : m;  // [sqrt(1/2), sqrt(2))
-  k = low ? k - 1 : k;
-  const double f = m - 1.0;
-  const double t = 2.0 + f;
-  double rc = __builtin_amdgcn_rcp(t);  // s = f / t: reciprocal, two Newton steps, one residual correction
-  rc = __builtin_fma(__builtin_fma(-t, rc, 1.0), rc, rc);
-  rc = __builtin_fma(__builtin_fma(-t, rc, 1.0), rc, rc);
-  double sq = f * rc;
-  sq = __builtin_fma(__builtin_fma(-t, sq, f), rc, sq);
-  const double z = sq * sq;
-  const double w = z * z;
-  double t1 = w * __longlong_as_double(0x3fc39a09d078c69fLL) + __longlong_as_double(0x3fcc71c51d8e78afLL);  // Lg6, Lg4
-  t1 = w * __builtin_fma(w, t1, __longlong_as_double(0x3fd999999997fa04LL));                                        // Lg2
-  double t2 = w * __longlong_as_double(0x3fc2f112df3e5244LL) + __longlong_as_double(0x3fc7466496cb03deLL);  // Lg7, Lg5
-  t2 = __builtin_fma(w, t2, __longlong_as_double(0x3fd2492494229359LL));                                            // Lg3
-  t2 = z * __builtin_fma(w, t2, __longlong_as_double(0x3fe5555555555593LL));                                        // Lg1
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
-  const double dk = (double)k;
-  const double ln2_hi = __longlong_as_double(0x3fe62e42fee00000LL), ln2_lo = __longlong_as_double(0x3dea39ef35793c76LL);
-  const double e = ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f) - dk * ln2_hi;
-  __builtin_amdgcn_sched_barrier(0);  // chains kept compact: freely interleaved they were measured slower
-  return e;
-}
-
 __device__ __forceinline__ double wait_time(double rate, double e, bool& bad) {
   // utils.py:37-48: rate == 0 -> inf; finite -> exponential(scale=1/rate) == (1/rate)*std_exp; else error
   if (rate == 0.0) return __builtin_huge_val();

@@ -18,6 +18,11 @@ __global__ void eval(const double* dH, const double* u, double* rate, double* nl
   }
 }
 
+__global__ void eval_trig(const double* t, double* s, double* c, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mjhmc::sincospi_unit(t[i], s[i], c[i]);
+}
+
 static double ulps(double got, double want) {
   if (std::isnan(got) && std::isnan(want)) return 0;
   if (got == want) return 0;
@@ -70,6 +75,30 @@ int main() {
   }
   std::printf("n=%d  jump_rate: max %.0f ulp on the fast range, %.0f ulp on the literal ranges;  neg_log_unit: max %.0f ulp;  "
               "exp_any: max %.0f ulp (subnormal, inf, 0 and NaN results included)\n", n, worst_r, worst_special, worst_l, worst_e);
+  // sincospi_unit on [0, 2] (the Box-Muller angle 2 u2): against long double sin / cos of pi t, absolute error in units
+  // of 2^-53 (the values are <= 1 in magnitude; that is one ulp of [1/2, 1))
+  std::vector<double> tt;
+  for (int k = 0; k <= 400000; ++k) tt.push_back(2.0 * k / 400000.0);
+  for (double v : u) tt.push_back(2.0 * v);
+  const int m = (int)tt.size();
+  double *d_t, *d_s, *d_c;
+  hipMalloc(&d_t, m * 8);
+  hipMalloc(&d_s, m * 8);
+  hipMalloc(&d_c, m * 8);
+  hipMemcpy(d_t, tt.data(), m * 8, hipMemcpyHostToDevice);
+  eval_trig<<<(m + 255) / 256, 256>>>(d_t, d_s, d_c, m);
+  std::vector<double> ss(m), cc(m);
+  hipMemcpy(ss.data(), d_s, m * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(cc.data(), d_c, m * 8, hipMemcpyDeviceToHost);
+  double worst_t = 0;
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int i = 0; i < m; ++i) {
+    const long double ws = sinl(pi * (long double)tt[i]), wc = cosl(pi * (long double)tt[i]);
+    const double es = (double)fabsl((long double)ss[i] - ws) * 0x1p53;   // in units of 2^-53 = one ulp of [1/2, 1)
+    const double ec = (double)fabsl((long double)cc[i] - wc) * 0x1p53;
+    worst_t = std::fmax(worst_t, std::fmax(es, ec));
+  }
+  std::printf("sincospi_unit: max error %.2f x 2^-53 (one ulp of [1/2, 1)) over %d angles\n", worst_t, m);
   // the literal ranges run the device library's exp and sqrt (subnormal results: a few ulp from glibc's)
-  return (worst_r <= 2 && worst_special <= 16 && worst_l <= 2 && worst_e <= 2) ? 0 : 1;
+  return (worst_r <= 2 && worst_special <= 16 && worst_l <= 2 && worst_e <= 2 && worst_t <= 1.5) ? 0 : 1;
 }
