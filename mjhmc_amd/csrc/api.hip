@@ -977,7 +977,8 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
 // the state buffers of one parity and writes the other, so its input survives it: when some particle meets a
 // non-finite rate at iteration f (the reference aborts the WHOLE batch there, markov_jump_hmc.py:376-389) the
 // launch that contains f is run again for the iterations before f and the call returns n_done = f.
-// A big dense MJHMC batch is launched as TWO halves on two streams that run FREELY for the whole mjhmc_iterate call.
+// A big dense batch (every sampler mode) is launched as TWO halves on two streams that run FREELY for the whole
+// mjhmc_iterate call.
 // Every kernel of the dense path is a persistent grid of one workgroup per CU, so a launch ends with a partial round
 // (ProductOfT C3: 3125 tiles = 12.2 rounds of 256, then the inverse-L pass of ~250 tiles another partial one: 14 rounds
 // where 13.2 would do) and the machine drains at every launch boundary.  Two independent halves fill each other's
@@ -1323,7 +1324,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   int64_t split_at = 0;
   // (The elementwise compacted passes -- C4 -- were tried as 2 / 3 / 4 free-running parts the same way: 0.2727 ms per
   // iteration unsplit, 0.2729 / 0.2744 / 0.310 split: their kernels leave room for each other already.)
-  if (allow_split && s->en->is_dense() && s->mode == MJHMC_MODE_MJHMC && !replay_normal && !replay_exp && !replay_unif &&
+  if (allow_split && s->en->is_dense() && !replay_normal && !replay_exp && !replay_unif &&
       ring_slot0 < 0 && !std::getenv("MJHMC_NO_SPLIT")) {
     static int cus = 0;
     if (cus == 0) {

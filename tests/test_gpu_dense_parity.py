@@ -391,10 +391,12 @@ def test_sic_512_atoms_control_arm_and_leapfrog():
 # ---------------------------------------------------------------------------------------------
 # big dense batches are launched as two halves on two streams (api.hip: half_args): invisible in the results
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('what', ['pot36', 'sic_p1', 'sic_p9'])
+@pytest.mark.parametrize('what', ['pot36', 'sic_p1', 'sic_p9', 'pot36_control', 'sic_p1_ct'])
 def test_split_launches_equal_single_launches(what, monkeypatch):
     from mjhmc_amd import engine, _lib
     ctx = engine.context(0)
+    mode = {'pot36_control': _lib.MODE_CONTROL, 'sic_p1_ct': _lib.MODE_CTHMC}.get(what, _lib.MODE_MJHMC)   # the other sampler families
+    what = what.split('_c')[0]
     if what == 'pot36':
         D, N, dtype = 36, 20000, 'float32'
         W, lognu = ref_init_weights(D, D)
@@ -410,7 +412,7 @@ def test_split_launches_equal_single_launches(what, monkeypatch):
         en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, D, params)
         X0 = a0[:, None] + 0.2 * np.random.RandomState(4).randn(D, N)
         hp = (0.0625, 3, 0.1)
-    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype) for _ in range(2)]
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype, mode=mode) for _ in range(2)]
     fields = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
     all_stats = [[], []]
     for n_it in (1, 3, 2):
