@@ -1090,7 +1090,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   int64_t split_at = 0;  // particles per part
   int n_parts = 3;       // C2: 2 / 3 / 4 / 8 parts measured 0.0803 / 0.0779 / 0.0803 / 0.0782 ms per iteration, unsplit 0.0855
   bool allow_split_now = true;  // (the recovery launch runs on one stream)
-  if (ring_slot0 < 0 && s->mode == MJHMC_MODE_MJHMC && !std::getenv("MJHMC_NO_SPLIT")) {
+  if (ring_slot0 < 0 && !std::getenv("MJHMC_NO_SPLIT")) {
     if (const char* np = std::getenv("MJHMC_SPLIT_PARTS")) n_parts = std::max(2, std::min(8, std::atoi(np)));
     const int64_t nslots = s->Npad >> (6 - s->sh.logG);
     if (nslots >= 8 * 4096) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part

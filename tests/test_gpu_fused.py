@@ -231,12 +231,12 @@ def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
 @pytest.mark.parametrize('kind,D,N', [('E_ISO_GAUSS', 512, 33000), ('E_DIAG_GAUSS', 64, 263000),
                                       ('E_ISO_GAUSS', 24, 530003),      # a quad of lanes per particle
                                       ('E_ISO_GAUSS', 40, 270001)])     # ragged rows (predicated chunks)
-def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch):
+def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch, mode_name='MODE_MJHMC'):
     """A big fused launch runs as two halves on two streams (api.hip, iterate_fused_t): invisible in the results, and a
     non-finite rate in either half ends the call like an unsplit one."""
     from mjhmc_amd import _lib
     params = list(10.0 ** np.linspace(-1, 0, D)) if kind == 'E_DIAG_GAUSS' else [1.0]
-    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params)
+    (a, b), _lib = _pair(kind, D, N, getattr(_lib, mode_name), params=params)
     for s in (a, b):
         s.set_hparams(0.1, 4, 0.1, 1.0, 0.5)
     for n_it in (6, 1, 70 if D == 512 else 3):                     # 70: two fused launches, the parts meet in between
@@ -248,6 +248,8 @@ def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch):
         assert da == db == n_it
         assert [_stats_tuple(t) for t in sa] == [_stats_tuple(t) for t in sb]
         _same_state(a, b, _lib)
+    if mode_name == 'MODE_CONTROL':
+        return                                                     # the discrete-time samplers have no rates to be non-finite
     for poison in ('0:7', '0:%d' % (N - 3)):                       # first half, second half
         monkeypatch.setenv('MJHMC_DEBUG_POISON', poison)
         sa, da = a.iterate(5)
@@ -266,3 +268,8 @@ def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch):
         monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
         assert da == db == 4
         _same_state(a, b, _lib)
+
+
+@pytest.mark.parametrize('mode_name', ['MODE_CONTROL', 'MODE_CTHMC'])
+def test_split_fused_launch_other_sampler_families(mode_name, monkeypatch):
+    test_split_fused_launch_equals_single_launch('E_ISO_GAUSS', 64, 263000, monkeypatch, mode_name=mode_name)
