@@ -2,9 +2,11 @@
 """Headline benchmark: particle-steps/s (ndims x nparticles x L per sampling_iteration) of the MJHMC hot path on
 MI355X, each workload with the roofline that bounds its kernel and the NumPy CPU baseline timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c1|all] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--head c3|c2|c4|c5] [--workload c2|c3|c4|c5|c1|all]
+                    [--scaling weak|strong]
 
-The ONE JSON line rank 0 prints has BASELINE.json configs[1] (C2) as its top-level workload and all GPU workloads
+The ONE JSON line rank 0 prints has the workload BASELINE.json's numeric target is stated on (C3, ProductOfT
+512 x 100 000: ">= 50x the NumPy reference at 1 GPU") as its top-level workload (--head) and all GPU workloads
 (C2..C5 = configs[1..4]) under "workloads", each with ms_per_step, roofline and cpu_baseline.
 
 A "step" is one MarkovJumpHMC.sampling_iteration over all particles; --steps K is the batch one
@@ -13,16 +15,22 @@ lasts >= 0.5 s: a 3 ms region measures the clock ramp, not the kernel), every ca
 on both sides, MAX over ranks; value = all ranks' particle-steps / the summed time, median and spread over the R
 calls reported next to it.  Inputs are resident in HBM before the timed region starts.
 
-N > 1 is launched as  python -m torch.distributed.run --nproc-per-node N bench.py ...  (one rank per GPU).  Particle
-columns are independent chains: each rank owns a block of columns (global particle ids keep the RNG streams those
-of an unsharded run), nothing is exchanged inside the timed region.  --scaling weak (default): every rank runs the
-full single-GPU workload; --scaling strong: the workload's particle count is the TOTAL, N/world per rank
-(BASELINE.json words C4 and C5 that way: "1 000 000 sharded across 8", "200 000 ... on 8xMI355X").
+N > 1: one rank per GPU.  Either  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (the ranks
+find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment and pass the RCCL id through the launcher's store)
+or plainly  python bench.py --gpus N ...  : with WORLD_SIZE unset the process only SPAWNS the N ranks (subprocess, before
+anything touches a GPU or loads the library; never exec), gives them RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous file
+in a fresh directory (MJHMC_COMM_ID_FILE), relays rank 0's line and exits non-zero if any rank does.  Particle columns are
+independent chains: each rank owns a block of columns (global particle ids keep the RNG streams those of an unsharded
+run), nothing is exchanged inside the timed region.  --scaling weak (default): every rank runs the full single-GPU
+workload (that is `value`); at N > 1 the line also carries, under "strong", C4 and C5 with the workload's particle
+count as the TOTAL (BASELINE.json words them that way: "1 000 000 sharded across 8", "200 000 ... on 8xMI355X").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -100,11 +108,15 @@ def algorithmic_bytes_per_particle(D, esize):
     return 4 * D * esize + 6 * esize + 17
 
 
+CPU_BASELINE_N = 8000      # "time at N = 8 000 and state N explicitly", >= 2 timed iterations after 1 warm-up
+
+
 def cpu_baseline(w, seconds_target):
     """The NumPy oracle (structurally faithful port of the reference's NumPy path) timed on this host: a bounded
-    column sample of the same workload."""
+    column sample of the same workload -- N = 8 000 columns (all of them for a smaller workload), one warm-up
+    iteration, then at least TWO timed sampling_iterations and as many more as fit `seconds_target`."""
     from oracle import mjhmc_oracle as orc
-    n = min(w['N'], 4000 if w['D'] >= 256 else 20000)
+    n = min(w['N'], CPU_BASELINE_N)
     threads = 1
     if w['kind'] in ('pot', 'sic'):
         if w['kind'] == 'pot':
@@ -129,13 +141,14 @@ def cpu_baseline(w, seconds_target):
         s.sampling_iteration()
         iters += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_target or iters >= 50:
+        if iters >= 2 and (dt > seconds_target or iters >= 50):
             break
     value = w['D'] * n * w['L'] * iters / dt
     return dict(value=value, unit='particle-steps/s', cores=threads, kind='port',
                 sample='NumPy oracle (port of the reference path), ndims=%d, nparticles=%d of %d, L=%d, %d '
                        'sampling_iterations after 1 warm-up, %.1f s, numpy %s, os.cpu_count=%d'
-                       % (w['D'], n, w['N'], w['L'], iters, dt, np.__version__, os.cpu_count()))
+                       % (w['D'], n, w['N'], w['L'], iters, dt, np.__version__, os.cpu_count()),
+                nparticles=n, iterations=iters, seconds=dt)
 
 
 def measured_traffic(key, it_per_launch):
@@ -154,19 +167,51 @@ def measured_traffic(key, it_per_launch):
     return None
 
 
+class StoreRendezvous(object):
+    """put / get / all_agree (the interface of mjhmc_amd.parallel.FileRendezvous) over the launcher's key/value store:
+    under torch.distributed.run every rank finds MASTER_ADDR / MASTER_PORT in its environment and the elastic agent
+    already serves a TCPStore there (TORCHELASTIC_USE_AGENT_STORE); without an agent rank 0 serves it."""
+
+    def __init__(self, rank, world):
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        agent = os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+        self.rank, self.world = rank, world
+        self.store = TCPStore(host_name=os.environ['MASTER_ADDR'], port=int(os.environ['MASTER_PORT']), world_size=None,
+                              is_master=(rank == 0) and not agent, timeout=timedelta(seconds=300), wait_for_workers=False)
+        self.prefix = 'mjhmc_bench/%s/' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+
+    def put(self, key, data):
+        self.store.set(self.prefix + key, bytes(data))
+
+    def get(self, key):
+        return bytes(self.store.get(self.prefix + key))          # blocks until the key exists
+
+    def all_agree(self, name, ok):
+        self.put('%s.%d' % (name, self.rank), b'1' if ok else b'0')
+        return all(self.get('%s.%d' % (name, r)) == b'1' for r in range(self.world))
+
+
 class Rig(object):
     """process-wide plumbing of one bench run: one rank per GPU; the ranks meet through the library's own RCCL
     communicator (mjhmc_comm_*, mjhmc_amd/parallel.py: RcclComm) -- barrier, MAX of the elapsed times, and the sample
-    all-gather checked after the timed regions.  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to
-    exercise the multi-rank code path with several ranks on a single-GPU box (RCCL refuses two ranks on one device):
-    they go through the torch.distributed shim instead."""
+    all-gather checked after the timed regions.  The 128-byte RCCL id travels through an explicit channel: the file the
+    spawning parent names in MJHMC_COMM_ID_FILE (a fresh directory), or the launcher's store under
+    torch.distributed.run.  Whether RCCL is used at all is decided by ALL ranks before any of them enters a collective
+    (a flag per rank through the same channel): if any rank cannot load librccl, or the communicator does not come up
+    everywhere, every rank takes its barrier / MAX through torch.distributed gloo instead and the line says so
+    (config.comm_note).  MJHMC_BENCH_BACKEND=gloo + MJHMC_BENCH_ONE_GPU=1 exist only to exercise the multi-rank code
+    path with several ranks on a single-GPU box (RCCL refuses two ranks on one device)."""
 
     def __init__(self, args):
         self.args = args
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
-        assert self.world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+        if self.world != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d in the environment (launch either as `python bench.py '
+                             '--gpus N` with WORLD_SIZE unset, or under torch.distributed.run --nproc-per-node N)'
+                             % (args.gpus, self.world))
         if os.environ.get('MJHMC_BENCH_ONE_GPU'):
             self.local_rank = 0
         from mjhmc_amd import engine
@@ -185,23 +230,41 @@ class Rig(object):
                 os.dup2(keep, 1)
                 os.close(keep)
 
+    def _rendezvous(self):
+        from mjhmc_amd.parallel import FileRendezvous
+        path = os.environ.get('MJHMC_COMM_ID_FILE')
+        if path:
+            return FileRendezvous(os.path.dirname(path) or '.', self.rank, self.world)
+        return StoreRendezvous(self.rank, self.world)
+
+    def _gloo(self, note):
+        self.comm_note = note
+        sys.stderr.write('rank %d: %s\n' % (self.rank, note))
+        import torch.distributed as dist
+        from mjhmc_amd.parallel import Comm
+        dist.init_process_group('gloo')
+        self.comm = Comm()
+
     def _connect(self):
-        if os.environ.get('MJHMC_BENCH_BACKEND', 'rccl') == 'gloo':
-            import torch.distributed as dist
-            from mjhmc_amd.parallel import Comm
-            dist.init_process_group('gloo')
-            self.comm = Comm()
-        else:
-            from mjhmc_amd.parallel import RcclComm
-            try:
-                self.comm = RcclComm(self.rank, self.world, device=self.local_rank)
-            except Exception as exc:  # e.g. librccl not loadable: the timing needs only a barrier and a MAX -- keep the line
-                self.comm_note = 'RCCL communicator failed (%s); barrier / MAX through torch.distributed gloo' % repr(exc)[:200]
-                sys.stderr.write('rank %d: %s\n' % (self.rank, self.comm_note))
-                import torch.distributed as dist
-                from mjhmc_amd.parallel import Comm
-                dist.init_process_group('gloo')
-                self.comm = Comm()
+        from mjhmc_amd import _lib
+        from mjhmc_amd.parallel import RcclComm
+        rdv = self._rendezvous()
+        want_rccl = os.environ.get('MJHMC_BENCH_BACKEND', 'rccl') != 'gloo'
+        loadable = want_rccl and _lib.load().mjhmc_comm_available() == 0
+        if not rdv.all_agree('rccl_loadable', loadable):         # decided by everybody BEFORE anybody enters a collective
+            return self._gloo('gloo requested (MJHMC_BENCH_BACKEND)' if not want_rccl else
+                              'librccl not loadable on every rank; barrier / MAX through torch.distributed gloo')
+        comm, err = None, None
+        try:
+            comm = RcclComm(self.rank, self.world, device=self.local_rank, rendezvous=rdv)
+        except Exception as exc:
+            err = repr(exc)[:200]
+        if rdv.all_agree('rccl_up', comm is not None):
+            self.comm = comm
+            return
+        if comm is not None:
+            comm.close()
+        self._gloo('RCCL communicator did not come up on every rank (%s); barrier / MAX through torch.distributed gloo' % err)
 
     def barrier(self, smp):
         smp.sync()
@@ -214,11 +277,11 @@ class Rig(object):
         return [float(v) for v in self.comm.allreduce_f64(np.asarray(list(values), dtype=np.float64), 'max')]
 
 
-def run_workload(rig, key, steps, warmup, cpu_seconds):
+def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
     from mjhmc_amd import engine, _lib
-    args, rank, world = rig.args, rig.rank, rig.world
+    rank, world = rig.rank, rig.world
     w = dict(WORKLOADS[key])
-    n_total = w['N'] if args.scaling == 'strong' else w['N'] * world
+    n_total = w['N'] if scaling == 'strong' else w['N'] * world
     n_rank = n_total // world
     first = rank * n_rank
     kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T,
@@ -271,23 +334,23 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
     elapsed = float(np.sum(call_s))
     iters = steps * reps
 
-    fused = w['kind'] == 'iso' and steps >= 2 and not os.environ.get('MJHMC_NO_FUSE')
-    # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel), after the timed region
+    fused = w['kind'] == 'iso' and steps >= 2          # mjhmc_iterate fuses the Gaussian forces whenever a call has >= 2 iterations
+    # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel: what every
+    # sampling_iteration() caller gets -- a call of ONE iteration is never fused), after the timed region
     unfused_ms = None
     if fused:
-        os.environ['MJHMC_NO_FUSE'] = '1'
-        try:
-            smp.iterate(32)
-            smp.iterate(32)
-            t_u = smp.last_timing()
-            unfused_ms = t_u['jump_kernel_ms'] / max(t_u['n_jump_launches'], 1)
-        finally:
-            del os.environ['MJHMC_NO_FUSE']
+        for _ in range(8):
+            smp.iterate(1)
+        t_sum = 0.0
+        for _ in range(32):
+            smp.iterate(1)
+            t_sum += smp.last_timing()['jump_kernel_ms']
+        unfused_ms = t_sum / 32
     # The C-ABI boundary hands over HOST buffers in the reference's (ndims, nparticles) layout; the device keeps rows
     # per particle.  What that costs (re-tile kernel + PCIe, pageable host memory), outside `value`: a state read,
     # and a batch of 10 stacked samples = 10 iterations into the device ring + one download of the ring.
     boundary = None
-    if world == 1 and key == rig.head:
+    if world == 1 and key == rig.head and scaling == 'weak':
         esz = {'float64': 8, 'float32': 4, 'bfloat16': 2}[w['dtype']]
         t_b = time.perf_counter()
         Xh = smp.read(_lib.F_X)
@@ -371,7 +434,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
                     'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': abytes / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     'traffic': measured_traffic(key + '_one_iteration_per_launch', 1),
-                    'what': 'the same kernel with the state crossing HBM every iteration (MJHMC_NO_FUSE=1): HBM-bound'}
+                    'what': 'the same kernel with the state crossing HBM every iteration (calls of ONE iteration): HBM-bound'}
         else:
             roof = {'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': hbm['achieved'] / HBM_PEAK_GBS, 'traffic': traffic,
@@ -379,6 +442,13 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
                               'mjhmc_jump_kernel + the compacted passes of one iteration (inverse-L pass with the pending refresh, cold list)',
                     'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'iterations_per_launch': 1.0,
                     'algorithmic_bytes_per_launch': abytes, 'valu': valu}
+    alg_bytes = (roof.get('hbm', {}).get('algorithmic_bytes_per_launch') or roof.get('algorithmic_bytes_per_launch')
+                 or roof.get('hbm_algorithmic', {}).get('algorithmic_bytes_per_launch'))
+    if fused:
+        alg_bytes = abytes                     # a fused launch has to move the state across HBM once, whatever it fuses
+    if scaling == 'strong' and world > 1:
+        roof['traffic'] = None                 # the PMC passes were taken on the single-GPU shapes
+    roof['traffic_over_algorithmic'] = (roof['traffic'] / alg_bytes) if roof.get('traffic') and alg_bytes else None
     per_step = np.array(call_s) * 1e3 / steps
     out = {
         'value': units / elapsed, 'unit': 'particle-steps/s', 'ms_per_step': elapsed * 1e3 / iters,
@@ -396,63 +466,204 @@ def run_workload(rig, key, steps, warmup, cpu_seconds):
     if world == 1 and cpu_seconds > 0:
         out['cpu_baseline'] = cpu_baseline(w, cpu_seconds)
         out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+    if w['kind'] == 'pot':
+        out['config']['arithmetic'] = 'float32 state and float32 MFMA force (dtype of the sampler: %s)' % w['dtype']
     return out
 
 
 def sample_gather_check(rig):
     """The one collective of the path: the all-gather of sample columns at the end of sample() (RCCL over xGMI, device
-    ring to device ring), outside every timed region, on a small sampler; every rank checks the whole block."""
+    ring to device ring), outside every timed region, on a small sampler with UNEVEN column shards.  Every rank also
+    runs the unsharded sampler on its own GPU (the counter RNG is keyed by global particle id, so the shards ARE the
+    unsharded run's columns) and compares the three gathered forms with it bit for bit: time-major blocks
+    (np.concatenate(axis=1)), stacked (np.stack(axis=-1)) and the dwell-time-resampled columns."""
     try:
         from mjhmc_amd import engine, _lib
-        from mjhmc_amd.parallel import ShardPlan, assemble_stacked
+        from mjhmc_amd.parallel import ShardPlan, assemble_resample, assemble_stacked
         comm = rig.comm
-        D, ncol, n = 32, 8192, 4
-        plan = ShardPlan(ncol * rig.world, rig.world)
+        D, n = 32, 4
+        total = 8192 * rig.world + max(1, rig.world // 2)     # not divisible: the first shards hold one column more
+        plan = ShardPlan(total, rig.world)
+        lo, hi = plan.span(rig.rank)
+        X0 = np.random.RandomState(77).randn(D, total)
         en = engine.DeviceEnergy(rig.ctx, _lib.E_ISO_GAUSS, D, [1.0])
-        smp = engine.DeviceSampler(en, np.random.RandomState(rig.rank).randn(D, ncol), seed=1, first_particle_id=rig.rank * ncol)
-        smp.set_hparams(0.1, 5, 0.05, 1.0)
-        smp.ring_alloc(n)
-        smp.iterate(n, ring_slot0=0)
-        mine = smp.ring_read(0, n, stacked=False)
+
+        def run(cols, first):
+            smp = engine.DeviceSampler(en, X0[:, cols], seed=1, first_particle_id=first)
+            smp.set_hparams(0.1, 5, 0.05, 1.0)
+            smp.ring_alloc(n)
+            smp.iterate(n, ring_slot0=0)
+            return smp
+
+        smp = run(slice(lo, hi), lo)
+        whole = run(slice(0, total), 0)
+        want_cat, want_cube = whole.ring_read(0, n, stacked=False), whole.ring_read(0, n, stacked=True)
+        u = np.random.RandomState(78).rand(n * total)
         comm.barrier()
         tg0 = time.perf_counter()
         if comm.on_device:
-            full = comm.allgather_ring(smp, 0, n, False, plan.counts)
+            got_cat = comm.allgather_ring(smp, 0, n, False, plan.counts)
         else:
-            full = assemble_stacked(comm, plan, mine, n, False)
+            got_cat = assemble_stacked(comm, plan, smp.ring_read(0, n, stacked=False), n, False)
         tg1 = time.perf_counter()
-        cube = full.reshape(D, n, ncol * rig.world)[:, :, rig.rank * ncol:(rig.rank + 1) * ncol]
-        ok = full.shape == (D, n * ncol * rig.world) and np.array_equal(cube.reshape(D, n * ncol), mine)
-        ok_all = int(comm.allreduce_ints([1 if ok else 0], 'min')[0])
-        return {'ok': bool(ok_all), 'backend': comm.backend, 'columns_per_rank': ncol * n, 'ms': (tg1 - tg0) * 1e3,
-                'bytes_per_rank': int(D * ncol * n * 8), 'device_to_device': bool(comm.on_device)}
+        if comm.on_device:
+            got_cube = comm.allgather_ring(smp, 0, n, True, plan.counts)
+        else:
+            got_cube = assemble_stacked(comm, plan, smp.ring_read(0, n, stacked=True), n, True)
+        got_pick, idx = assemble_resample(comm, plan, n, smp.ring_read_dwell(0, n), smp.ring_gather, uniforms=u,
+                                          dev=smp if comm.on_device else None)
+        want_pick = whole.ring_gather(idx)
+        checks = {'time_major': bool(np.array_equal(got_cat, want_cat)), 'stacked': bool(np.array_equal(got_cube, want_cube)),
+                  'resampled_columns': bool(np.array_equal(got_pick, want_pick))}
+        ok_all = int(comm.allreduce_ints([1 if all(checks.values()) else 0], 'min')[0])
+        info = {'ok': bool(ok_all), 'checks_rank0': checks, 'backend': comm.backend,
+                'ranks': comm.count() if hasattr(comm, 'count') else comm.world,
+                'columns_per_rank': [int(c) for c in plan.counts], 'slots': n, 'ms_time_major': (tg1 - tg0) * 1e3,
+                'bytes_per_rank': int(D * plan.counts[0] * n * 8), 'device_to_device': bool(comm.on_device),
+                'compared_with': 'the unsharded sampler run on every rank\'s own GPU, bit for bit'}
+        smp.close()
+        whole.close()
+        return info
     except Exception as exc:  # the bench line must survive a collective problem
         return {'ok': False, 'error': repr(exc)[:300]}
 
 
-def main():
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: this process touches no GPU and does not load the library; it
+    starts the N ranks as child processes (never exec), each with RANK / LOCAL_RANK / WORLD_SIZE, MASTER_ADDR / MASTER_PORT
+    (only the gloo safety net reads them) and MJHMC_COMM_ID_FILE = a path in a fresh directory through which rank 0
+    publishes the RCCL id; relays rank 0's stdout (the ONE JSON line), sends the other ranks' stdout to stderr, and exits
+    non-zero if any rank does (ending the others: a rank that died would leave them waiting at the rendezvous)."""
+    import shutil
+    import socket
+    import tempfile
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    rdv_dir = tempfile.mkdtemp(prefix='mjhmc_bench_')
+    procs, relays, collected = [], [], [[] for _ in range(n)]
+
+    def relay(r, pipe):
+        for line in iter(pipe.readline, b''):
+            if args.spawn_check:
+                collected[r].append(line)
+            elif r == 0:
+                sys.stdout.buffer.write(line)
+                sys.stdout.buffer.flush()
+            else:
+                sys.stderr.buffer.write(line)
+                sys.stderr.buffer.flush()
+        pipe.close()
+
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MJHMC_COMM_ID_FILE=os.path.join(rdv_dir, 'comm.id'),
+                       MJHMC_BENCH_SPAWNED='1')
+            env.pop('TORCHELASTIC_USE_AGENT_STORE', None)
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE)
+            procs.append(p)
+            t = threading.Thread(target=relay, args=(r, p.stdout), daemon=True)
+            t.start()
+            relays.append(t)
+        alive = set(range(n))
+        while alive and rc == 0:
+            time.sleep(0.05)
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is not None:
+                    alive.discard(r)
+                    if code != 0:
+                        rc = code if code > 0 else 1
+                        sys.stderr.write('bench.py: rank %d exited with status %d; stopping the other ranks\n' % (r, code))
+        for r in sorted(alive):                       # only after a failure: our own children, by pid
+            procs[r].terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        for t in relays:
+            t.join(timeout=10)
+        if args.spawn_check and rc == 0:
+            reports = [json.loads(b''.join(c).decode().strip().splitlines()[-1]) for c in collected]
+            print(json.dumps({'spawn_check': reports, 'n_gpus': n, 'rendezvous_dir_fresh': True}))
+    finally:
+        shutil.rmtree(rdv_dir, ignore_errors=True)
+    return rc
+
+
+def spawn_report():
+    """--spawn-check: what this rank was given, and whether the rendezvous channel works -- through the same
+    FileRendezvous the RCCL id travels by -- without touching a GPU or loading the library."""
+    from mjhmc_amd.parallel import FileRendezvous, default_id_path
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    path, explicit = default_id_path()
+    if explicit:
+        rdv = FileRendezvous(os.path.dirname(path), rank, world, timeout=60)
+    else:
+        rdv = StoreRendezvous(rank, world)
+    if rank == 0:
+        rdv.put('probe', b'id-from-rank-0')
+    seen = rdv.get('probe').decode()
+    agree = rdv.all_agree('probe_ok', seen == 'id-from-rank-0')
+    print(json.dumps({'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '-1')), 'world': world,
+                      'id_file': path, 'id_file_explicit': bool(explicit), 'probe': seen, 'all_ranks_agree': bool(agree),
+                      'channel': type(rdv).__name__,
+                      'library_loaded': any('libmjhmc_hip' in ln for ln in open('/proc/self/maps')),
+                      'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}))
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=64)     # iterations per mjhmc_iterate call (one fused launch of the elementwise kernels)
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--workload', default='all', choices=sorted(WORKLOADS) + ['all'])
+    ap.add_argument('--head', default='c3', choices=['c2', 'c3', 'c4', 'c5'],
+                    help='top-level workload of the line (default: C3, the workload of BASELINE.json\'s numeric target)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--spawn-check', action='store_true',
+                    help='ranks report their environment and the rendezvous channel, then exit before touching a GPU')
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args, argv)
+    if args.spawn_check:
+        return spawn_report()
     rig = Rig(args)
     keys = ['c2', 'c3', 'c4', 'c5'] if args.workload == 'all' else [args.workload]
-    head = keys[0]
+    head = args.head if args.head in keys else keys[0]
+    keys = [head] + [k for k in keys if k != head]
     rig.head = head
-    results = {}
+    results, strong = {}, {}
+
+    def budget(key):
+        # the head workload runs exactly --steps / --warmup; the other dense workloads (10-20 ms per iteration: a batch
+        # of K of them is already long) are capped
+        if key == head or key in ('c2', 'c4', 'c1'):
+            return args.steps, args.warmup
+        return max(2, min(args.steps, 16)), min(args.warmup, 4)
+
     for key in keys:
-        # the dense workloads run ~10-20 ms per iteration: a batch of K of them is already long
-        steps = args.steps if key in ('c2', 'c4', 'c1') else max(2, min(args.steps, 16))
-        warm = args.warmup if key in ('c2', 'c4', 'c1') else min(args.warmup, 4)
+        steps, warm = budget(key)
         cpu_s = 0 if args.no_cpu_baseline else (12.0 if key == head else 6.0)
-        results[key] = run_workload(rig, key, steps, warm, cpu_s)
+        results[key] = run_workload(rig, key, steps, warm, cpu_s, args.scaling)
         if results[key] is not None:
             results[key]['steps'] = steps
             results[key]['warmup'] = warm
+    if rig.world > 1 and args.scaling == 'weak':
+        # BASELINE.json words C4 and C5 as totals sharded over the GPUs: the same line carries them strong-scaled
+        for key in [k for k in ('c4', 'c5') if k in keys]:
+            steps, warm = budget(key)
+            strong[key] = run_workload(rig, key, steps, warm, 0, 'strong')
+            if strong[key] is not None:
+                strong[key].update(steps=steps, warmup=warm, scaling='strong')
     gather_info = sample_gather_check(rig) if rig.comm is not None else None
     if rig.rank == 0:
         h = results[head]
@@ -465,6 +676,13 @@ def main():
         }
         if 'cpu_baseline' in h:
             out['cpu_baseline'] = h['cpu_baseline']
+        c3 = results.get('c3')
+        if c3 is not None and 'cpu_baseline' in c3:
+            # BASELINE.json: ">= 50x the NumPy reference in particle-steps/sec on ProductOfT (ndims=512, 100k particles) at 1 GPU"
+            ratio = c3['value'] / c3['cpu_baseline']['value']
+            out['target'] = {'workload': 'c3', 'min_gpu_over_cpu': 50, 'gpu_over_cpu': ratio, 'met': bool(ratio >= 50),
+                             'cpu_sample': 'N = %d columns, %d timed iterations' % (c3['cpu_baseline']['nparticles'],
+                                                                                    c3['cpu_baseline']['iterations'])}
         if 'boundary' in h:
             out['boundary'] = h['boundary']
         if gather_info is not None:
@@ -474,12 +692,16 @@ def main():
         if len(keys) > 1:
             out['workloads'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world, scaling=args.scaling)
                                 for k, v in results.items()}
+        if strong:
+            out['strong'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world) for k, v in strong.items()}
         print(json.dumps(out))
+        sys.stdout.flush()
     if rig.comm is not None:
         rig.comm.barrier()
         if hasattr(rig.comm, 'close'):
             rig.comm.close()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

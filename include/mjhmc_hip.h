@@ -264,6 +264,11 @@ typedef enum { MJHMC_OP_SUM = 0, MJHMC_OP_MIN = 1, MJHMC_OP_MAX = 2 } mjhmc_redu
 int mjhmc_comm_unique_id(void* id);
 int mjhmc_comm_create(mjhmc_ctx* ctx, int rank, int world, const void* id, mjhmc_comm** out);
 int mjhmc_comm_destroy(mjhmc_comm* c);
+/* 0 when librccl can be loaded and has every entry point the communicator uses, MJHMC_ERR_COMM otherwise (needs no
+ * device and enters no collective: the ranks of a job can agree on a fallback BEFORE any of them calls mjhmc_comm_create) */
+int mjhmc_comm_available(void);
+/* the number of ranks of the communicator as RCCL reports it (ncclCommCount) */
+int mjhmc_comm_count(mjhmc_comm* c, int* count);
 /* host values, in place: integer bookkeeping (l/f/r counts, E_count / dEdX_count increments: sums), the number of
  * iterations every rank committed before a non-finite rate (min: the reference retries the WHOLE batch,
  * markov_jump_hmc.py:376-389), lag sums of the autocorrelation, elapsed times (max) */

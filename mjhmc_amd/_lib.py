@@ -82,6 +82,8 @@ PROTOTYPES = {
     'mjhmc_comm_unique_id': (ctypes.c_int, [_P]),
     'mjhmc_comm_create': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.POINTER(_P)]),
     'mjhmc_comm_destroy': (ctypes.c_int, [_P]),
+    'mjhmc_comm_available': (ctypes.c_int, []),
+    'mjhmc_comm_count': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     'mjhmc_comm_allreduce_i64': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int]),
     'mjhmc_comm_allreduce_f64': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int]),
     'mjhmc_comm_bcast': (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int]),
@@ -92,7 +94,24 @@ PROTOTYPES = {
     'mjhmc_sync': (ctypes.c_int, [_P]),
 }
 
+# libmjhmc_hip_test.so only (csrc/Makefile: test_hooks; built with -DMJHMC_TEST_HOOKS): the SAME sources plus the
+# environment A/B switches of the launch strategies, the failure-placing hook and the single-GPU gather hooks
+TEST_HOOKS_PATH = os.path.join(_HERE, 'lib', 'libmjhmc_hip_test.so')
+TEST_HOOK_PROTOTYPES = {
+    'mjhmc_test_gather_ring_local': (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    'mjhmc_test_gather_columns_local': (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int, _P, _P, _P]),
+}
+
 _lib = None
+_hooks = None
+
+
+def _attach(lib, protos):
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
@@ -104,18 +123,24 @@ def load():
         raise EngineError('libmjhmc_hip.so not found at %s -- build it with `make -C mjhmc_amd/csrc` '
                           '(or python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.'
                           % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _attach(ctypes.CDLL(LIB_PATH), PROTOTYPES)
+    return _lib
 
 
-def check(rc):
+def load_test_hooks():
+    """The test build of the library (tests and measurement tools only; the product never loads it): pass it to
+    engine.Context(device, lib=...)."""
+    global _hooks
+    if _hooks is None:
+        if not os.path.exists(TEST_HOOKS_PATH):
+            raise EngineError('libmjhmc_hip_test.so not found at %s -- `make -C mjhmc_amd/csrc test_hooks`' % TEST_HOOKS_PATH)
+        _hooks = _attach(_attach(ctypes.CDLL(TEST_HOOKS_PATH), PROTOTYPES), TEST_HOOK_PROTOTYPES)
+    return _hooks
+
+
+def check(rc, lib=None):
     if rc != 0:
-        msg = load().mjhmc_last_error()
+        msg = (lib or load()).mjhmc_last_error()
         raise EngineError('libmjhmc_hip: %s (status %d)' % (msg.decode() if msg else '?', rc))
 
 

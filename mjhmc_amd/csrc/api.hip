@@ -30,6 +30,22 @@ static int pow2ceil(int v) {
   return p;
 }
 
+// The A/B switches of the measurement tools and of the launch-strategy tests (MJHMC_NO_FUSE, MJHMC_NO_COMPACT,
+// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
+// MJHMC_SIC_COPIES) and the failure-placing hook MJHMC_DEBUG_POISON exist only in libmjhmc_hip_test.so (built with
+// -DMJHMC_TEST_HOOKS, `make test_hooks`).  The shipped library consults no environment variable on the sampling path:
+// the only ones it reads at all name libraries to dlopen (MJHMC_RCCL_LIB; hipRTC / hipFFT by their sonames).
+#ifdef MJHMC_TEST_HOOKS
+static const char* test_env(const char* name) { return std::getenv(name); }
+#else
+static const char* test_env(const char*) { return nullptr; }
+#endif
+
+static int ab_flags() {
+  return (test_env("MJHMC_NO_BLOCK_DECIDE") ? kAbNoBlockDecide : 0) | (test_env("MJHMC_NO_WPP") ? kAbNoWpp : 0) |
+         (test_env("MJHMC_NO_QUAD") ? kAbNoQuad : 0);
+}
+
 static int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -50,7 +66,7 @@ int pick_shape(int D, int dtype, Shape* out) {
     G = 1;
   } else {
     C = 4;
-    if (const char* force = std::getenv("MJHMC_CHUNKS_PER_LANE")) {  // perf experiments
+    if (const char* force = test_env("MJHMC_CHUNKS_PER_LANE")) {  // perf experiments
       const int f = std::atoi(force);
       C = f == 8 ? 8 : (f == 1 ? 1 : 4);
     }
@@ -646,7 +662,7 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
       // alternate between them): every CU streams the same 1 MB per leapfrog step out of its XCD's L2, and spreading
       // that over two sets of lines was measured faster than all CUs hitting one
       e->sic_copies = kSicCopies;
-      if (const char* cp = std::getenv("MJHMC_SIC_COPIES")) e->sic_copies = std::max(1, std::min(4, std::atoi(cp)));
+      if (const char* cp = test_env("MJHMC_SIC_COPIES")) e->sic_copies = std::max(1, std::min(4, std::atoi(cp)));
       for (int i = 0; i < 3 && !rc; ++i) {
         const int reps = i < 2 ? e->sic_copies : 1;
         if (hipMalloc(&e->sic[i], bytes[i] * reps) != hipSuccess) rc = fail(MJHMC_ERR_HIP, "allocating SPARSE_CODE parameters failed");
@@ -1090,8 +1106,8 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   int64_t split_at = 0;  // particles per part
   int n_parts = 3;       // C2: 2 / 3 / 4 / 8 parts measured 0.0803 / 0.0779 / 0.0803 / 0.0782 ms per iteration, unsplit 0.0855
   bool allow_split_now = true;  // (the recovery launch runs on one stream)
-  if (ring_slot0 < 0 && !std::getenv("MJHMC_NO_SPLIT")) {
-    if (const char* np = std::getenv("MJHMC_SPLIT_PARTS")) n_parts = std::max(2, std::min(8, std::atoi(np)));
+  if (ring_slot0 < 0 && !test_env("MJHMC_NO_SPLIT")) {
+    if (const char* np = test_env("MJHMC_SPLIT_PARTS")) n_parts = std::max(2, std::min(8, std::atoi(np)));
     const int64_t nslots = s->Npad >> (6 - s->sh.logG);
     if (nslots >= 8 * 4096) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part
     if (split_at <= 0 || split_at * (n_parts - 1) >= s->N) split_at = 0;
@@ -1138,6 +1154,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     a.iter = l.i0;
     a.defer_r = 0;
     a.n_fuse = l.K;
+    a.ab = ab_flags();
     if (ring_slot0 >= 0) {
       a.xiter = (T*)((char*)s->ring + (size_t)(ring_slot0 + l.i0) * mb);
       a.xiter_stride = mb / sizeof(T);
@@ -1203,7 +1220,8 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     return (in != s->Xbuf[0]) ? s->Xbuf[0] : s->Xbuf[1];
   };
 
-  if (const char* poison = std::getenv("MJHMC_DEBUG_POISON")) {  // test hook, see iterate_t (fused launches: iteration 0 only)
+#ifdef MJHMC_TEST_HOOKS
+  if (const char* poison = test_env("MJHMC_DEBUG_POISON")) {  // test hook, see iterate_t (fused launches: iteration 0 only)
     int pit = -1;
     long long pp = -1;
     if (std::sscanf(poison, "%d:%lld", &pit, &pp) == 2 && pit == 0 && pp >= 0 && pp < s->N) {
@@ -1213,6 +1231,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
                             ssize(s), hipMemcpyHostToDevice, s->stream));
     }
   }
+#endif  // MJHMC_TEST_HOOKS
   std::vector<Launch> launches;
   HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i0 = 0; i0 < n_iter; i0 += kMaxFuse) {
@@ -1284,7 +1303,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // while the batch is small (launch-/latency-bound) -- big batches of those take the compacted passes below instead.
   const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
   const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || s->N < 16384 || s->D <= 4);
-  if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !std::getenv("MJHMC_NO_FUSE"))
+  if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !test_env("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);
   if (s->stats_cap < n_iter) {
@@ -1305,7 +1324,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // Several particles per wave and a big batch: the inverse-L trajectory of the cold-cache particles runs in its
   // own compacted pass (mjhmc_flf_kernel) instead of in every wave of the jump kernel that holds a cold particle.
   const bool compact = s->mode == MJHMC_MODE_MJHMC && !s->en->is_dense() && !s->en->is_user() && !replay_normal && !replay_exp &&
-                       s->sh.logG < 6 && s->N >= 16384 && !std::getenv("MJHMC_NO_COMPACT");
+                       s->sh.logG < 6 && s->N >= 16384 && !test_env("MJHMC_NO_COMPACT");
   if (compact) {
     if (!s->flf_list) {
       HIPCHK(hipMalloc((void**)&s->flf_list, (size_t)s->Npad * sizeof(int)));
@@ -1325,14 +1344,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // (The elementwise compacted passes -- C4 -- were tried as 2 / 3 / 4 free-running parts the same way: 0.2727 ms per
   // iteration unsplit, 0.2729 / 0.2744 / 0.310 split: their kernels leave room for each other already.)
   if (allow_split && s->en->is_dense() && !replay_normal && !replay_exp && !replay_unif &&
-      ring_slot0 < 0 && !std::getenv("MJHMC_NO_SPLIT")) {
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      cus = std::max(1, cus);
-    }
+      ring_slot0 < 0 && !test_env("MJHMC_NO_SPLIT")) {
+    const int cus = std::max(1, s->ctx->prop.multiProcessorCount);  // of THIS sampler's device
     const int ppt = s->en->is_sic() ? sic_particles_per_tile(s->en->sic_P) : 32;
     const int64_t unit = 64 * (int64_t)ppt;  // whole tiles and whole 64-particle row groups on both sides
     if ((s->N + ppt - 1) / ppt >= 2 * (int64_t)cus) split_at = (s->Npad / 2) / unit * unit;
@@ -1370,7 +1383,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     if (replay_unif)
       HIPCHK(hipMemcpyAsync(s->runif, replay_unif + (size_t)i * (2 * s->N + 1), (2 * s->N + 1) * sizeof(double),
                             hipMemcpyHostToDevice, s->stream));
-    if (const char* poison = std::getenv("MJHMC_DEBUG_POISON")) {
+#ifdef MJHMC_TEST_HOOKS
+    if (const char* poison = test_env("MJHMC_DEBUG_POISON")) {
       // test hook "iteration:particle": that particle's kinetic energy reads NaN in that iteration of the call -> its rates
       // are not finite -> the whole-batch abort of markov_jump_hmc.py:376-389, at a chosen point of a multi-iteration call
       int pit = -1;
@@ -1384,6 +1398,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
                               ssize(s), hipMemcpyHostToDevice, pst));
       }
     }
+#endif  // MJHMC_TEST_HOOKS
     if (split_at && i == 0) {  // the second stream starts from everything the first has been given so far
       HIPCHK(hipEventRecord(s->ev_fork, s->stream));
       HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
@@ -1419,6 +1434,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     a.iter = i;
     a.n_fuse = 0;
     a.defer_r = 0;
+    a.ab = ab_flags();
     a.xiter = nullptr;
     a.xiter_stride = 0;
     a.eps = (T)s->eps;

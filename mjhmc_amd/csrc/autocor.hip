@@ -153,10 +153,12 @@ struct DevBuf {
 
 // staging budget: series-major float64 input + spectra of one chunk
 size_t staging_budget() {
+#ifdef MJHMC_TEST_HOOKS  // the chunked path at test sizes (libmjhmc_hip_test.so only)
   if (const char* e = std::getenv("MJHMC_AUTOCOR_STAGING_MB")) {
     const long mb = std::atol(e);
     if (mb > 0) return (size_t)mb << 20;
   }
+#endif
   return (size_t)1 << 30;
 }
 

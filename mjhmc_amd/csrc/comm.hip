@@ -26,6 +26,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
@@ -36,14 +37,20 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r;
   if (r.so || !r.err.empty()) return r;
-  const char* names[] = {std::getenv("MJHMC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    if (!n || !*n) continue;
-    r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.so) break;
+  // MJHMC_RCCL_LIB names the library to load and is then the ONLY name tried; otherwise the sonames of the ROCm install
+  const char* named = std::getenv("MJHMC_RCCL_LIB");
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  if (named && *named) {
+    r.so = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    for (const char* n : names) {
+      r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.so) break;
+    }
   }
   if (!r.so) {
-    r.err = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    const char* why = dlerror();  // ONE call: dlerror() clears the message it returns
+    r.err = std::string("librccl.so could not be loaded: ") + (why ? why : "?");
     return r;
   }
   auto sym = [&](const char* name) -> void* {
@@ -54,6 +61,7 @@ Rccl& rccl() {
   r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
   r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
   r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
   r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
@@ -215,36 +223,34 @@ int mjhmc_comm_allgatherv(mjhmc_comm* c, const void* send, const int64_t* nbytes
   return 0;
 }
 
-int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n, int stacked,
-                              const int64_t* particles_per_rank, double* host_out) {
-  if (!c || !s || !particles_per_rank || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
-  if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return mjhmc_fail(MJHMC_ERR_INVALID, "slots out of range");
-  if (particles_per_rank[c->rank] != s->N) return mjhmc_fail(MJHMC_ERR_INVALID, "particles_per_rank[rank] != nparticles");
-  HIPCHK(hipSetDevice(c->ctx->device));
-  int64_t total = 0, mx = 0;
-  for (int r = 0; r < c->world; ++r) {
-    if (particles_per_rank[r] < 1) return mjhmc_fail(MJHMC_ERR_INVALID, "every rank must own at least one particle");
-    total += particles_per_rank[r];
-    mx = std::max(mx, particles_per_rank[r]);
-  }
+// ---- the sample all-gather in three steps: pack | collective | unpack ------------------------------------------------
+// A rank's block of the ring gather is [n][mx][pitch] (slot-major, mx = the largest shard; the rows beyond the rank's
+// own count stay unread); of the column gather [mx][pitch].  The receive side holds `world` such blocks, rank-major.
+
+// pack: ring slots [slot0, slot0 + n) of one sampler, padding rows dropped (each slot holds its N valid rows first)
+static int ring_pack(mjhmc_sampler* s, int slot0, int n, int64_t mx, void* dst) {
   const size_t rb = row_bytes(s), mb = mat_bytes(s);
-  const size_t blk = (size_t)n * mx * rb;  // [n][mx][pitch], rank r fills [t][0 .. cnt_r)
-  TRY(need(c, 0, blk));
-  TRY(need(c, 1, blk * c->world));
-  // this rank's n slots, padding rows dropped (each slot holds its N valid rows first)
-  HIPCHK(hipMemcpy2DAsync(c->buf[0], (size_t)mx * rb, (const char*)s->ring + (size_t)slot0 * mb, mb, (size_t)s->N * rb,
-                          (size_t)n, hipMemcpyDeviceToDevice, s->stream));
-  NCCLCHK(rccl().AllGather(c->buf[0], c->buf[1], blk, ncclInt8, c->nccl, s->stream));
+  HIPCHK(hipMemcpy2DAsync(dst, (size_t)mx * rb, (const char*)s->ring + (size_t)slot0 * mb, mb, (size_t)s->N * rb, (size_t)n,
+                          hipMemcpyDeviceToDevice, s->stream));
+  return 0;
+}
+
+// unpack: `world` received blocks -> the unsharded sample block in the reference's layout, on the host.
+//   stacked == 0: (D, n * total) time-major like np.concatenate(axis=1) of the per-iteration states
+//   stacked != 0: (D, total, n) like np.stack(axis=-1)
+static int ring_unpack(mjhmc_sampler* s, const char* recv, size_t blk, int world, const int64_t* counts, int64_t total,
+                       int64_t mx, int n, int stacked, double* host_out) {
+  const size_t rb = row_bytes(s);
   const size_t elems = (size_t)s->D * total * n;
   TRY(ensure_stage(s, elems));
   int64_t off = 0;
-  for (int r = 0; r < c->world; ++r) {
-    const int64_t cnt = particles_per_rank[r];
+  for (int r = 0; r < world; ++r) {
+    const int64_t cnt = counts[r];
     for (int t = 0; t < n; ++t) {
-      const char* src = (const char*)c->buf[1] + (size_t)r * blk + (size_t)t * mx * rb;
-      if (!stacked)  // (D, n * total), time-major like np.concatenate(axis=1) of the per-iteration states
+      const char* src = recv + (size_t)r * blk + (size_t)t * mx * rb;
+      if (!stacked)
         TRY(download_cols(s, src, nullptr, cnt, host_out, elems, (int64_t)n * total, 1, (int64_t)t * total + off, false));
-      else           // (D, total, n) like np.stack(axis=-1)
+      else
         TRY(download_cols(s, src, nullptr, cnt, host_out, elems, total * n, n, off * n + t, false));
     }
     off += cnt;
@@ -254,50 +260,164 @@ int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n,
   return 0;
 }
 
-int mjhmc_comm_allgather_columns(mjhmc_comm* c, mjhmc_sampler* s, const int64_t* local_idx, int64_t n_local,
-                                 const int64_t* columns_per_rank, double* host_out) {
-  if (!c || !s || !columns_per_rank || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
-  if (n_local < 0 || (n_local && !local_idx)) return mjhmc_fail(MJHMC_ERR_INVALID, "bad local index list");
-  if (columns_per_rank[c->rank] != n_local) return mjhmc_fail(MJHMC_ERR_INVALID, "columns_per_rank[rank] != n_local");
-  HIPCHK(hipSetDevice(c->ctx->device));
-  int64_t total = 0, mx = 0;
-  for (int r = 0; r < c->world; ++r) {
-    if (columns_per_rank[r] < 0) return mjhmc_fail(MJHMC_ERR_INVALID, "negative column count");
-    total += columns_per_rank[r];
-    mx = std::max(mx, columns_per_rank[r]);
-  }
-  if (total == 0) return 0;
+// pack of the column gather: the n_local ring columns this rank owns (local pool indices slot * N + column)
+static int columns_pack(mjhmc_sampler* s, const int64_t* local_idx, int64_t n_local, void* dst, int64_t* dev_rows) {
+  if (!n_local) return 0;
   const int64_t pool = (int64_t)s->ring_slots * s->N;
   std::vector<int64_t> rows((size_t)n_local);  // pool index (slot * N + p) -> padded ring row (slot * Npad + p)
   for (int64_t k = 0; k < n_local; ++k) {
     if (local_idx[k] < 0 || local_idx[k] >= pool) return mjhmc_fail(MJHMC_ERR_INVALID, "gather index outside the sample ring");
     rows[(size_t)k] = (local_idx[k] / s->N) * s->Npad + local_idx[k] % s->N;
   }
-  const size_t rb = row_bytes(s);
-  const size_t blk = (size_t)mx * rb;
-  TRY(need(c, 0, blk + (size_t)std::max<int64_t>(n_local, 1) * sizeof(int64_t)));
-  TRY(need(c, 1, blk * c->world));
-  if (n_local) {
-    int64_t* drows = (int64_t*)((char*)c->buf[0] + blk);
-    HIPCHK(hipMemcpyAsync(drows, rows.data(), (size_t)n_local * sizeof(int64_t), hipMemcpyHostToDevice, s->stream));
-    const int cpr = (int)(rb / 16);
-    const int64_t threads = n_local * cpr;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s->stream,
-                       (const uint4*)s->ring, drows, (uint4*)c->buf[0], n_local, cpr);
-    HIPCHK(hipGetLastError());
-  }
-  NCCLCHK(rccl().AllGather(c->buf[0], c->buf[1], blk, ncclInt8, c->nccl, s->stream));
+  // the row list is pageable host memory: the copy is done with it when hipMemcpyAsync returns
+  HIPCHK(hipMemcpyAsync(dev_rows, rows.data(), (size_t)n_local * sizeof(int64_t), hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  const int cpr = (int)(row_bytes(s) / 16);
+  const int64_t threads = n_local * cpr;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s->stream,
+                     (const uint4*)s->ring, dev_rows, (uint4*)dst, n_local, cpr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// unpack of the column gather: rank-major (rank 0's columns, then rank 1's, ...), (D, total) on the host
+static int columns_unpack(mjhmc_sampler* s, const char* recv, size_t blk, int world, const int64_t* counts, int64_t total,
+                          double* host_out) {
   const size_t elems = (size_t)s->D * total;
   TRY(ensure_stage(s, elems));
   int64_t off = 0;
-  for (int r = 0; r < c->world; ++r) {  // rank-major: rank 0's columns, then rank 1's, ...
-    const int64_t cnt = columns_per_rank[r];
-    if (cnt) TRY(download_cols(s, (const char*)c->buf[1] + (size_t)r * blk, nullptr, cnt, host_out, elems, total, 1, off, false));
+  for (int r = 0; r < world; ++r) {
+    const int64_t cnt = counts[r];
+    if (cnt) TRY(download_cols(s, recv + (size_t)r * blk, nullptr, cnt, host_out, elems, total, 1, off, false));
     off += cnt;
   }
   HIPCHK(hipMemcpyAsync(host_out, s->stage, elems * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return 0;
 }
+
+static int shard_totals(const int64_t* counts, int world, int64_t least, int64_t* total, int64_t* mx) {
+  *total = 0;
+  *mx = 0;
+  for (int r = 0; r < world; ++r) {
+    if (counts[r] < least)
+      return mjhmc_fail(MJHMC_ERR_INVALID, least ? "every rank must own at least one particle" : "negative column count");
+    *total += counts[r];
+    *mx = std::max(*mx, counts[r]);
+  }
+  return 0;
+}
+
+int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n, int stacked,
+                              const int64_t* particles_per_rank, double* host_out) {
+  if (!c || !s || !particles_per_rank || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return mjhmc_fail(MJHMC_ERR_INVALID, "slots out of range");
+  if (particles_per_rank[c->rank] != s->N) return mjhmc_fail(MJHMC_ERR_INVALID, "particles_per_rank[rank] != nparticles");
+  HIPCHK(hipSetDevice(c->ctx->device));
+  int64_t total, mx;
+  TRY(shard_totals(particles_per_rank, c->world, 1, &total, &mx));
+  const size_t blk = (size_t)n * mx * row_bytes(s);
+  TRY(need(c, 0, blk));
+  TRY(need(c, 1, blk * c->world));
+  TRY(ring_pack(s, slot0, n, mx, c->buf[0]));
+  NCCLCHK(rccl().AllGather(c->buf[0], c->buf[1], blk, ncclInt8, c->nccl, s->stream));
+  return ring_unpack(s, (const char*)c->buf[1], blk, c->world, particles_per_rank, total, mx, n, stacked, host_out);
+}
+
+int mjhmc_comm_allgather_columns(mjhmc_comm* c, mjhmc_sampler* s, const int64_t* local_idx, int64_t n_local,
+                                 const int64_t* columns_per_rank, double* host_out) {
+  if (!c || !s || !columns_per_rank || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (n_local < 0 || (n_local && !local_idx)) return mjhmc_fail(MJHMC_ERR_INVALID, "bad local index list");
+  if (columns_per_rank[c->rank] != n_local) return mjhmc_fail(MJHMC_ERR_INVALID, "columns_per_rank[rank] != n_local");
+  HIPCHK(hipSetDevice(c->ctx->device));
+  int64_t total, mx;
+  TRY(shard_totals(columns_per_rank, c->world, 0, &total, &mx));
+  if (total == 0) return 0;
+  const size_t blk = (size_t)mx * row_bytes(s);
+  TRY(need(c, 0, blk + (size_t)std::max<int64_t>(n_local, 1) * sizeof(int64_t)));
+  TRY(need(c, 1, blk * c->world));
+  TRY(columns_pack(s, local_idx, n_local, c->buf[0], (int64_t*)((char*)c->buf[0] + blk)));
+  NCCLCHK(rccl().AllGather(c->buf[0], c->buf[1], blk, ncclInt8, c->nccl, s->stream));
+  return columns_unpack(s, (const char*)c->buf[1], blk, c->world, columns_per_rank, total, host_out);
+}
+
+int mjhmc_comm_available(void) {
+  Rccl& r = rccl();
+  if (!r.err.empty()) return mjhmc_fail(MJHMC_ERR_COMM, r.err);
+  return 0;
+}
+
+int mjhmc_comm_count(mjhmc_comm* c, int* count) {
+  if (!c || !count) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
+  NCCLCHK(rccl().CommCount(c->nccl, count));
+  return 0;
+}
+
+#ifdef MJHMC_TEST_HOOKS
+// TEST HOOKS (libmjhmc_hip_test.so only): the pack and unpack steps of the two sample gathers with the collective
+// replaced by "the world's samplers all live on THIS GPU": sampler r plays rank r, its packed block is written where
+// ncclAllGather would have put it, and the REAL unpack runs on samplers[0]'s stream.  This executes the rank > 0
+// offsets, the padding to the largest shard and both output layouts on a single-GPU box.
+int mjhmc_test_gather_ring_local(mjhmc_sampler** samplers, int world, int slot0, int n, int stacked, double* host_out) {
+  if (!samplers || world < 1 || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "bad argument");
+  mjhmc_sampler* s0 = samplers[0];
+  std::vector<int64_t> counts((size_t)world);
+  for (int r = 0; r < world; ++r) {
+    mjhmc_sampler* s = samplers[r];
+    if (!s || s->D != s0->D || s->dtype != s0->dtype || s->sh.pitch != s0->sh.pitch)
+      return mjhmc_fail(MJHMC_ERR_INVALID, "samplers of one gather must share ndims and dtype");
+    if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return mjhmc_fail(MJHMC_ERR_INVALID, "slots out of range");
+    counts[(size_t)r] = s->N;
+  }
+  HIPCHK(hipSetDevice(s0->ctx->device));
+  int64_t total, mx;
+  TRY(shard_totals(counts.data(), world, 1, &total, &mx));
+  const size_t blk = (size_t)n * mx * row_bytes(s0);
+  char* recv = nullptr;
+  HIPCHK(hipMalloc(&recv, blk * world));
+  // padding rows must never be read: NaN bytes.  (hipMemset runs on the null stream, the samplers' streams do not wait
+  // for it: synchronise before the packs.)
+  int rc = (hipMemset(recv, 0xff, blk * world) == hipSuccess && hipDeviceSynchronize() == hipSuccess) ? 0 : mjhmc_fail(MJHMC_ERR_HIP, "hipMemset");
+  for (int r = 0; r < world && !rc; ++r) {
+    rc = ring_pack(samplers[r], slot0, n, mx, recv + (size_t)r * blk);
+    if (!rc && hipStreamSynchronize(samplers[r]->stream) != hipSuccess) rc = mjhmc_fail(MJHMC_ERR_HIP, "sync");
+  }
+  if (!rc) rc = ring_unpack(s0, recv, blk, world, counts.data(), total, mx, n, stacked, host_out);
+  (void)hipFree(recv);
+  return rc;
+}
+
+// local_idx: the ranks' index lists back to back (n_local[r] entries for rank r)
+int mjhmc_test_gather_columns_local(mjhmc_sampler** samplers, int world, const int64_t* local_idx, const int64_t* n_local,
+                                    double* host_out) {
+  if (!samplers || world < 1 || !n_local || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "bad argument");
+  mjhmc_sampler* s0 = samplers[0];
+  HIPCHK(hipSetDevice(s0->ctx->device));
+  int64_t total, mx;
+  TRY(shard_totals(n_local, world, 0, &total, &mx));
+  if (total == 0) return 0;
+  const size_t blk = (size_t)mx * row_bytes(s0);
+  char* recv = nullptr;
+  int64_t* rows = nullptr;
+  HIPCHK(hipMalloc(&recv, blk * world));
+  if (hipMalloc(&rows, (size_t)mx * sizeof(int64_t)) != hipSuccess) {
+    (void)hipFree(recv);
+    return mjhmc_fail(MJHMC_ERR_HIP, "hipMalloc");
+  }
+  int rc = (hipMemset(recv, 0xff, blk * world) == hipSuccess && hipDeviceSynchronize() == hipSuccess) ? 0 : mjhmc_fail(MJHMC_ERR_HIP, "hipMemset");
+  const int64_t* idx = local_idx;
+  for (int r = 0; r < world && !rc; ++r) {
+    mjhmc_sampler* s = samplers[r];
+    if (!s || s->D != s0->D || s->dtype != s0->dtype) rc = mjhmc_fail(MJHMC_ERR_INVALID, "samplers of one gather must share ndims and dtype");
+    if (!rc) rc = columns_pack(s, idx, n_local[r], recv + (size_t)r * blk, rows);
+    if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = mjhmc_fail(MJHMC_ERR_HIP, "sync");
+    idx += n_local[r];
+  }
+  if (!rc) rc = columns_unpack(s0, recv, blk, world, n_local, total, host_out);
+  (void)hipFree(rows);
+  (void)hipFree(recv);
+  return rc;
+}
+#endif  // MJHMC_TEST_HOOKS
 
 }  // extern "C"

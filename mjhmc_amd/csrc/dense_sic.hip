@@ -88,6 +88,7 @@ struct SicShared {
   f32x4 pubR[8][2][64];       // 16 KB: scaled residual as B fragments
   f32x4 ring[8][kRing][64];   // 64 KB: per-wave ring of dictionary (A operand) fragments, filled by LDS-DMA
   float ys[kYLds * kI];       // 12 KB: the patches
+  int ypatch[kP];             // byte offset of column c's patch inside ys (the column -> patch map does not depend on the tile)
   float red[2][8][kP];
   float colsum[kP];           // per-column energies, summed over a particle's columns when n_patches > 1
   int move[kP];
@@ -169,7 +170,20 @@ template <int NB>
 __device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared<NB>& sh) {
   if (mdl.P <= kYLds)
     for (int i = threadIdx.x; i < mdl.P * kI; i += blockDim.x) sh.ys[i] = mdl.y[i];
+  if (threadIdx.x < kP) {  // col_of: column c works on patch min(c, cpt - 1) % P
+    const int cpt = (kP / mdl.P) * mdl.P;
+    sh.ypatch[threadIdx.x] = ((threadIdx.x < cpt ? (int)threadIdx.x : cpt - 1) % mdl.P) * kI * (int)sizeof(float);
+  }
   __syncthreads();
+}
+
+// this lane's index in its wave, produced by instructions the compiler must re-issue wherever it is asked for: addresses
+// derived from it are RECOMPUTED inside the leapfrog loop (two vector instructions) instead of being kept live across it
+// -- at the 256-register budget they were spilled, and every spill reload is a counted load that drains the ring
+__device__ __forceinline__ unsigned lane_id_here() {
+  unsigned l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
 
 // what column c of a tile works on
@@ -210,7 +224,7 @@ __device__ __forceinline__ f32x4 frag_of(const f32x16& acc, int s, float scale) 
 }
 
 // residual of the tile at the X held in x (GEMM1).  Leaves it in `res` (fp32 accumulator layout).
-template <int NB>
+template <int NB, bool YG>
 __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
                                              int lane, int patch, const CTile<NB>& x, f32x16& res) {
   constexpr int kSteps = 16 * NB;  // GEMM1 k-steps = fragments per wave
@@ -221,12 +235,32 @@ __device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared<NB>&
   }
   __syncthreads();
   {  // res starts at -y[i]
-    const float* yv = (mdl.P <= kYLds ? sh.ys : mdl.y) + kI * patch + 32 * w + 4 * h;
+    using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
+    using lds_int = __attribute__((address_space(3))) const int;
+    using glb_f32x4 = __attribute__((address_space(1))) const f32x4;
+    if constexpr (!YG) {
+      // the patches are in LDS (n_patches <= kYLds): ds_read_b128 from an address rebuilt here from the lane index --
+      // nothing counted in vmcnt, nothing kept in a register across the loop.  (A pointer selected at run time between
+      // LDS and global memory is generic: its loads are flat_load, waited for with vmcnt(0), which drained the
+      // dictionary ring at the head of every GEMM1.)
+      const unsigned lid = lane_id_here();
+      unsigned ya = lds_addr(sh.ys) + (unsigned)__builtin_amdgcn_readfirstlane(128 * w) + ((lid >> 5) << 4);
+      if (mdl.P > 1) ya += (unsigned)*(lds_int*)(unsigned long)(lds_addr(sh.ypatch) + ((lid & 31u) << 2));
+      lds_f32x4* yv = (lds_f32x4*)(unsigned long)ya;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(yv + 8 * g);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = yv[2 * g];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
+        for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
+      }
+    } else {  // n_patches 13..32: global loads (counted: this instantiation drains the ring once per GEMM1)
+      glb_f32x4* yv = (glb_f32x4*)(__attribute__((address_space(1))) const float*)(mdl.y + kI * patch + 32 * w + 4 * h);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = yv[2 * g];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
+      }
     }
   }
   // 16 NB k-steps; the fragment of k-step ks is in ring slot ks % kRing, and its slot is refilled with the fragment
@@ -391,19 +425,27 @@ __device__ __forceinline__ void round_to_state(CTile<NB>& t) {
 
 // L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
 // separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place.
-template <bool CAUCHY, int NB>
+template <bool CAUCHY, int NB, bool YG>
 __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
                                                 int lane, const Col& col, CTile<NB>& x, CTile<NB>& v, int L, float eps,
                                                 float chalf) {
+  // the step scale is wave-uniform: both values sit in scalar registers and the select is an integer s_cselect (a float
+  // select is a per-lane v_cndmask whose operand was spilled and reloaded -- a counted load -- in front of every GEMM2)
+  const int c_half = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, chalf));
+  const int c_full = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f * chalf));
   f32x16 res;
-  sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+  sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
   if (L > 0) sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, chalf, v);
   else astream_rewind(as);
   for (int s = 1; s <= L; ++s) {
+    asm volatile("; MJHMC_LEAPFROG_STEP_BEGIN (tools/check_isa.sh)");
 #pragma unroll
     for (int b = 0; b < NB; ++b) x.b[b] = x.b[b] + eps * v.b[b];
-    sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-    sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, s < L ? 2.0f * chalf : chalf, v);
+    sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+    // the step scale is wave-uniform: selected as an integer so that it stays in a scalar register (a float select is a
+    // per-lane v_cndmask whose operand was spilled and reloaded -- a counted load -- in front of every GEMM2)
+    sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, __builtin_bit_cast(float, s < L ? c_full : c_half), v);
+    asm volatile("; MJHMC_LEAPFROG_STEP_END");
   }
   // the successor position is stored in bf16 (and GEMM1 already saw bf16(x)): evaluate the prior on
   // what will be stored, so EX is the energy of the stored state
@@ -438,7 +480,7 @@ __device__ __forceinline__ void sic_add_normals(const RngKey& key, uint32_t pid,
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <bool CAUCHY, int NB>
+template <bool CAUCHY, int NB, bool YG>
 __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, const SicModel mdl) {
   __shared__ SicShared<NB> sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
@@ -449,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
     CTile<NB> x;
     ctile_load(a.X, col.q, w, h, x);
     f32x16 res;
-    sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+    sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
     if (a.G) {
       CTile<NB> g;
 #pragma unroll
@@ -518,7 +560,7 @@ struct FromList {
   __device__ int64_t operator()(int64_t s) const { return list[s]; }
 };
 
-template <bool CAUCHY, int NB>
+template <bool CAUCHY, int NB, bool YG>
 __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, const SicModel mdl) {
   __shared__ SicShared<NB> sh;
   if (a.ctl->failed) return;
@@ -535,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
     ctile_load(a.V_in, col.q, w, h, v);
 #pragma unroll
     for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
-    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY, NB, YG>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);  // the same rounding the jump kernel applies to the forward proposal
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (w == 0 && h == 0 && col.leader) a.Hwork[col.part] = ex + ev;
@@ -546,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
 
 // MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
 // the reference's sparse-coding experiments, search/control_sp_img/control_objective.py:10)
-template <bool CAUCHY, bool REPLAY, int MODE, int NB>
+template <bool CAUCHY, bool REPLAY, int MODE, int NB, bool YG>
 __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, const SicModel mdl) {
   __shared__ SicShared<NB> sh;
   if (a.ctl->failed) return;
@@ -565,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
     CTile<NB> x, v;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
-    const float EXL = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float EXL = sic_trajectory<CAUCHY, NB, YG>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
     const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
@@ -670,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
 }
 
 // HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
-template <bool CAUCHY, int NB>
+template <bool CAUCHY, int NB, bool YG>
 __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, const SicModel mdl) {
   __shared__ SicShared<NB> sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
@@ -681,12 +723,12 @@ __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, c
     CTile<NB> x, v;
     ctile_load(a.X, col.q, w, h, x);
     ctile_load(a.V, col.q, w, h, v);
-    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY, NB, YG>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
     round_to_state(v);
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (a.G) {  // dE/dX of the stored end point
       f32x16 res;
-      sic_residual(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+      sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
       CTile<NB> g;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
@@ -726,53 +768,57 @@ static int sic_cus() {
   return std::max(1, cus);
 }
 
-template <bool CAUCHY, int MODE, int NB>
+template <bool CAUCHY, int MODE, int NB, bool YG>
 static void sic_launch_mode(const SicJumpArgs& a, const SicModel& mdl, unsigned grid, hipStream_t st) {
   const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);
-  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
-  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB, YG>), dim3(grid), dim3(512), 0, st, a, mdl);
+  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB, YG>), dim3(grid), dim3(512), 0, st, a, mdl);
 }
 
-template <bool CAUCHY, int NB>
+template <bool CAUCHY, int NB, bool YG>
 static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
     (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
     hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
                        a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
-    hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
-    sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
+    hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB, YG>), dim3(grid), dim3(512), 0, st, a, mdl);
+    sic_launch_mode<CAUCHY, kModeMJHMC, NB, YG>(a, mdl, grid, st);
   } else if (a.mode == kModeCT) {
-    sic_launch_mode<CAUCHY, kModeCT, NB>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeCT, NB, YG>(a, mdl, grid, st);
   } else {
-    sic_launch_mode<CAUCHY, kModeControl, NB>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeControl, NB, YG>(a, mdl, grid, st);
   }
 }
 
-// the prior (Cauchy / Laplace) and the dictionary width (1024 / 512 atoms) select the instantiation
-#define SIC_DISPATCH(CALL)                                   \
-  do {                                                       \
-    if (mdl.nc == 1024) {                                    \
-      if (mdl.cauchy) CALL(true, 4); else CALL(false, 4);    \
-    } else {                                                 \
-      if (mdl.cauchy) CALL(true, 2); else CALL(false, 2);    \
-    }                                                        \
+// the prior (Cauchy / Laplace), the dictionary width (1024 / 512 atoms) and where the patches are read from (LDS for
+// n_patches <= kYLds, global memory otherwise) select the instantiation
+#define SIC_DISPATCH(CALL)                                                 \
+  do {                                                                     \
+    const bool yg = mdl.P > kYLds;                                         \
+    if (mdl.nc == 1024) {                                                  \
+      if (mdl.cauchy) { if (yg) CALL(true, 4, true); else CALL(true, 4, false); }     \
+      else { if (yg) CALL(false, 4, true); else CALL(false, 4, false); }               \
+    } else {                                                               \
+      if (mdl.cauchy) { if (yg) CALL(true, 2, true); else CALL(true, 2, false); }     \
+      else { if (yg) CALL(false, 2, true); else CALL(false, 2, false); }               \
+    }                                                                      \
   } while (0)
 
 void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-#define SIC_JUMP(C, NBV) sic_launch_jump_t<C, NBV>(a, mdl, st)
+#define SIC_JUMP(C, NBV, YGV) sic_launch_jump_t<C, NBV, YGV>(a, mdl, st)
   SIC_DISPATCH(SIC_JUMP);
 }
 
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-#define SIC_EVAL(C, NBV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
+#define SIC_EVAL(C, NBV, YGV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV, YGV>), dim3(grid), dim3(512), 0, st, a, mdl)
   SIC_DISPATCH(SIC_EVAL);
 }
 
 void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-#define SIC_LEAP(C, NBV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
+#define SIC_LEAP(C, NBV, YGV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV, YGV>), dim3(grid), dim3(512), 0, st, a, mdl)
   SIC_DISPATCH(SIC_LEAP);
 }
 

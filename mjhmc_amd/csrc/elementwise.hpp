@@ -479,6 +479,9 @@ struct FunnelRefF {
 // kernel arguments
 // ------------------------------------------------------------------------------------------
 
+// launch_jump_t's A/B flags (JumpArgs::ab): take the generic instance instead of a specialised lane mapping
+constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4;
+
 template <typename T>
 struct JumpArgs {
   const T* X_in;
@@ -511,6 +514,7 @@ struct JumpArgs {
   // its dwelling times at dwell_ring + it * Npad; X_out is then not written (the last slot is the live state).
   int defer_r;          // != 0: R-movers keep their old momentum here; mjhmc_refresh_kernel draws the new one
   int n_fuse;
+  int ab;               // host-side launch A/B flags (kAb*): always 0 in the shipped library, set by the test build's switches
   T* xiter;
   size_t xiter_stride;  // elements of T between consecutive ring slots
   int mode;             // kModeMJHMC / kModeControl / kModeCT
@@ -1854,10 +1858,10 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool replay = a.noise != nullptr;
   if constexpr (En::kFuse) if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
     if (a.mode == kModeMJHMC) {
-      if (full && a.logG == 6 && !std::getenv("MJHMC_NO_BLOCK_DECIDE")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 5, true>(a, en, st);
-      else if (full && a.logG == 5 && !std::getenv("MJHMC_NO_BLOCK_DECIDE")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 6, true>(a, en, st);
+      if (full && a.logG == 6 && !(a.ab & kAbNoBlockDecide)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 5, true>(a, en, st);
+      else if (full && a.logG == 5 && !(a.ab & kAbNoBlockDecide)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 6, true>(a, en, st);
       else if (full && a.logG == 6) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1, true>(a, en, st);
-      else if (full && a.logG == 2 && !std::getenv("MJHMC_NO_QUAD")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3, true>(a, en, st);
+      else if (full && a.logG == 2 && !(a.ab & kAbNoQuad)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3, true>(a, en, st);
       else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true, 0, true>(a, en, st);
       else launch_jump_r<En, T, E, kModeMJHMC, false, false, 0, true>(a, en, st);
     } else if (a.mode == kModeCT) {
@@ -1869,8 +1873,8 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   }
   if (a.mode == kModeMJHMC) {
     if (replay) launch_jump_r<En, T, E, kModeMJHMC, true, false>(a, en, st);
-    else if (full && a.logG == 6 && !std::getenv("MJHMC_NO_WPP")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1>(a, en, st);
-    else if (full && a.logG == 2 && !std::getenv("MJHMC_NO_QUAD")) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3>(a, en, st);
+    else if (full && a.logG == 6 && !(a.ab & kAbNoWpp)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 1>(a, en, st);
+    else if (full && a.logG == 2 && !(a.ab & kAbNoQuad)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 3>(a, en, st);
     else if (full) launch_jump_r<En, T, E, kModeMJHMC, false, true>(a, en, st);
     else launch_jump_r<En, T, E, kModeMJHMC, false, false>(a, en, st);
   } else if (a.mode == kModeCT) {

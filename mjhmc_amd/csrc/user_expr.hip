@@ -10,6 +10,7 @@
 // creation, for gfx950.  The resulting energy runs through exactly the code paths of the built-in elementwise
 // energies: same lane mapping, same jump / accept logic, same counter RNG, all three sampler families, replay mode.
 #include <dlfcn.h>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
@@ -38,13 +39,20 @@ struct Rtc {
 Rtc& rtc() {
   static Rtc r;
   if (r.so || !r.err.empty()) return r;
+  // MJHMC_HIPRTC_LIB names the library to load and is then the ONLY name tried; otherwise the sonames of the ROCm install
+  const char* named = std::getenv("MJHMC_HIPRTC_LIB");
   const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
-  for (const char* n : names) {
-    r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.so) break;
+  if (named && *named) {
+    r.so = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    for (const char* n : names) {
+      r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.so) break;
+    }
   }
   if (!r.so) {
-    r.err = std::string("libhiprtc.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    const char* why = dlerror();  // ONE call: dlerror() clears the message it returns
+    r.err = std::string("libhiprtc.so could not be loaded: ") + (why ? why : "?");
     return r;
   }
   auto sym = [&](const char* name) -> void* {

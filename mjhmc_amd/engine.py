@@ -23,10 +23,10 @@ def dtype_code(dtype):
 
 
 class Context(object):
-    def __init__(self, device=0):
-        self.lib = _lib.load()
+    def __init__(self, device=0, lib=None):
+        self.lib = lib if lib is not None else _lib.load()     # lib: _lib.load_test_hooks() in the A/B tests
         h = ctypes.c_void_p()
-        check(self.lib.mjhmc_ctx_create(int(device), ctypes.byref(h)))
+        check(self.lib.mjhmc_ctx_create(int(device), ctypes.byref(h)), self.lib)
         self.handle = h
         self.device = int(device)
 
@@ -34,7 +34,7 @@ class Context(object):
         name = ctypes.create_string_buffer(256)
         ncu = ctypes.c_int()
         hbm = ctypes.c_uint64()
-        check(self.lib.mjhmc_ctx_info(self.handle, name, 256, ctypes.byref(ncu), ctypes.byref(hbm)))
+        check(self.lib.mjhmc_ctx_info(self.handle, name, 256, ctypes.byref(ncu), ctypes.byref(hbm)), self.lib)
         return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
 
     def autocor(self, samples, linear=False):
@@ -45,7 +45,7 @@ class Context(object):
         n = samples.shape[2]
         out = np.empty(n, dtype=np.float64)
         check(self.lib.mjhmc_autocor(self.handle, ptr(samples), int(samples.shape[0] * samples.shape[1]), int(n),
-                                     1 if linear else 0, ptr(out)))
+                                     1 if linear else 0, ptr(out)), self.lib)
         return out
 
 
@@ -66,7 +66,7 @@ class DeviceEnergy(object):
         self.params = np.ascontiguousarray(np.atleast_1d(params), dtype=np.float64)
         h = ctypes.c_void_p()
         check(ctx.lib.mjhmc_energy_create(ctx.handle, self.kind, self.ndims, ptr(self.params), self.params.size,
-                                          ctypes.byref(h)))
+                                          ctypes.byref(h)), ctx.lib)
         self.handle = h
 
     @classmethod
@@ -86,7 +86,7 @@ class DeviceEnergy(object):
         check(ctx.lib.mjhmc_energy_create_expr_coupled(
             ctx.handle, self.ndims, ';'.join(str(t) for t in stats).encode() if stats else None, str(energy_expr).encode(),
             str(energy0_expr).encode() if energy0_expr else None, str(grad_expr).encode(),
-            ptr(self.params) if self.params.size else None, self.params.size, _lib.KERNEL_HEADERS.encode(), ctypes.byref(h)))
+            ptr(self.params) if self.params.size else None, self.params.size, _lib.KERNEL_HEADERS.encode(), ctypes.byref(h)), ctx.lib)
         self.handle = h
         return self
 
@@ -98,7 +98,7 @@ class DeviceEnergy(object):
         E = np.empty(n) if want_E else None
         G = np.empty((self.ndims, n)) if want_grad else None
         if n:
-            check(self.ctx.lib.mjhmc_eval(self.handle, dtype_code(dtype), ptr(X), n, ptr(E), ptr(G)))
+            check(self.ctx.lib.mjhmc_eval(self.handle, dtype_code(dtype), ptr(X), n, ptr(E), ptr(G)), self.ctx.lib)
         return E, G
 
     def leapfrog(self, X, V, epsilon, n_steps, want_grad=True, dtype='float64'):
@@ -114,7 +114,7 @@ class DeviceEnergy(object):
         G = np.empty_like(X) if want_grad else None
         if n:
             check(self.ctx.lib.mjhmc_leapfrog(self.handle, dtype_code(dtype), ptr(X), ptr(V), n, float(epsilon), int(n_steps),
-                                              ptr(Xo), ptr(Vo), ptr(EX), ptr(EV), ptr(G)))
+                                              ptr(Xo), ptr(Vo), ptr(EX), ptr(EV), ptr(G)), self.ctx.lib)
         return Xo, Vo, EX, EV, G
 
     def __del__(self):
@@ -142,13 +142,13 @@ class DeviceSampler(object):
         h = ctypes.c_void_p()
         check(self.lib.mjhmc_sampler_create(self.ctx.handle, energy.handle, self.nparticles, int(first_particle_id),
                                             dtype_code(dtype), ptr(X), ptr(V), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
-                                            int(mode), ctypes.byref(h)))
+                                            int(mode), ctypes.byref(h)), self.lib)
         self.handle = h
         self.ring_slots = 0
 
     def set_hparams(self, epsilon, num_leapfrog_steps, p_r, beta=1.0, p_flip=0.5):
         check(self.lib.mjhmc_set_hparams(self.handle, float(epsilon), int(num_leapfrog_steps), float(p_r), float(beta),
-                                         float(p_flip)))
+                                         float(p_flip)), self.lib)
 
     def iterate(self, n_iter=1, replay_normal=None, replay_exp=None, replay_unif=None, ring_slot0=-1):
         """Returns (list of IterStats for the attempts made, n_done)."""
@@ -159,33 +159,33 @@ class DeviceSampler(object):
         stats = (_lib.IterStats * n_iter)()
         done = ctypes.c_int()
         check(self.lib.mjhmc_iterate(self.handle, int(n_iter), ptr(rn), ptr(re), ptr(ru), int(ring_slot0), stats,
-                                     ctypes.byref(done)))
+                                     ctypes.byref(done)), self.lib)
         n_done = done.value
         attempts = n_done + 1 if n_done < n_iter else n_iter
         return [stats[i] for i in range(attempts)], n_done
 
     def reset_flf_cache(self):
-        check(self.lib.mjhmc_reset_flf_cache(self.handle))
+        check(self.lib.mjhmc_reset_flf_cache(self.handle), self.lib)
 
     def checkpoint(self):
-        check(self.lib.mjhmc_checkpoint(self.handle))
+        check(self.lib.mjhmc_checkpoint(self.handle), self.lib)
 
     def restore(self):
-        check(self.lib.mjhmc_restore(self.handle))
+        check(self.lib.mjhmc_restore(self.handle), self.lib)
 
     def rollback(self):
-        check(self.lib.mjhmc_rollback(self.handle))
+        check(self.lib.mjhmc_rollback(self.handle), self.lib)
 
     def get_tick(self):
         t = ctypes.c_uint64()
-        check(self.lib.mjhmc_get_tick(self.handle, ctypes.byref(t)))
+        check(self.lib.mjhmc_get_tick(self.handle, ctypes.byref(t)), self.lib)
         return int(t.value)
 
     def set_tick(self, tick):
-        check(self.lib.mjhmc_set_tick(self.handle, ctypes.c_uint64(int(tick))))
+        check(self.lib.mjhmc_set_tick(self.handle, ctypes.c_uint64(int(tick))), self.lib)
 
     def advance_tick(self, n=1):
-        check(self.lib.mjhmc_advance_tick(self.handle, int(n)))
+        check(self.lib.mjhmc_advance_tick(self.handle, int(n)), self.lib)
 
     def read(self, field):
         D, N = self.ndims, self.nparticles
@@ -195,7 +195,7 @@ class DeviceSampler(object):
             out = np.empty(N, dtype=np.uint8)
         else:
             out = np.empty(N)
-        check(self.lib.mjhmc_read(self.handle, int(field), ptr(out), out.nbytes))
+        check(self.lib.mjhmc_read(self.handle, int(field), ptr(out), out.nbytes), self.lib)
         return out
 
     def write(self, field, arr):
@@ -203,49 +203,49 @@ class DeviceSampler(object):
             a = as_f64(np.asarray(arr, dtype=np.float64).reshape(-1), (self.nparticles,))
         else:
             a = as_f64(arr, (self.ndims, self.nparticles))
-        check(self.lib.mjhmc_write(self.handle, int(field), ptr(a), a.nbytes))
+        check(self.lib.mjhmc_write(self.handle, int(field), ptr(a), a.nbytes), self.lib)
 
     def ring_alloc(self, n_slots):
-        check(self.lib.mjhmc_ring_alloc(self.handle, int(n_slots)))
+        check(self.lib.mjhmc_ring_alloc(self.handle, int(n_slots)), self.lib)
         self.ring_slots = max(self.ring_slots, int(n_slots))
 
     def ring_read_dwell(self, slot0, n):
         out = np.empty((n, self.nparticles))
-        check(self.lib.mjhmc_ring_read_dwell(self.handle, int(slot0), int(n), ptr(out)))
+        check(self.lib.mjhmc_ring_read_dwell(self.handle, int(slot0), int(n), ptr(out)), self.lib)
         return out
 
     def ring_gather(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         out = np.empty((self.ndims, idx.size))
         if idx.size:
-            check(self.lib.mjhmc_ring_gather(self.handle, ptr(idx), idx.size, ptr(out)))
+            check(self.lib.mjhmc_ring_gather(self.handle, ptr(idx), idx.size, ptr(out)), self.lib)
         return out
 
     def ring_read(self, slot0, n, stacked=False):
         shape = (self.ndims, self.nparticles, n) if stacked else (self.ndims, n * self.nparticles)
         out = np.empty(shape)
-        check(self.lib.mjhmc_ring_read(self.handle, int(slot0), int(n), 1 if stacked else 0, ptr(out)))
+        check(self.lib.mjhmc_ring_read(self.handle, int(slot0), int(n), 1 if stacked else 0, ptr(out)), self.lib)
         return out
 
     def ring_moments(self, slot0, n, shift=0.0):
         """(sum (x - shift), sum (x - shift)^2) over all state elements of ring slots [slot0, slot0 + n)."""
         a, b = ctypes.c_double(), ctypes.c_double()
-        check(self.lib.mjhmc_ring_moments(self.handle, int(slot0), int(n), float(shift), ctypes.byref(a), ctypes.byref(b)))
+        check(self.lib.mjhmc_ring_moments(self.handle, int(slot0), int(n), float(shift), ctypes.byref(a), ctypes.byref(b)), self.lib)
         return a.value, b.value
 
     def ring_autocor(self, slot0, n, linear=False):
         """Lag sums over time of ring slots [slot0, slot0 + n), summed over all state elements."""
         out = np.empty(int(n), dtype=np.float64)
-        check(self.lib.mjhmc_ring_autocor(self.handle, int(slot0), int(n), 1 if linear else 0, ptr(out)))
+        check(self.lib.mjhmc_ring_autocor(self.handle, int(slot0), int(n), 1 if linear else 0, ptr(out)), self.lib)
         return out
 
     def last_timing(self):
         t, k, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        check(self.lib.mjhmc_last_timing(self.handle, ctypes.byref(t), ctypes.byref(k), ctypes.byref(n)))
+        check(self.lib.mjhmc_last_timing(self.handle, ctypes.byref(t), ctypes.byref(k), ctypes.byref(n)), self.lib)
         return dict(total_ms=t.value, jump_kernel_ms=k.value, n_jump_launches=n.value)
 
     def sync(self):
-        check(self.lib.mjhmc_sync(self.handle))
+        check(self.lib.mjhmc_sync(self.handle), self.lib)
 
     def close(self):
         if getattr(self, 'handle', None):

@@ -54,17 +54,72 @@ class _CommBase(object):
         return self.allreduce_ints(v, 'sum')
 
 
+class FileRendezvous(object):
+    """Host-side key/value exchange between the ranks of one job through a directory all of them see (a fresh
+    ``mkdtemp`` directory made by the launcher: nothing stale can be in it).  Writes are atomic (tmp + rename)."""
+
+    def __init__(self, dirpath, rank, world, timeout=300.0):
+        self.dir, self.rank, self.world, self.timeout = str(dirpath), int(rank), int(world), float(timeout)
+
+    def _path(self, key):
+        return os.path.join(self.dir, key)
+
+    def put(self, key, data):
+        tmp = '%s.%d.tmp' % (self._path(key), os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(bytes(data))
+        os.replace(tmp, self._path(key))
+
+    def get(self, key):
+        t0 = time.time()
+        while not os.path.exists(self._path(key)):
+            if time.time() - t0 > self.timeout:
+                raise RuntimeError('rank %d: nothing at %s after %.0f s' % (self.rank, self._path(key), self.timeout))
+            time.sleep(0.005)
+        with open(self._path(key), 'rb') as f:
+            return f.read()
+
+    def all_agree(self, name, ok):
+        """every rank posts a flag; True only when EVERY rank posted ok (decided before any collective is entered)"""
+        self.put('%s.%d' % (name, self.rank), b'1' if ok else b'0')
+        return all(self.get('%s.%d' % (name, r)) == b'1' for r in range(self.world))
+
+
+def _process_start_ticks(pid):
+    """start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat): (pid, start time) names one
+    process for the lifetime of the machine, a recycled pid has another start time"""
+    try:
+        with open('/proc/%d/stat' % pid) as f:
+            return f.read().rsplit(')', 1)[1].split()[19]
+    except Exception:
+        return '0'
+
+
+def default_id_path():
+    """Where rank 0 publishes the communicator id when the caller names no channel: ``MJHMC_COMM_ID_FILE`` (what
+    ``bench.py --gpus N`` and any launcher that wants an explicit rendezvous export: a path in a fresh directory);
+    last resort: a name built from the launcher's pid AND its start time plus MASTER_PORT, which every rank of one
+    ``torch.distributed.run`` / ``mpirun`` job on a node shares and no earlier (crashed) job can have used."""
+    path = os.environ.get('MJHMC_COMM_ID_FILE')
+    if path:
+        return path, True
+    import tempfile
+    ppid = os.getppid()
+    return os.path.join(tempfile.gettempdir(), 'mjhmc_comm_%d_%s_%s.id'
+                        % (ppid, _process_start_ticks(ppid), os.environ.get('MASTER_PORT', '0'))), False
+
+
 class RcclComm(_CommBase):
     """This rank's end of the library's RCCL communicator.
 
-    Rendezvous: rank 0 draws the 128-byte unique id and publishes it through a file the other ranks wait for
-    (``id_path``; default: a name in the system temp directory built from the launcher's pid and MASTER_PORT, which
-    every rank of one ``torch.distributed.run`` / ``mpirun`` job on a node shares)."""
+    Rendezvous: rank 0 draws the 128-byte unique id and hands it to the other ranks through ``rendezvous`` (any object
+    with ``put(key, bytes)`` / ``get(key) -> bytes``: FileRendezvous, or the launcher's key/value store), else through
+    the file ``id_path`` (default: default_id_path())."""
 
     on_device = True
     _created = 0
 
-    def __init__(self, rank=None, world=None, device=None, id_path=None, timeout=300.0):
+    def __init__(self, rank=None, world=None, device=None, id_path=None, timeout=300.0, rendezvous=None):
         from . import _lib, engine
         self._lib_mod = _lib
         rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
@@ -73,35 +128,39 @@ class RcclComm(_CommBase):
         self.rank, self.world, self.backend, self.device = rank, world, 'rccl', device
         self.ctx = engine.context(device)
         self.lib = self.ctx.lib
-        if id_path is None:
-            import tempfile
-            id_path = os.path.join(tempfile.gettempdir(), 'mjhmc_comm_%d_%s_%d.id'
-                                   % (os.getppid(), os.environ.get('MASTER_PORT', '0'), RcclComm._created))
+        serial = RcclComm._created                          # several communicators of one job: one id each
         RcclComm._created += 1
+        if rendezvous is None:
+            if id_path is None:
+                id_path, _ = default_id_path()
+            d, base = os.path.split('%s.%d' % (id_path, serial) if serial else id_path)
+            rendezvous, key = FileRendezvous(d or '.', rank, world, timeout), base
+        else:
+            key = 'mjhmc_comm_id.%d' % serial
         buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
         if rank == 0:
             _lib.check(self.lib.mjhmc_comm_unique_id(buf))
-            tmp = '%s.%d.tmp' % (id_path, os.getpid())
-            with open(tmp, 'wb') as f:
-                f.write(buf.raw)
-            os.replace(tmp, id_path)                     # atomic: readers never see a partial id
+            rendezvous.put(key, buf.raw)
         else:
-            t0 = time.time()
-            while not os.path.exists(id_path):
-                if time.time() - t0 > timeout:
-                    raise RuntimeError('rank %d: no communicator id at %s after %.0f s' % (rank, id_path, timeout))
-                time.sleep(0.01)
-            with open(id_path, 'rb') as f:
-                buf.raw = f.read(_lib.COMM_ID_BYTES)
+            raw = rendezvous.get(key)
+            if len(raw) != _lib.COMM_ID_BYTES:
+                raise RuntimeError('rank %d: communicator id of %d bytes (expected %d)' % (rank, len(raw), _lib.COMM_ID_BYTES))
+            buf.raw = raw
         h = ctypes.c_void_p()
         _lib.check(self.lib.mjhmc_comm_create(self.ctx.handle, rank, world, buf, ctypes.byref(h)))
         self.handle = h
         self.barrier()                                   # everyone has read the id: rank 0 may remove the file
-        if rank == 0:
+        if rank == 0 and isinstance(rendezvous, FileRendezvous):
             try:
-                os.remove(id_path)
+                os.remove(os.path.join(rendezvous.dir, key))
             except OSError:
                 pass
+
+    def count(self):
+        """ranks of the communicator as RCCL reports them (ncclCommCount)"""
+        n = ctypes.c_int()
+        self._lib_mod.check(self.lib.mjhmc_comm_count(self.handle, ctypes.byref(n)))
+        return int(n.value)
 
     # -- small host-value collectives ---------------------------------------------------------
     def allreduce_ints(self, values, op='sum'):

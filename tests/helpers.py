@@ -196,3 +196,17 @@ def check_control_iteration(s, o, delta_rel, x_tol, e_rtol, tag=''):
     eEV = np.abs(s.state.EV[0, same] - o.state.EV[0, same]).max() / scale
     assert eEX <= e_rtol and eEV <= e_rtol, (tag, 'EX, EV errors / max|H|', eEX, eEV, 'allowed', e_rtol)
     return int(diff.sum())
+
+
+_HOOKS_CTX = {}
+
+
+def hooks_context(device=0):
+    """An engine.Context on libmjhmc_hip_test.so -- the SAME sources built with -DMJHMC_TEST_HOOKS (csrc/Makefile:
+    test_hooks): only there do the environment A/B switches of the launch strategies (MJHMC_NO_FUSE, MJHMC_NO_COMPACT,
+    MJHMC_NO_SPLIT, ...), the failure-placing hook MJHMC_DEBUG_POISON and the single-GPU gather hooks exist.  The A/B
+    tests run the PRODUCT library's sampler against a test-build sampler with a switch set."""
+    from mjhmc_amd import engine, _lib
+    if device not in _HOOKS_CTX:
+        _HOOKS_CTX[device] = engine.Context(device, lib=_lib.load_test_hooks())
+    return _HOOKS_CTX[device]

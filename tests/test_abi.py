@@ -93,6 +93,54 @@ def test_user_expression_energies_compile_without_a_device(lib):
     assert rc == -1 and b"undeclared identifier 'T'" in lib.mjhmc_last_error()
 
 
+def test_unloadable_rccl_and_hiprtc_are_errors_not_crashes():
+    """librccl / libhiprtc are dlopen'ed on first use; when that fails the entry points return MJHMC_ERR_COMM /
+    MJHMC_ERR_INVALID with the loader's message (dlerror() is consumed ONCE -- a second call returns NULL)."""
+    import subprocess
+    import sys
+    code = """
+import ctypes, sys
+sys.path.insert(0, %r)
+from mjhmc_amd import _lib
+lib = _lib.load()
+assert lib.mjhmc_comm_available() == -6, lib.mjhmc_last_error()
+msg = lib.mjhmc_last_error()
+assert b'librccl.so could not be loaded' in msg and b'/nonexistent/librccl.so' in msg, msg
+buf = ctypes.create_string_buffer(128)
+assert lib.mjhmc_comm_unique_id(buf) == -6
+rc = lib.mjhmc_expr_check(4, b"0.5*x*x", b"x", _lib.KERNEL_HEADERS.encode())
+assert rc != 0 and b'libhiprtc.so could not be loaded' in lib.mjhmc_last_error(), lib.mjhmc_last_error()
+print('load failures ok')
+""" % ROOT
+    env = dict(os.environ, MJHMC_RCCL_LIB='/nonexistent/librccl.so', MJHMC_HIPRTC_LIB='/nonexistent/libhiprtc.so')
+    env.pop('MJHMC_HIP_LIB', None)
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and 'load failures ok' in p.stdout.decode(), p.stdout.decode()[-2000:]
+
+
+def test_rccl_loads_here(lib):
+    assert lib.mjhmc_comm_available() == 0, lib.mjhmc_last_error()
+
+
+def test_shipped_library_reads_no_switches_test_build_does():
+    """The A/B environment switches and the failure-placing hook are compiled into libmjhmc_hip_test.so only."""
+    hooks = _lib.TEST_HOOKS_PATH
+    if not os.path.exists(hooks):
+        import __graft_entry__ as g
+        g.build()
+    ship = open(_lib.LIB_PATH, 'rb').read()
+    test = open(hooks, 'rb').read()
+    for name in (b'MJHMC_DEBUG_POISON', b'MJHMC_NO_FUSE', b'MJHMC_NO_SPLIT', b'MJHMC_NO_COMPACT', b'MJHMC_CHUNKS_PER_LANE',
+                 b'MJHMC_AUTOCOR_STAGING_MB', b'mjhmc_test_gather_ring_local'):
+        assert name not in ship, name
+        assert name in test, name
+    envs = set(re.findall(rb'MJHMC_[A-Z_]{3,}', ship)) - {b'MJHMC_ERR_', b'MJHMC_E_'}
+    assert {e for e in envs if not e.startswith((b'MJHMC_E_', b'MJHMC_ERR', b'MJHMC_F', b'MJHMC_MODE', b'MJHMC_OP', b'MJHMC_BF'))} \
+        <= {b'MJHMC_RCCL_LIB', b'MJHMC_HIPRTC_LIB', b'MJHMC_HIPFFT_LIB', b'MJHMC_JUMP_WAVES', b'MJHMC_ABI_VERSION', b'MJHMC_COMM_ID_BYTES'}, envs
+    t = _lib.load_test_hooks()
+    assert hasattr(t, 'mjhmc_test_gather_ring_local') and hasattr(t, 'mjhmc_iterate')
+
+
 def test_host_side_under_address_sanitizer(tmp_path):
     """`make asan`: the translation units that hold host logic (handles, argument checks, RCCL / hipRTC plumbing) built
     with AddressSanitizer on the host side and driven through their error paths and the hipRTC compile (no device

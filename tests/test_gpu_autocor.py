@@ -71,10 +71,29 @@ def test_ring_resident_autocorrelation(cls_name, D, N, T, monkeypatch):
     samples, e2, g2 = generate_samples(cls, _gaussian(D, N, 3), num_steps=T, **kw)
     assert ac.shape == (T,) and np.array_equal(e, e2) and np.array_equal(g, g2)
     np.testing.assert_allclose(ac, aco.fft_autocor(samples), rtol=0, atol=ATOL)
-    # a staging budget of 1 MB forces several chunks of series (and a ragged last one)
+    # a staging budget of 1 MB forces several chunks of series (and a ragged last one): the test build of the library
+    # reads MJHMC_AUTOCOR_STAGING_MB; host-array source and ring source against the product library's one-chunk result
+    from mjhmc_amd import engine, _lib
+    from tests.helpers import hooks_context
     monkeypatch.setenv('MJHMC_AUTOCOR_STAGING_MB', '1')
-    ac_chunked, _, _ = calculate_autocorrelation(cls, _gaussian(D, N, 3), num_steps=T, **kw)
-    np.testing.assert_allclose(ac_chunked, ac, rtol=0, atol=1e-13)
+    hctx = hooks_context(0)
+    for linear in (False, True):
+        want = engine.context(0).autocor(samples, linear=linear)
+        got = hctx.autocor(samples, linear=linear)
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13 * abs(want[0]))
+    rs = np.random.RandomState(9)
+    Xr = rs.randn(D, N)
+    rings = []
+    for ctx in (engine.context(0), hctx):
+        en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.0])
+        smp = engine.DeviceSampler(en, Xr, seed=3)
+        smp.set_hparams(0.3, 4, 0.1, 1.0)
+        smp.ring_alloc(T)
+        smp.iterate(T, ring_slot0=0)
+        rings.append(smp.ring_autocor(0, T))
+        smp.close()
+    np.testing.assert_allclose(rings[1], rings[0], rtol=1e-13, atol=1e-13 * abs(rings[0][0]))
+    monkeypatch.delenv('MJHMC_AUTOCOR_STAGING_MB', raising=False)
     # gradient-budget form: the curve of the truncated run
     ac3, e3, g3 = calculate_autocorrelation(cls, _gaussian(D, N, 3), num_grad_steps=60, **kw)
     k = int(np.nonzero(g2 >= 60)[0][0]) + 1 if np.any(g2 >= 60) else None

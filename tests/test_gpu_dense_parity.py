@@ -15,7 +15,7 @@ import pytest
 
 from oracle import mjhmc_oracle as orc
 from tests.helpers import (load, ref_init_weights, sic_problem, to_bf16, resync as _resync, check_iteration,
-                           check_control_iteration)
+                           check_control_iteration, hooks_context)
 
 pytestmark = pytest.mark.gpu
 np.seterr(all='ignore')
@@ -394,14 +394,14 @@ def test_sic_512_atoms_control_arm_and_leapfrog():
 @pytest.mark.parametrize('what', ['pot36', 'sic_p1', 'sic_p9', 'pot36_control', 'sic_p1_ct'])
 def test_split_launches_equal_single_launches(what, monkeypatch):
     from mjhmc_amd import engine, _lib
-    ctx = engine.context(0)
+    ctxs = (engine.context(0), hooks_context(0))       # [0] the product library, [1] the test build with MJHMC_NO_SPLIT
     mode = {'pot36_control': _lib.MODE_CONTROL, 'sic_p1_ct': _lib.MODE_CTHMC}.get(what, _lib.MODE_MJHMC)   # the other sampler families
     what = what.split('_c')[0]
     if what == 'pot36':
         D, N, dtype = 36, 20000, 'float32'
         W, lognu = ref_init_weights(D, D)
         params = np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)])
-        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, params)
+        ens = [engine.DeviceEnergy(c, _lib.E_PRODUCT_OF_T, D, params) for c in ctxs]
         X0 = np.random.RandomState(3).randn(D, N)
         hp = (0.1, 6, 0.1)
     else:
@@ -409,10 +409,10 @@ def test_split_launches_equal_single_launches(what, monkeypatch):
         B, imgs, a0 = sic_problem(0, n_patches=P)
         D, dtype = P * 1024, 'bfloat16'
         params = np.concatenate([[float(P), 256.0, 1024.0, 0.01, 1.0], B.ravel(), imgs[:, :P].T.ravel()])
-        en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, D, params)
+        ens = [engine.DeviceEnergy(c, _lib.E_SPARSE_CODE, D, params) for c in ctxs]
         X0 = a0[:, None] + 0.2 * np.random.RandomState(4).randn(D, N)
         hp = (0.0625, 3, 0.1)
-    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype, mode=mode) for _ in range(2)]
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype, mode=mode) for en in ens]
     fields = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
     all_stats = [[], []]
     for n_it in (1, 3, 2):
@@ -441,7 +441,7 @@ def test_split_launches_failure_in_the_middle_of_a_call(what, poison, monkeypatc
     taken at the start of the call is put back and the call re-run on one stream).  The failure is placed with the
     library's test hook MJHMC_DEBUG_POISON=iteration:particle (that particle's kinetic energy reads NaN there)."""
     from mjhmc_amd import engine, _lib
-    ctx = engine.context(0)
+    ctx = hooks_context(0)                 # both samplers from the test build: only it can place a failure
     if what == 'pot36':
         D, N, dtype = 36, 20000, 'float32'
         W, lognu = ref_init_weights(D, D)

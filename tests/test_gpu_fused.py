@@ -6,19 +6,24 @@ non-finite rate (whole-batch abort, markov_jump_hmc.py:376-389)."""
 import numpy as np
 import pytest
 
-from tests.helpers import bits_equal
+from tests.helpers import bits_equal, hooks_context
 
 pytestmark = pytest.mark.gpu
 FIELDS = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
 
 
-def _pair(kind, D, N, mode, seed=5, params=None, scale=1.0, dtype='float64', dtype2=None):
+def _pair(kind, D, N, mode, seed=5, params=None, scale=1.0, dtype='float64', dtype2=None, libs='pp'):
+    """two samplers from the same inputs; libs: per sampler 'p' = the product library, 'h' = the test build (the only
+    one that reads the MJHMC_NO_* / MJHMC_DEBUG_POISON environment switches)"""
     from mjhmc_amd import engine, _lib
     rs = np.random.RandomState(D * 7 + N)
     X0 = rs.randn(D, N) * scale
-    ctx = engine.context(0)
-    en = engine.DeviceEnergy(ctx, getattr(_lib, kind), D, params if params is not None else [1.0])
-    return [engine.DeviceSampler(en, X0, seed=seed, mode=mode, dtype=dt) for dt in (dtype, dtype2 or dtype)], _lib
+    out = []
+    for which, dt in zip(libs, (dtype, dtype2 or dtype)):
+        ctx = engine.context(0) if which == 'p' else hooks_context(0)
+        en = engine.DeviceEnergy(ctx, getattr(_lib, kind), D, params if params is not None else [1.0])
+        out.append(engine.DeviceSampler(en, X0, seed=seed, mode=mode, dtype=dt))
+    return out, _lib
 
 
 def _same_state(a, b, _lib, fields=FIELDS):
@@ -167,7 +172,7 @@ def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
     and the per-iteration counters (the cold tallies now come from the list lengths) equal the in-kernel form."""
     from mjhmc_amd import _lib
     params = {'E_FUNNEL_NEAL': [3.0], 'E_ROUGH_WELL': [100.0, 4.0]}.get(kind, [1.0])
-    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params)
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, libs='ph')
     for s in (a, b):
         s.set_hparams(0.05, 7, 0.1, 1.0, 0.5)
     stats_a, stats_b = [], []
@@ -195,7 +200,7 @@ def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
     s_thr = np.sqrt(709.0 / (0.011 * D))
     mid = 0
     for scale in np.linspace(0.45, 0.9, 46) * s_thr:
-        (a, b), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale))
+        (a, b), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale), libs='hh')
         for s in (a, b):
             s.set_hparams(0.5, 5, 0.1, 1.0, 0.5)
         monkeypatch.delenv('MJHMC_NO_COMPACT', raising=False)
@@ -236,8 +241,9 @@ def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch, mode_n
     non-finite rate in either half ends the call like an unsplit one."""
     from mjhmc_amd import _lib
     params = list(10.0 ** np.linspace(-1, 0, D)) if kind == 'E_DIAG_GAUSS' else [1.0]
-    (a, b), _lib = _pair(kind, D, N, getattr(_lib, mode_name), params=params)
-    for s in (a, b):
+    (a, b), _lib = _pair(kind, D, N, getattr(_lib, mode_name), params=params, libs='ph')
+    (ha, hb), _lib = _pair(kind, D, N, getattr(_lib, mode_name), params=params, libs='hh')      # the pair that can be poisoned
+    for s in (a, b, ha, hb):
         s.set_hparams(0.1, 4, 0.1, 1.0, 0.5)
     for n_it in (6, 1, 70 if D == 512 else 3):                     # 70: two fused launches, the parts meet in between
         monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
@@ -250,6 +256,7 @@ def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch, mode_n
         _same_state(a, b, _lib)
     if mode_name == 'MODE_CONTROL':
         return                                                     # the discrete-time samplers have no rates to be non-finite
+    a, b = ha, hb                                                  # both from the test build: only it can place a failure
     for poison in ('0:7', '0:%d' % (N - 3)):                       # first half, second half
         monkeypatch.setenv('MJHMC_DEBUG_POISON', poison)
         sa, da = a.iterate(5)

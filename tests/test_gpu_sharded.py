@@ -210,3 +210,91 @@ print('ok')
     script.write_text(code % dict(root=ROOT, port=port))
     p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0, p.stdout.decode()[-4000:]
+
+
+@pytest.mark.parametrize('case', ['f64', 'f64_ragged', 'f32_pot', 'bf16_sic'])
+def test_gather_unpack_for_ranks_above_zero_on_one_gpu(case):
+    """The pack and unpack steps of the two sample all-gathers (csrc/comm.hip: ring_pack / ring_unpack, columns_pack /
+    columns_unpack) with the collective replaced by "all ranks' samplers live on this GPU" (test build of the library,
+    mjhmc_test_gather_*_local): three UNEVEN column shards (34 / 33 / 33), three ring slots -- the offsets of ranks
+    1 and 2, the padding to the largest shard, the time-major and the stacked layout and the rank-major column gather
+    with its scatter back into sample order, for float64, float32 and bfloat16 row pitches."""
+    import ctypes
+    import numpy as np
+    from mjhmc_amd import engine, _lib
+    from mjhmc_amd.parallel import ShardPlan
+    from tests.helpers import hooks_context, sic_problem, ref_init_weights
+    ctx = hooks_context(0)
+    lib = ctx.lib
+    N, n, world = 100, 3, 3
+    plan = ShardPlan(N, world)
+    assert plan.counts.tolist() == [34, 33, 33]
+    rs = np.random.RandomState(12)
+    if case in ('f64', 'f64_ragged'):
+        D = 24 if case == 'f64' else 5
+        en, X0, dtype, hp = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.0]), rs.randn(D, N), 'float64', (0.2, 4, 0.1)
+    elif case == 'f32_pot':
+        D = 36
+        W, lognu = ref_init_weights(D, D)
+        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)]))
+        X0, dtype, hp = rs.randn(D, N), 'float32', (0.1, 4, 0.1)
+    else:
+        D = 1024
+        B, imgs, a0 = sic_problem(0)
+        en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, D, np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), imgs[:, :1].T.ravel()]))
+        X0, dtype, hp = a0[:, None] + 0.1 * rs.randn(D, N), 'bfloat16', (0.0625, 3, 0.1)
+
+    def run(lo, hi):
+        s = engine.DeviceSampler(en, X0[:, lo:hi], seed=21, first_particle_id=lo, dtype=dtype)
+        s.set_hparams(hp[0], hp[1], hp[2], 1.0)
+        s.ring_alloc(n)
+        s.iterate(n, ring_slot0=0)
+        return s
+
+    shards = [run(*plan.span(r)) for r in range(world)]
+    handles = (ctypes.c_void_p * world)(*[s.handle for s in shards])
+    per_cat = [s.ring_read(0, n, stacked=False).reshape(D, n, -1) for s in shards]           # (D, n, N_r) per rank
+    want_cat = np.concatenate(per_cat, axis=2).reshape(D, n * N)
+    want_cube = np.concatenate([s.ring_read(0, n, stacked=True) for s in shards], axis=1)     # (D, N, n)
+    got = np.full((D, n * N), np.nan)
+    _lib.check(lib.mjhmc_test_gather_ring_local(handles, world, 0, n, 0, _lib.ptr(got)), lib)
+    assert np.array_equal(got, want_cat), 'time-major'
+    got = np.full((D, N, n), np.nan)
+    _lib.check(lib.mjhmc_test_gather_ring_local(handles, world, 0, n, 1, _lib.ptr(got)), lib)
+    assert np.array_equal(got, want_cube), 'stacked'
+    # a sub-range of slots
+    got = np.full((D, 2 * N), np.nan)
+    _lib.check(lib.mjhmc_test_gather_ring_local(handles, world, 1, 2, 0, _lib.ptr(got)), lib)
+    assert np.array_equal(got, want_cat.reshape(D, n, N)[:, 1:].reshape(D, 2 * N)), 'slots 1..2'
+
+    # resampled columns: global pool indices t * N + c -> owner, local pool index t * N_r + (c - lo), rank-major blocks,
+    # scattered back into sample order exactly as parallel.assemble_resample does
+    m = 257
+    sample_idx = np.sort(rs.randint(0, n * N, size=m))
+    t_of, col_of = np.divmod(sample_idx, N)
+    owner = plan.owner_of(col_of)
+    lists, counts = [], []
+    for r in range(world):
+        mine = np.nonzero(owner == r)[0]
+        lists.append(t_of[mine] * int(plan.counts[r]) + (col_of[mine] - int(plan.offsets[r])))
+        counts.append(mine.size)
+    idx = np.ascontiguousarray(np.concatenate(lists), dtype=np.int64)
+    cnt = np.ascontiguousarray(counts, dtype=np.int64)
+    flat = np.full((D, m), np.nan)
+    _lib.check(lib.mjhmc_test_gather_columns_local(handles, world, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(flat)), lib)
+    out = np.empty_like(flat)
+    out[:, np.argsort(owner, kind='stable')] = flat
+    assert np.array_equal(out, want_cat[:, sample_idx]), 'resampled columns'
+    # a rank that owns none of the picked columns
+    only0 = np.ascontiguousarray(lists[0][:5], dtype=np.int64)
+    flat = np.full((D, 5), np.nan)
+    _lib.check(lib.mjhmc_test_gather_columns_local(handles, world, _lib.ptr(only0), _lib.ptr(np.array([5, 0, 0], dtype=np.int64)),
+                                                   _lib.ptr(flat)), lib)
+    assert np.array_equal(flat, want_cat[:, sample_idx[owner == 0][:5]])
+
+    if dtype == 'float64':      # and the shards ARE the unsharded run's columns (counter RNG keyed by global particle id)
+        whole = run(0, N)
+        assert np.array_equal(want_cat, whole.ring_read(0, n, stacked=False))
+        whole.close()
+    for s in shards:
+        s.close()

@@ -23,12 +23,11 @@ for w in c2 c4 c5; do
 done
 # the one-iteration-per-launch form of C2 (the HBM-bound kernel the fused launch is measured against)
 case " $WL " in *" c2 "*)
-  export MJHMC_NO_FUSE=1
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_c2nofuse" -o c2nofuse -- python3 "$ROOT/bench.py" --workload c2 --no-cpu-baseline > "$OUT/bench_c2nofuse.json" 2> "$OUT/kt_c2nofuse.err"
+  # --steps 1: a call of ONE iteration is never fused (what every sampling_iteration() caller gets)
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_c2nofuse" -o c2nofuse -- python3 "$ROOT/bench.py" --workload c2 --steps 1 --no-cpu-baseline > "$OUT/bench_c2nofuse.json" 2> "$OUT/kt_c2nofuse.err"
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_c2nofuse_$c" -o c2nofuse -- python3 "$ROOT/bench.py" --workload c2 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_c2nofuse_$c.err"
-  done
-  unset MJHMC_NO_FUSE;;
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_c2nofuse_$c" -o c2nofuse -- python3 "$ROOT/bench.py" --workload c2 --steps 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_c2nofuse_$c.err"
+  done;;
 esac
 # keep what is small: drop raw per-dispatch traces over 8 MB
 find "$OUT" -name "*.csv" -size +8M -delete

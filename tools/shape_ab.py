@@ -1,3 +1,6 @@
+import os as _os
+# the environment A/B switches exist only in the test build of the library (csrc/Makefile: test_hooks)
+_os.environ.setdefault('MJHMC_HIP_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mjhmc_amd', 'lib', 'libmjhmc_hip_test.so'))
 import os, sys
 import numpy as np
 sys.path.insert(0, '/root/repo')

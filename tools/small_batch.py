@@ -1,4 +1,7 @@
 """Per-iteration time of small batches (the reference's typical sizes): fused vs one launch per iteration."""
+import os as _os
+# the environment A/B switches exist only in the test build of the library (csrc/Makefile: test_hooks)
+_os.environ.setdefault('MJHMC_HIP_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mjhmc_amd', 'lib', 'libmjhmc_hip_test.so'))
 import os
 import sys
 import time

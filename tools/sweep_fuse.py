@@ -1,5 +1,8 @@
 """Fused vs one-iteration-per-launch jump kernels over state-row sizes (A/B inside one process).
 usage: python tools/sweep_fuse.py"""
+import os as _os
+# the environment A/B switches exist only in the test build of the library (csrc/Makefile: test_hooks)
+_os.environ.setdefault('MJHMC_HIP_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mjhmc_amd', 'lib', 'libmjhmc_hip_test.so'))
 import os
 import sys
 
