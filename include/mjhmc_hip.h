@@ -65,7 +65,9 @@ typedef enum {
   MJHMC_E_FUNNEL_REF = 5,
   MJHMC_E_PRODUCT_OF_T = 6,
   MJHMC_E_SPARSE_CODE = 7,
-  MJHMC_E_USER_EXPR = 8      /* created by mjhmc_energy_create_expr only */
+  MJHMC_E_USER_EXPR = 8,     /* created by mjhmc_energy_create_expr only */
+  MJHMC_E_HOST = 9           /* no parameters: E and dE/dX are evaluated by the CALLER (opaque Python callables of
+                                LambdaDistribution, README.md:27-36); samplers of it are driven by mjhmc_traj_* below */
 } mjhmc_energy_kind;
 
 /* arithmetic type of state and force.  BF16: bfloat16 state in HBM and as MFMA operands, float32
@@ -185,6 +187,29 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
  * and its dwelling times in dwell slot ring_slot0+i (see mjhmc_ring_alloc). */
 int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                   const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
+
+/* ---- energies only the caller can evaluate (MJHMC_E_HOST) ----------------------------------------------------------
+ * LambdaDistribution(energy_func, energy_grad_func, init) takes two arbitrary Python callables (README.md:27-36,
+ * mjhmc/misc/distributions.py:198-251).  When they match no built-in functor and are not stated as C expressions,
+ * the sampler keeps everything on the device EXCEPT the two evaluations: the particle state (X, V, dE/dX, EX, EV, the
+ * inverse-L cache), the leapfrog updates in the reference's literal order (hmc_state.py:86-100), the jump decision,
+ * successor selection, momentum refresh, counters, dwelling times and the sample ring.  One sampling_iteration
+ * (markov_jump_hmc.py:355-415; :116-148 and :251-290 for the other sampler families) is
+ *     mjhmc_traj_begin(s, &n)                  n = N proposal columns (the L proposal of every particle) + n_cold columns
+ *                                              (the inverse-L proposal F L F of the cold-cache particles, MJHMC only)
+ *     X = mjhmc_traj_step(s, NULL, 0, X)       first step: uses the stored dE/dX
+ *     for every further leapfrog step:  g = energy_grad_func(X);  mjhmc_traj_step(s, g, 0, X)
+ *     g = energy_grad_func(X);                 mjhmc_traj_step(s, g, 1, NULL)       closing half kick
+ *     mjhmc_traj_finish(s, energy_func(X), ..., &stats)      decide + commit; stats->nonfinite as mjhmc_iterate reports it
+ * All matrices are (ndims, n) float64 C order, columns in the order above.  mjhmc_iterate refuses such samplers.
+ * mjhmc_host_set_energy: E (N) and dE/dX (D,N) of the CURRENT state -- after mjhmc_sampler_create and after every
+ * mjhmc_write of X (HMCState.__init__ evaluates both, hmc_state.py:30-38). */
+int mjhmc_host_set_energy(mjhmc_sampler* s, const double* E, const double* dEdX);
+int mjhmc_traj_begin(mjhmc_sampler* s, int64_t* n_cols);
+int mjhmc_traj_step(mjhmc_sampler* s, const double* grad, int last, double* X_out);
+/* replay_* as mjhmc_iterate's, for ONE iteration; ring_slot >= 0 records X and the dwelling times there */
+int mjhmc_traj_finish(mjhmc_sampler* s, const double* E, const double* replay_normal, const double* replay_exp,
+                      const double* replay_unif, int ring_slot, mjhmc_iter_stats* stats);
 
 /* Transaction support for multi-GPU runs: the reference aborts and retries the WHOLE batch when any
  * particle hits a non-finite rate (markov_jump_hmc.py:376-389).  With columns sharded over ranks a

@@ -14,7 +14,7 @@ KERNEL_HEADERS = os.path.join(_HERE, 'csrc')     # elementwise.hpp / philox.hpp:
 LIB_PATH = os.environ.get('MJHMC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmjhmc_hip.so')
 
 # enums of include/mjhmc_hip.h
-E_ISO_GAUSS, E_DIAG_GAUSS, E_ROUGH_WELL, E_MM_GAUSS, E_FUNNEL_NEAL, E_FUNNEL_REF, E_PRODUCT_OF_T, E_SPARSE_CODE, E_USER_EXPR = range(9)
+E_ISO_GAUSS, E_DIAG_GAUSS, E_ROUGH_WELL, E_MM_GAUSS, E_FUNNEL_NEAL, E_FUNNEL_REF, E_PRODUCT_OF_T, E_SPARSE_CODE, E_USER_EXPR, E_HOST = range(10)
 F64, F32, BF16 = 0, 1, 2
 MODE_MJHMC, MODE_CONTROL, MODE_CTHMC = 0, 1, 2
 F_X, F_V, F_EX, F_EV, F_DEDX, F_HFLF, F_CACHE, F_DWELL, F_TRANS = range(9)
@@ -62,6 +62,10 @@ PROTOTYPES = {
                                          ctypes.c_double]),
     'mjhmc_iterate': (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_int, ctypes.POINTER(IterStats),
                                      ctypes.POINTER(ctypes.c_int)]),
+    'mjhmc_host_set_energy': (ctypes.c_int, [_P, _P, _P]),
+    'mjhmc_traj_begin': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64)]),
+    'mjhmc_traj_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
+    'mjhmc_traj_finish': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(IterStats)]),
     'mjhmc_checkpoint': (ctypes.c_int, [_P]),
     'mjhmc_restore': (ctypes.c_int, [_P]),
     'mjhmc_rollback': (ctypes.c_int, [_P]),

@@ -470,6 +470,7 @@ static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout,
 }
 
 static int run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
+  if (s->en->is_host()) return host_run_eval(s, V, Vgen, EVout);  // E and dE/dX are the caller's (mjhmc_host_set_energy)
   if (s->en->is_pot()) return run_eval_pot(s, X, Gout, Eout, V, Vgen, EVout);
   if (s->en->is_sic()) return run_eval_sic(s, X, Gout, Eout, V, Vgen, EVout);
   return s->dtype == MJHMC_F64 ? run_eval_t<double>(s, X, Gout, Eout, V, Vgen, EVout)
@@ -672,6 +673,9 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
       }
       break;
     }
+    case MJHMC_E_HOST:  // no device form: the caller evaluates E and dE/dX (host_energy.hip)
+      if (nparams) rc = fail(MJHMC_ERR_INVALID, "HOST takes no parameters");
+      break;
     default:
       rc = fail(MJHMC_ERR_UNSUPPORTED, "energy kind not implemented in this build");
   }
@@ -766,6 +770,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   for (void* q : s->ick)
     if (q) (void)hipFree(q);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
+  host_traj_free(s);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -781,6 +786,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   if ((dtype == MJHMC_BF16) != e->is_sic())
     return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
+  if (e->is_host() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "host-evaluated energies run in float64");
   if (mode < MJHMC_MODE_MJHMC || mode > MJHMC_MODE_CTHMC) return fail(MJHMC_ERR_INVALID, "unknown sampler mode");
   if (first_particle_id < 0 || first_particle_id + nparticles > 0xFFFFFFFFLL)
     return fail(MJHMC_ERR_INVALID, "global particle ids must fit 32 bits");
@@ -819,7 +825,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       HIPCHK(hipMalloc(&s->Vbuf[i], mb));
       HIPCHK(hipMemsetAsync(s->Xbuf[i], 0, mb, s->stream));
       HIPCHK(hipMemsetAsync(s->Vbuf[i], 0, mb, s->stream));
-      if (e->is_pot()) {
+      if (e->is_pot() || (e->is_host() && i == 0)) {  // these keep dE/dX as part of the state, like HMCState.dEdX
         HIPCHK(hipMalloc(&s->Gbuf[i], mb));
         HIPCHK(hipMemsetAsync(s->Gbuf[i], 0, mb, s->stream));
       }
@@ -888,7 +894,7 @@ int mjhmc_checkpoint(mjhmc_sampler* s) {
   const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
   // ProductOfT keeps dE/dX of the current state (HMCState.dEdX) and the jump kernel does not recompute it: it is
   // part of the state a rollback must put back
-  const int nck = s->en->is_pot() ? 7 : 6;
+  const int nck = (s->en->is_pot() || s->en->is_host()) ? 7 : 6;
   const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
   const void* src[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
                         s->Gbuf[s->vcur]};
@@ -906,7 +912,7 @@ int mjhmc_restore(mjhmc_sampler* s) {
   if (!s->ck_valid) return fail(MJHMC_ERR_INVALID, "no checkpoint taken");
   HIPCHK(hipSetDevice(s->ctx->device));
   const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
-  const int nck = s->en->is_pot() ? 7 : 6;
+  const int nck = (s->en->is_pot() || s->en->is_host()) ? 7 : 6;
   const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
   s->Xcur = s->Xbuf[0];
   void* dst[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
@@ -1711,6 +1717,8 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   }
   if (ring_slot0 >= 0 && (!s->ring || ring_slot0 + n_iter > s->ring_slots))
     return fail(MJHMC_ERR_INVALID, "ring slots out of range (call mjhmc_ring_alloc)");
+  if (s->en->is_host())
+    return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy is driven step by step: mjhmc_traj_begin / _step / _finish");
   HIPCHK(hipSetDevice(s->ctx->device));
   return s->dtype == MJHMC_F64
              ? iterate_t<double>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done)
@@ -1744,7 +1752,7 @@ int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       TRY(ensure_stage(s, mat));
       const void* src = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
-      if (field == MJHMC_F_DEDX && s->en->is_pot()) {
+      if (field == MJHMC_F_DEDX && (s->en->is_pot() || s->en->is_host())) {
         src = s->Gbuf[s->vcur];
       } else if (field == MJHMC_F_DEDX && s->en->is_sic()) {
         if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, (size_t)s->Npad * s->D * sizeof(float)));
@@ -1801,6 +1809,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       s->undo_valid = false;
+      if (field == MJHMC_F_X) s->host_energy_set = false;  // MJHMC_E_HOST: E and dE/dX of the new X are the caller's to supply
       TRY(upload_matrix(s, (const double*)host_src, dst));
       TRY(run_eval(s, s->Xcur, s->Gbuf[s->vcur], s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
       HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
@@ -1975,6 +1984,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
   if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE evaluates with BF16 state");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
+  if (e->is_host()) return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy has no device evaluation: call the callables");
   HIPCHK(hipSetDevice(e->ctx->device));
   // a throw-away sampler-shaped workspace keeps one code path for re-tiling and evaluation
   mjhmc_sampler w;
@@ -2026,6 +2036,7 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
   if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
   if (e->is_pot() && dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T integrates in float32");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
+  if (e->is_host()) return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy has no device leapfrog operator");
   HIPCHK(hipSetDevice(e->ctx->device));
   mjhmc_sampler w;
   w.ctx = e->ctx;

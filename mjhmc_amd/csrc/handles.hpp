@@ -61,12 +61,16 @@ struct mjhmc_energy {
   bool is_dense() const { return is_pot() || is_sic(); }
   UserEnergy* user = nullptr;  // MJHMC_E_USER_EXPR: the hipRTC-built kernels of this energy
   bool is_user() const { return ep.kind == MJHMC_E_USER_EXPR; }
+  // MJHMC_E_HOST: E and dE/dX are evaluated by the caller (opaque Python callables), host_energy.hip
+  bool is_host() const { return ep.kind == MJHMC_E_HOST; }
 };
 
 struct Shape {
   int E, logG, pitch, CH, esize;
 };
 
+
+struct HostTraj;  // proposal workspace of a host-energy sampler (host_energy.hip)
 
 struct mjhmc_sampler {
   mjhmc_ctx* ctx;
@@ -127,6 +131,8 @@ struct mjhmc_sampler {
   double last_total_ms = 0, last_jump_ms = 0;
   int last_jump_launches = 0;
   bool timing_pending = false;
+  HostTraj* ht = nullptr;         // MJHMC_E_HOST: trajectory workspace (mjhmc_traj_*)
+  bool host_energy_set = false;   // MJHMC_E_HOST: EX and dE/dX of the current state are the caller's (mjhmc_host_set_energy)
 };
 
 inline size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s->sh.esize; }
@@ -134,6 +140,10 @@ inline size_t row_bytes(const mjhmc_sampler* s) { return (size_t)s->sh.pitch * s
 inline size_t ssize(const mjhmc_sampler* s) { return s->dtype == MJHMC_F64 ? 8 : 4; }
 inline size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_bytes(s); }
 
+
+// host_energy.hip
+void host_traj_free(mjhmc_sampler* s);
+int host_run_eval(mjhmc_sampler* s, const void* V, void* Vgen, void* EVout);
 
 // lanes-per-particle / elements-per-lane selection of the elementwise kernels for ndims = D
 int pick_shape(int D, int dtype, Shape* out);

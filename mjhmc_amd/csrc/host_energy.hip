@@ -1,0 +1,582 @@
+// LambdaDistribution(energy_func, energy_grad_func, init) with OPAQUE Python callables (README.md:27-36,
+// mjhmc/misc/distributions.py:198-251): energies the engine has no device form of -- neither a built-in functor nor
+// C expressions -- for example a dense quadratic form.  A Python callable cannot run in a kernel, so for these energies
+// E and dE/dX are evaluated by the CALLER, once per leapfrog step, and everything else stays on the device: the particle
+// state (X, V, dE/dX, EX, EV, the inverse-L cache), the leapfrog arithmetic in the reference's literal operation order
+// (hmc_state.py:86-100), the jump decision (rates, waiting times, first minimum: the same device functions the
+// elementwise kernels call), the successor selection, momentum refresh, counters, dwelling times and the sample ring.
+//
+// Protocol of one sampling iteration (include/mjhmc_hip.h: mjhmc_traj_*):
+//   traj_begin   proposal columns [0, N): (X, V, dE/dX) of every particle -- the L proposal; MJHMC: columns [N, N + n_cold):
+//                (X, -V, dE/dX) of the particles whose inverse-L cache is cold, in ascending particle order -- F L F is
+//                read only through H() (markov_jump_hmc.py:360,367)
+//   traj_step    [V += (-eps/2) g(caller's gradient at the X handed out last)]; unless last: V += (-eps/2) g; X += eps V; X -> caller
+//   traj_finish  caller's E at the end points -> H of the proposals -> decide -> commit (or, on a non-finite rate,
+//                nothing: the attempt is not committed, markov_jump_hmc.py:376-389)
+// It is slow by construction (a host round trip per leapfrog step); kernels here are plain one-thread-per-element loops.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "handles.hpp"
+
+struct HostTraj {
+  double* X = nullptr;  // [2 Npad][pitch] proposal columns
+  double* V = nullptr;
+  double* G = nullptr;
+  double* E = nullptr;   // [2 Npad] caller's energies at the end points
+  double* EVw = nullptr; // [2 Npad] kinetic energies of the end points
+  double* noise = nullptr;  // [Npad][pitch] replay normals
+  int* cold = nullptr;      // [Npad] cold particles, ascending
+  int* coldpos = nullptr;   // [Npad] position in `cold`, -1 when the cache is hot
+  int* kmove = nullptr;     // [Npad] decision of the attempt
+  double* dtmp = nullptr;   // [Npad] dwelling time of the attempt
+  double* hnew = nullptr;   // [3 Npad] EX, EV, H_flf of the successor
+  int n_cold = 0;
+  int64_t n_cols = 0;
+  int phase = 0;  // 0 idle, 1 begun (stepping), 2 last kick done
+  int steps = 0;
+};
+
+namespace {
+
+__global__ void hk_copy_rows(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ idx,
+                             int64_t nrows, int pitch, double sign) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows * pitch) return;
+  const int64_t r = i / pitch;
+  const int d = (int)(i - r * pitch);
+  const int64_t sr = idx ? idx[r] : r;
+  dst[i] = sign * src[sr * pitch + d];
+}
+
+// y += a * x, product rounded before the sum (the library is built with -ffp-contract=off): NumPy's V += c * g
+__global__ void hk_axpy(double* __restrict__ y, const double* __restrict__ x, double a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = y[i] + a * x[i];
+}
+
+// (D, n) float64 row-major in `stage`  ->  rows [n][pitch]
+__global__ void hk_to_rows(const double* __restrict__ stage, double* __restrict__ dst, int D, int64_t n, int pitch) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * D) return;
+  const int d = (int)(i / n);
+  const int64_t r = i - (int64_t)d * n;
+  dst[r * pitch + d] = stage[i];
+}
+
+// out[r] = sum_d V[r][d]^2 / 2 : one wavefront per row (np.sum(V * V, axis=0) / 2., hmc_state.py:74-78)
+__global__ void hk_kinetic(const double* __restrict__ V, double* __restrict__ out, int64_t nrows, int D, int pitch) {
+  const int64_t r = blockIdx.x;
+  if (r >= nrows) return;
+  double s = 0.0;
+  for (int d = threadIdx.x; d < D; d += 64) {
+    const double v = V[r * pitch + d];
+    s += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) out[r] = s / 2.0;
+}
+
+// tick-0 normals: the initial momentum (hmc_state.py:24-26), as mjhmc_eval_kernel draws it
+__global__ void hk_gen_v(double* __restrict__ V, RngKey key, int64_t first_pid, int64_t N, int D, int pitch) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int pairs = (D + 1) / 2;
+  if (i >= N * pairs) return;
+  const int64_t p = i / pairs;
+  const int pr = (int)(i - p * pairs);
+  double z0, z1;
+  normal_pair(key, (uint32_t)(first_pid + p), (uint32_t)pr, z0, z1);
+  V[p * pitch + 2 * pr] = z0;
+  if (2 * pr + 1 < D) V[p * pitch + 2 * pr + 1] = z1;
+}
+
+struct DecideArgs {
+  const double* EX;
+  const double* EV;
+  const double* Hflf;
+  const double* E;    // proposals
+  const double* EVw;
+  const int* coldpos;
+  int* kmove;
+  double* dtmp;
+  double* hnew;
+  const double* rexp;
+  const double* runif;
+  Control* ctl;
+  int64_t N, Npad, first_pid;
+  double p_r, p_flip;
+  int mode;
+  RngKey key;
+};
+
+// one thread per particle: the jump decision, with the device functions of the elementwise kernels (one lane per
+// particle: their serial forms)
+template <bool REPLAY>
+__global__ void hk_decide(const DecideArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.N) return;
+  const uint32_t pid = (uint32_t)(a.first_pid + p);
+  const double EX0 = a.EX[p], EV0 = a.EV[p];
+  const double H0 = EX0 + EV0;
+  const double EXL = a.E[p], EVL = a.EVw[p];
+  const double HL = EXL + EVL;
+  JumpArgs<double> ja;
+  ja.p_r = a.p_r;
+  ja.p_flip = a.p_flip;
+  ja.rexp = a.rexp;
+  ja.runif = a.runif;
+  ja.N = a.N;
+  LaneMap m;
+  m.j = 0;
+  m.G = 1;
+  m.D = 1;
+  m.CH = 1;
+  m.lane0 = 0;
+  m.wpp = 0;
+  int k = 0;
+  double dwell = 0.0;
+  bool bad = false;
+  double EXn = EX0, EVn = EV0, Hc = __builtin_nan("");
+  if (a.mode == kModeMJHMC) {
+    const double hc = a.Hflf[p];
+    double Hf = hc;
+    if (!(hc == hc)) {
+      const int j = a.coldpos[p];
+      Hf = a.E[a.N + j] + a.EVw[a.N + j];
+    }
+    decide<double, REPLAY>(ja, a.key, m, H0, HL, Hf, p, pid, k, dwell, bad);
+    if (k == 0) {  // L accepted: the pre-move state becomes the cached inverse-L state (markov_jump_hmc.py:399-404)
+      EXn = EXL;
+      EVn = EVL;
+      Hc = H0;
+    }
+  } else if (a.mode == kModeCT) {
+    decide_ct<double, REPLAY>(ja, a.key, m, H0, HL, p, pid, k, dwell, bad);
+    if (k == 0) {
+      EXn = EXL;
+      EVn = EVL;
+    }
+  } else {  // markov_jump_hmc.py:116-148
+    double uacc, uflip, ugate;
+    if constexpr (REPLAY) {
+      uacc = a.runif[p];
+      uflip = a.runif[a.N + p];
+      ugate = a.runif[2 * a.N];
+    } else {
+      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      const u32x4 f = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+      const u32x4 g = philox4x32_10(0xFFFFFFFFu, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+      uacc = u53(q.w2, q.w3);
+      uflip = u53(f.w0, f.w1);
+      ugate = u53(g.w2, g.w3);
+    }
+    const double dH = H0 - HL;
+    const bool accept = !(dH < 0.0) || (uacc < exp(dH));
+    const bool flip = uflip < a.p_flip;
+    const bool gate = ugate < a.p_r;
+    k = (accept ? 1 : 0) | (flip ? 2 : 0) | (gate ? 4 : 0);
+    if (accept) {
+      EXn = EXL;
+      EVn = EVL;
+    }
+  }
+  if (bad) a.ctl->failed = 1;
+  a.kmove[p] = k;
+  a.dtmp[p] = dwell;
+  a.hnew[p] = EXn;
+  a.hnew[a.Npad + p] = EVn;
+  a.hnew[2 * a.Npad + p] = Hc;
+}
+
+struct CommitArgs {
+  double* X;
+  double* V;
+  double* G;
+  double* EXs;
+  double* EVs;
+  double* Hflf;
+  const double* TX;
+  const double* TV;
+  const double* TG;
+  const int* kmove;
+  const double* dtmp;
+  const double* hnew;
+  const double* noise;  // replay normals (rows) or nullptr
+  double* dwell;
+  double* dwell_ring;
+  uint8_t* trans;
+  double* ring_slot;  // X snapshot target or nullptr
+  unsigned long long* stats;
+  int64_t N, Npad, first_pid;
+  int D, pitch, mode;
+  double r_keep, r_mix;
+  RngKey key;
+};
+
+// one wavefront per particle: successor state (markov_jump_hmc.py:399-410 / 138-141 / 277-286), momentum refresh
+// (hmc_state.py:121-129), bookkeeping
+template <bool REPLAY>
+__global__ void hk_commit(const CommitArgs a) {
+  const int64_t p = blockIdx.x;
+  if (p >= a.N) return;
+  const int lane = threadIdx.x;
+  const int km = a.kmove[p];
+  const uint32_t pid = (uint32_t)(a.first_pid + p);
+  double* x = a.X + p * a.pitch;
+  double* v = a.V + p * a.pitch;
+  double* g = a.G + p * a.pitch;
+  const double* tx = a.TX + p * a.pitch;
+  const double* tv = a.TV + p * a.pitch;
+  const double* tg = a.TG + p * a.pitch;
+  bool take = false, flip_old = false, flip_new = false, refresh = false;
+  int n0 = 0, n1 = 0, n2 = 0, n3 = 0, k = km;
+  if (a.mode == kModeMJHMC) {
+    take = km == 0;
+    flip_old = km == 1;
+    refresh = km == 2;
+    n0 = km == 0;
+    n1 = km == 1;
+    n2 = km == 2;
+  } else if (a.mode == kModeCT) {  // FL: leap, then flip (:258,278)
+    take = km == 0;
+    flip_new = km == 0;
+    flip_old = km == 1;
+    refresh = km == 2;
+    n0 = km == 0;
+    n1 = km == 1;
+    n2 = km == 2;
+  } else {
+    const bool accept = km & 1, flip = km & 2, gate = km & 4;
+    take = accept;
+    flip_new = accept != flip;   // accepted L F, then possibly F again
+    flip_old = !accept && flip;
+    refresh = gate;
+    k = km & 3;
+    n0 = k == 3;
+    n1 = k == 2;
+    n2 = gate;
+    n3 = k == 1;
+  }
+  double ev = 0.0;
+  for (int d = lane; d < a.D; d += 64) {
+    double xv = x[d], vv = v[d];
+    if (take) {
+      xv = tx[d];
+      vv = tv[d];
+      g[d] = tg[d];
+      x[d] = xv;
+      if (flip_new) vv = -vv;
+    } else if (flip_old) {
+      vv = -vv;
+    }
+    if (refresh) {
+      double z;
+      if constexpr (REPLAY) {
+        z = a.noise[p * a.pitch + d];
+      } else {
+        double z0, z1;
+        normal_pair(a.key, pid, (uint32_t)(d >> 1), z0, z1);
+        z = (d & 1) ? z1 : z0;
+      }
+      vv = vv * a.r_keep + z * a.r_mix;
+      ev += vv * vv;
+    }
+    v[d] = vv;
+    if (a.ring_slot) a.ring_slot[p * a.pitch + d] = xv;
+  }
+  if (refresh) {
+    for (int o = 32; o > 0; o >>= 1) ev += __shfl_xor(ev, o);
+  }
+  if (lane == 0) {
+    a.EXs[p] = a.hnew[p];
+    a.EVs[p] = refresh ? ev / 2.0 : a.hnew[a.Npad + p];
+    a.Hflf[p] = a.hnew[2 * a.Npad + p];
+    a.dwell[p] = a.dtmp[p];
+    if (a.dwell_ring) a.dwell_ring[p] = a.dtmp[p];
+    a.trans[p] = (uint8_t)k;
+    if (n0) atomicAdd(&a.stats[0], 1ull);
+    if (n1) atomicAdd(&a.stats[1], 1ull);
+    if (n2) atomicAdd(&a.stats[2], 1ull);
+    if (n3) atomicAdd(&a.stats[3], 1ull);
+  }
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+int upload_rows(mjhmc_sampler* s, const double* host, int64_t n, double* dst) {
+  TRY(ensure_stage(s, (size_t)s->D * n));
+  HIPCHK(hipMemcpyAsync(s->stage, host, (size_t)s->D * n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(hk_to_rows, grid1((int64_t)s->D * n), dim3(256), 0, s->stream, s->stage, dst, s->D, n, s->sh.pitch);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int need_traj(mjhmc_sampler* s) {
+  if (s->ht) return 0;
+  HostTraj* t = new HostTraj();
+  s->ht = t;
+  const size_t rows = (size_t)2 * s->Npad, mb = rows * s->sh.pitch * sizeof(double);
+  HIPCHK(hipMalloc((void**)&t->X, mb));
+  HIPCHK(hipMalloc((void**)&t->V, mb));
+  HIPCHK(hipMalloc((void**)&t->G, mb));
+  HIPCHK(hipMemsetAsync(t->X, 0, mb, s->stream));
+  HIPCHK(hipMemsetAsync(t->V, 0, mb, s->stream));
+  HIPCHK(hipMemsetAsync(t->G, 0, mb, s->stream));
+  HIPCHK(hipMalloc((void**)&t->E, rows * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&t->EVw, rows * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&t->cold, s->Npad * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t->coldpos, s->Npad * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t->kmove, s->Npad * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t->dtmp, s->Npad * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&t->hnew, (size_t)3 * s->Npad * sizeof(double)));
+  return 0;
+}
+
+int check_host(mjhmc_sampler* s) {
+  if (!s) return mjhmc_fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  if (!s->en->is_host()) return mjhmc_fail(MJHMC_ERR_INVALID, "the sampler's energy is not MJHMC_E_HOST");
+  return 0;
+}
+
+}  // namespace
+
+void host_traj_free(mjhmc_sampler* s) {
+  HostTraj* t = s->ht;
+  if (!t) return;
+  void* bufs[] = {t->X, t->V, t->G, t->E, t->EVw, t->noise, t->cold, t->coldpos, t->kmove, t->dtmp, t->hnew};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete t;
+  s->ht = nullptr;
+}
+
+// run_eval of api.hip for a host energy: the kinetic energy of V (or the tick-0 momentum) is device work, E and dE/dX
+// are the caller's (mjhmc_host_set_energy)
+int host_run_eval(mjhmc_sampler* s, const void* V, void* Vgen, void* EVout) {
+  if (Vgen) {
+    const RngKey key{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), 0u, 0u};
+    const int64_t n = s->N * ((s->D + 1) / 2);
+    hipLaunchKernelGGL(hk_gen_v, grid1(n), dim3(256), 0, s->stream, (double*)Vgen, key, s->first_pid, s->N, s->D, s->sh.pitch);
+    HIPCHK(hipGetLastError());
+    V = Vgen;
+  }
+  if (V && EVout) {
+    hipLaunchKernelGGL(hk_kinetic, dim3((unsigned)s->N), dim3(64), 0, s->stream, (const double*)V, (double*)EVout, s->N, s->D,
+                       s->sh.pitch);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" {
+
+int mjhmc_host_set_energy(mjhmc_sampler* s, const double* E, const double* dEdX) {
+  TRY(check_host(s));
+  if (!E || !dEdX) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipMemcpyAsync(s->EX[s->scur], E, (size_t)s->N * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  TRY(upload_rows(s, dEdX, s->N, (double*)s->Gbuf[s->vcur]));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->host_energy_set = true;
+  return 0;
+}
+
+int mjhmc_traj_begin(mjhmc_sampler* s, int64_t* n_cols) {
+  TRY(check_host(s));
+  if (!n_cols) return mjhmc_fail(MJHMC_ERR_INVALID, "n_cols is NULL");
+  if (!s->host_energy_set)
+    return mjhmc_fail(MJHMC_ERR_INVALID, "E and dE/dX of the current state are unknown: call mjhmc_host_set_energy first");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  TRY(need_traj(s));
+  HostTraj* t = s->ht;
+  const int pitch = s->sh.pitch;
+  t->n_cold = 0;
+  if (s->mode == MJHMC_MODE_MJHMC) {  // the cold list on the host, ascending (the order of NumPy's boolean mask)
+    std::vector<double> h((size_t)s->N);
+    HIPCHK(hipMemcpyAsync(h.data(), s->Hflf[s->scur], (size_t)s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    std::vector<int> cold, pos((size_t)s->N, -1);
+    for (int64_t p = 0; p < s->N; ++p)
+      if (!(h[(size_t)p] == h[(size_t)p])) {
+        pos[(size_t)p] = (int)cold.size();
+        cold.push_back((int)p);
+      }
+    t->n_cold = (int)cold.size();
+    if (t->n_cold) HIPCHK(hipMemcpyAsync(t->cold, cold.data(), cold.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(t->coldpos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));  // the vectors go out of scope
+  }
+  const double* X = (const double*)s->Xcur;
+  const double* V = (const double*)s->Vbuf[s->vcur];
+  const double* G = (const double*)s->Gbuf[s->vcur];
+  const int64_t n1 = s->N * pitch;
+  hipLaunchKernelGGL(hk_copy_rows, grid1(n1), dim3(256), 0, s->stream, t->X, X, (const int*)nullptr, s->N, pitch, 1.0);
+  hipLaunchKernelGGL(hk_copy_rows, grid1(n1), dim3(256), 0, s->stream, t->V, V, (const int*)nullptr, s->N, pitch, 1.0);
+  hipLaunchKernelGGL(hk_copy_rows, grid1(n1), dim3(256), 0, s->stream, t->G, G, (const int*)nullptr, s->N, pitch, 1.0);
+  if (t->n_cold) {
+    const int64_t n2 = (int64_t)t->n_cold * pitch;
+    const size_t off = (size_t)s->N * pitch;
+    hipLaunchKernelGGL(hk_copy_rows, grid1(n2), dim3(256), 0, s->stream, t->X + off, X, (const int*)t->cold, (int64_t)t->n_cold, pitch, 1.0);
+    hipLaunchKernelGGL(hk_copy_rows, grid1(n2), dim3(256), 0, s->stream, t->V + off, V, (const int*)t->cold, (int64_t)t->n_cold, pitch, -1.0);
+    hipLaunchKernelGGL(hk_copy_rows, grid1(n2), dim3(256), 0, s->stream, t->G + off, G, (const int*)t->cold, (int64_t)t->n_cold, pitch, 1.0);
+  }
+  HIPCHK(hipGetLastError());
+  t->n_cols = s->N + t->n_cold;
+  t->phase = 1;
+  t->steps = 0;
+  *n_cols = t->n_cols;
+  return 0;
+}
+
+int mjhmc_traj_step(mjhmc_sampler* s, const double* grad, int last, double* X_out) {
+  TRY(check_host(s));
+  HostTraj* t = s->ht;
+  if (!t || t->phase != 1) return mjhmc_fail(MJHMC_ERR_INVALID, "no trajectory in progress (mjhmc_traj_begin)");
+  if (!last && !X_out) return mjhmc_fail(MJHMC_ERR_INVALID, "X_out is NULL");
+  if (t->steps > 0 && !grad) return mjhmc_fail(MJHMC_ERR_INVALID, "the gradient at the positions handed out last is missing");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const int64_t n = t->n_cols, ne = n * s->sh.pitch;
+  const double c = -s->eps / 2.;  // hmc_state.py:88
+  if (grad) {  // closes the step the caller evaluated the gradient for
+    if (t->steps == 0) return mjhmc_fail(MJHMC_ERR_INVALID, "the first step uses the stored dE/dX: pass NULL");
+    TRY(upload_rows(s, grad, n, t->G));
+    hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->V, (const double*)t->G, c, ne);
+  }
+  if (!last) {
+    hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->V, (const double*)t->G, c, ne);
+    hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->X, (const double*)t->V, s->eps, ne);
+    HIPCHK(hipGetLastError());
+    t->steps += 1;
+    return download_cols(s, t->X, nullptr, n, X_out, (size_t)s->D * n, n, 1, 0, true);
+  }
+  HIPCHK(hipGetLastError());
+  t->phase = 2;
+  return 0;
+}
+
+int mjhmc_traj_finish(mjhmc_sampler* s, const double* E, const double* replay_normal, const double* replay_exp,
+                      const double* replay_unif, int ring_slot, mjhmc_iter_stats* st) {
+  TRY(check_host(s));
+  HostTraj* t = s->ht;
+  if (!t || t->phase != 2) return mjhmc_fail(MJHMC_ERR_INVALID, "the trajectory is not complete (mjhmc_traj_step with last != 0)");
+  if (!E) return mjhmc_fail(MJHMC_ERR_INVALID, "E is NULL");
+  if (ring_slot >= s->ring_slots) return mjhmc_fail(MJHMC_ERR_INVALID, "ring slot out of range");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const int64_t n = t->n_cols;
+  const int pitch = s->sh.pitch;
+  const bool replay = s->mode == MJHMC_MODE_CONTROL ? (replay_unif != nullptr) : (replay_exp != nullptr);
+  if (replay && !replay_normal) return mjhmc_fail(MJHMC_ERR_INVALID, "replay needs the normals as well");
+  HIPCHK(hipMemcpyAsync(t->E, E, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(hk_kinetic, dim3((unsigned)n), dim3(64), 0, s->stream, (const double*)t->V, t->EVw, n, s->D, pitch);
+  if (replay) {
+    if (!t->noise) HIPCHK(hipMalloc((void**)&t->noise, (size_t)s->Npad * pitch * sizeof(double)));
+    TRY(upload_rows(s, replay_normal, s->N, t->noise));
+    if (replay_exp) {
+      if (!s->rexp) HIPCHK(hipMalloc((void**)&s->rexp, 3 * s->N * sizeof(double)));
+      HIPCHK(hipMemcpyAsync(s->rexp, replay_exp, 3 * s->N * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+    if (replay_unif) {
+      if (!s->runif) HIPCHK(hipMalloc((void**)&s->runif, (2 * s->N + 1) * sizeof(double)));
+      HIPCHK(hipMemcpyAsync(s->runif, replay_unif, (2 * s->N + 1) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+  }
+  HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
+  HIPCHK(hipMemsetAsync(s->stats, 0, 4 * sizeof(long long), s->stream));
+  const uint64_t tick = s->tick;
+  const RngKey key{(uint32_t)(s->seed & 0xFFFFFFFFu), (uint32_t)(s->seed >> 32), (uint32_t)(tick & 0xFFFFFFFFu),
+                   (uint32_t)(tick >> 32)};
+  DecideArgs d;
+  d.EX = (const double*)s->EX[s->scur];
+  d.EV = (const double*)s->EV[s->scur];
+  d.Hflf = (const double*)s->Hflf[s->scur];
+  d.E = t->E;
+  d.EVw = t->EVw;
+  d.coldpos = t->coldpos;
+  d.kmove = t->kmove;
+  d.dtmp = t->dtmp;
+  d.hnew = t->hnew;
+  d.rexp = replay ? s->rexp : nullptr;
+  d.runif = replay ? s->runif : nullptr;
+  d.ctl = s->ctl;
+  d.N = s->N;
+  d.Npad = s->Npad;
+  d.first_pid = s->first_pid;
+  d.p_r = s->p_r;
+  d.p_flip = s->p_flip;
+  d.mode = s->mode;
+  d.key = key;
+  if (replay) hipLaunchKernelGGL(hk_decide<true>, grid1(s->N), dim3(256), 0, s->stream, d);
+  else hipLaunchKernelGGL(hk_decide<false>, grid1(s->N), dim3(256), 0, s->stream, d);
+  HIPCHK(hipGetLastError());
+  Control hc;
+  HIPCHK(hipMemcpyAsync(&hc, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->tick += 1;  // one tick per attempt, committed or not (a retry redraws)
+  t->phase = 0;
+  long long hs[4] = {0, 0, 0, 0};
+  if (!hc.failed) {
+    CommitArgs c;
+    c.X = (double*)s->Xcur;
+    c.V = (double*)s->Vbuf[s->vcur];
+    c.G = (double*)s->Gbuf[s->vcur];
+    c.EXs = (double*)s->EX[s->scur];
+    c.EVs = (double*)s->EV[s->scur];
+    c.Hflf = (double*)s->Hflf[s->scur];
+    c.TX = t->X;
+    c.TV = t->V;
+    c.TG = t->G;
+    c.kmove = t->kmove;
+    c.dtmp = t->dtmp;
+    c.hnew = t->hnew;
+    c.noise = replay ? t->noise : nullptr;
+    c.dwell = s->dwell;
+    c.dwell_ring = ring_slot >= 0 ? s->dwell_ring + (size_t)ring_slot * s->Npad : nullptr;
+    c.trans = s->trans;
+    c.ring_slot = ring_slot >= 0 ? (double*)((char*)s->ring + (size_t)ring_slot * mat_bytes(s)) : nullptr;
+    c.stats = (unsigned long long*)s->stats;
+    c.N = s->N;
+    c.Npad = s->Npad;
+    c.first_pid = s->first_pid;
+    c.D = s->D;
+    c.pitch = pitch;
+    c.mode = s->mode;
+    c.r_keep = std::sqrt(1.0 - s->beta);  // hmc_state.py:125-126
+    c.r_mix = std::sqrt(s->beta);
+    c.key = key;
+    if (replay) hipLaunchKernelGGL(hk_commit<true>, dim3((unsigned)s->N), dim3(64), 0, s->stream, c);
+    else hipLaunchKernelGGL(hk_commit<false>, dim3((unsigned)s->N), dim3(64), 0, s->stream, c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hs, s->stats, sizeof(hs), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+  }
+  s->undo_valid = false;
+  if (st) {
+    std::memset(st, 0, sizeof(*st));
+    if (s->mode == MJHMC_MODE_MJHMC) {
+      st->l = hs[0];
+      st->f = hs[1];
+      st->r = hs[2];
+      st->n_cold = t->n_cold;
+    } else if (s->mode == MJHMC_MODE_CTHMC) {
+      st->fl = hs[0];
+      st->f = hs[1];
+      st->r = hs[2];
+    } else {
+      st->l = hs[0];
+      st->f = hs[1];
+      st->r = hs[2];
+      st->fl = hs[3];
+    }
+    st->E_evals = n;
+    st->dEdX_evals = (int64_t)t->steps * n;
+    st->nonfinite = hc.failed ? 1 : 0;
+    st->L_used = t->steps;
+    st->eps_used = s->eps;
+  }
+  return 0;
+}
+
+}  // extern "C"

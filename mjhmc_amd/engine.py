@@ -90,10 +90,33 @@ class DeviceEnergy(object):
         self.handle = h
         return self
 
+    @classmethod
+    def host(cls, ctx, ndims, energy_func, energy_grad_func):
+        """An energy only the caller can evaluate (MJHMC_E_HOST, include/mjhmc_hip.h): two opaque Python callables
+        ``energy_func(X (D,n)) -> (n,) or (1,n)`` and ``energy_grad_func(X) -> (D,n)`` (README.md:27-36).  Samplers of it
+        (HostEnergySampler) keep the state and the whole jump process on the device and call back once per leapfrog step."""
+        self = cls(ctx, _lib.E_HOST, ndims, np.zeros(0))
+        self.energy_func, self.energy_grad_func = energy_func, energy_grad_func
+        return self
+
+    def host_E(self, X):
+        e = np.asarray(self.energy_func(X), dtype=np.float64).reshape(-1)
+        if e.shape != (X.shape[1],):
+            raise ValueError('energy_func must return one energy per column: got %r for X %r' % (e.shape, X.shape))
+        return np.ascontiguousarray(e)
+
+    def host_grad(self, X):
+        g = np.asarray(self.energy_grad_func(X), dtype=np.float64)
+        if g.shape != X.shape:
+            raise ValueError('energy_grad_func must return an array shaped like X: got %r for X %r' % (g.shape, X.shape))
+        return np.ascontiguousarray(g)
+
     def eval(self, X, want_E=True, want_grad=True, dtype='float64'):
         X = as_f64(X)
         if X.ndim != 2 or X.shape[0] != self.ndims:
             raise ValueError('X must be (ndims, n)')
+        if self.kind == _lib.E_HOST:                       # the callables ARE the energy
+            return (self.host_E(X) if want_E else None), (self.host_grad(X) if want_grad else None)
         n = X.shape[1]
         E = np.empty(n) if want_E else None
         G = np.empty((self.ndims, n)) if want_grad else None
@@ -104,6 +127,8 @@ class DeviceEnergy(object):
     def leapfrog(self, X, V, epsilon, n_steps, want_grad=True, dtype='float64'):
         """n_steps leapfrog steps from (X, V) in the reference's operation order (hmc_state.py:86-100).
         Returns (X', V', EX' (n,), EV' (n,), dEdX' or None)."""
+        if self.kind == _lib.E_HOST:
+            raise NotImplementedError('the stand-alone leapfrog operator needs a device energy; opaque callables have none')
         X = as_f64(X)
         V = as_f64(V, X.shape)
         if X.ndim != 2 or X.shape[0] != self.ndims:
@@ -257,3 +282,72 @@ class DeviceSampler(object):
             self.close()
         except Exception:
             pass
+
+
+class HostEnergySampler(DeviceSampler):
+    """DeviceSampler for an energy given as opaque Python callables (DeviceEnergy.host): ``iterate`` has the contract of
+    the device's mjhmc_iterate, but every sampling iteration is driven from here through mjhmc_traj_begin / _step /
+    _finish -- the callables are called once per leapfrog step on the proposal columns (N + n_cold of them), everything
+    else (state, leapfrog arithmetic, jump decision, commit, counters, sample ring) runs on the device."""
+
+    def __init__(self, energy, Xinit, Vinit=None, seed=0, first_particle_id=0, dtype='float64', mode=_lib.MODE_MJHMC):
+        if dtype_code(dtype) != _lib.F64:
+            raise ValueError('host-evaluated energies run in float64')
+        super(HostEnergySampler, self).__init__(energy, Xinit, Vinit, seed, first_particle_id, 'float64', mode)
+        self._L = 5
+        self._set_energy(as_f64(Xinit))
+
+    def _set_energy(self, X):
+        E, G = self.energy.host_E(X), self.energy.host_grad(X)
+        check(self.lib.mjhmc_host_set_energy(self.handle, ptr(E), ptr(G)), self.lib)
+
+    def set_hparams(self, epsilon, num_leapfrog_steps, p_r, beta=1.0, p_flip=0.5):
+        super(HostEnergySampler, self).set_hparams(epsilon, num_leapfrog_steps, p_r, beta, p_flip)
+        self._L = int(num_leapfrog_steps)
+
+    def write(self, field, arr):
+        super(HostEnergySampler, self).write(field, arr)
+        if field == _lib.F_X:                              # HMCState(X): E and dE/dX of the new positions (hmc_state.py:30-38)
+            self._set_energy(as_f64(arr, (self.ndims, self.nparticles)))
+
+    def _attempt(self, rn, re, ru, ring_slot):
+        n = ctypes.c_int64()
+        check(self.lib.mjhmc_traj_begin(self.handle, ctypes.byref(n)), self.lib)
+        X = np.empty((self.ndims, n.value))
+        g = None
+        for _ in range(self._L):
+            check(self.lib.mjhmc_traj_step(self.handle, ptr(g), 0, ptr(X)), self.lib)
+            g = self.energy.host_grad(X)
+        check(self.lib.mjhmc_traj_step(self.handle, ptr(g), 1, None), self.lib)
+        if self._L == 0:                                   # no step was taken: the end points are the start points
+            X0 = self.read(_lib.F_X)
+            X = np.concatenate([X0, X0[:, np.isnan(self.read(_lib.F_HFLF))]], axis=1)[:, :n.value]
+        E = self.energy.host_E(X)
+        st = _lib.IterStats()
+        check(self.lib.mjhmc_traj_finish(self.handle, ptr(E), ptr(rn), ptr(re), ptr(ru), int(ring_slot), ctypes.byref(st)),
+              self.lib)
+        return st
+
+    def iterate(self, n_iter=1, replay_normal=None, replay_exp=None, replay_unif=None, ring_slot0=-1):
+        D, N = self.ndims, self.nparticles
+        rn = None if replay_normal is None else as_f64(replay_normal).reshape(n_iter, D, N)
+        re = None if replay_exp is None else as_f64(replay_exp).reshape(n_iter, 3, N)
+        ru = None if replay_unif is None else as_f64(replay_unif).reshape(n_iter, 2 * N + 1)
+        stats, done = [], 0
+        for i in range(n_iter):
+            st = self._attempt(None if rn is None else np.ascontiguousarray(rn[i]), None if re is None else np.ascontiguousarray(re[i]),
+                               None if ru is None else np.ascontiguousarray(ru[i]), ring_slot0 + i if ring_slot0 >= 0 else -1)
+            stats.append(st)
+            if st.nonfinite:
+                break
+            done += 1
+        return stats, done
+
+    def last_timing(self):
+        return dict(total_ms=0.0, jump_kernel_ms=0.0, n_jump_launches=0)
+
+
+def make_sampler(energy, *args, **kwargs):
+    """DeviceSampler, or HostEnergySampler for an energy only the caller can evaluate."""
+    cls = HostEnergySampler if energy.kind == _lib.E_HOST else DeviceSampler
+    return cls(energy, *args, **kwargs)

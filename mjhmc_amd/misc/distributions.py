@@ -47,6 +47,8 @@ class Distribution(object):
             kind, params = self.device_energy()
             if kind == _lib.E_USER_EXPR:                   # params = (energy_expr, grad_expr, float64 parameters, stats, energy0_expr)
                 self._dev = engine.DeviceEnergy.from_expr(engine.context(device), self.ndims, *params)
+            elif kind == _lib.E_HOST:                      # params = (energy_func, energy_grad_func): opaque callables
+                self._dev = engine.DeviceEnergy.host(engine.context(device), self.ndims, *params)
             else:
                 self._dev = engine.DeviceEnergy(engine.context(device), kind, self.ndims, params)
         return self._dev
@@ -138,10 +140,14 @@ class LambdaDistribution(Distribution):
 
     The reference's class ignores its callables (it evaluates a non-existent ``self.J``); the README contract is
     what is kept: ``energy_func`` / ``energy_grad_func`` define the distribution and ``init`` is the initial state.
-    Python callables cannot run inside a GPU kernel, so the device needs the same functions in one of three forms:
+    Python callables cannot run inside a GPU kernel, so the callables reach the device in one of four ways:
 
-    * nothing: the callables are probed on a few points and matched against the built-in elementwise families
-      (isotropic Gaussian with any sigma -- the README example -- and diagonal Gaussians);
+    * nothing, and the callables are recognised: they are probed on a few points and matched against the built-in
+      elementwise families (isotropic Gaussian with any sigma -- the README example -- and diagonal Gaussians);
+    * nothing, and they are NOT recognised (any opaque pair of callables, e.g. a dense quadratic form): the sampler
+      keeps the state and the whole jump process on the device and calls ``energy_grad_func`` back once per leapfrog
+      step and ``energy_func`` once per iteration (MJHMC_E_HOST, mjhmc_traj_* of include/mjhmc_hip.h) -- correct for
+      any callables, slow by construction (a host round trip per leapfrog step);
     * ``device_expr=(energy_expr, grad_expr)`` [+ ``device_params``]: C expressions of one coordinate for a separable
       energy ``E(x) = sum_d energy_expr(x_d)``, ``dE/dx_d = grad_expr(x_d)`` with ``x`` the coordinate, ``d`` its
       index and ``p[k]`` the float64 ``device_params``; the engine's kernels are compiled around them with hipRTC
@@ -172,15 +178,15 @@ class LambdaDistribution(Distribution):
                                                 stats, None if e0 is None else str(e0)))
         elif self._functor is None:
             self._functor = _recognise(energy_func, energy_grad_func, self.init.shape[0])
+            if self._functor is None and energy_func is not None and energy_grad_func is not None:
+                self._functor = (_lib.E_HOST, (energy_func, energy_grad_func))       # opaque callables: host call-backs
             self._checked = True
         super(LambdaDistribution, self).__init__(ndims=self.init.shape[0], nbatch=self.init.shape[1])
 
     def device_energy(self):
         if self._functor is None:
-            raise NotImplementedError(
-                'LambdaDistribution %r: the callables match no built-in device energy.  State them for the device as '
-                'device_expr=("<E of one coordinate x>", "<dE/dx>") (separable energies, compiled with hipRTC), pass '
-                'device_energy=(kind, params), or subclass Distribution' % self.name)
+            raise NotImplementedError('LambdaDistribution %r needs energy_func and energy_grad_func (or device_expr= / '
+                                      'device_energy=)' % self.name)
         return self._functor
 
     def bind(self, device=0):

@@ -77,10 +77,10 @@ class HMCBase(object):
             first, stop = self._plan.span(self._comm.rank)
             X0 = X0[:, first:stop]
             V0 = None if V0 is None else V0[:, first:stop]
-        self._dev = engine.DeviceSampler(distribution.bind(self._device), np.ascontiguousarray(X0), Vinit=V0,
-                                         seed=self.seed, first_particle_id=first,
-                                         dtype=self._dtype or getattr(distribution, 'state_dtype', 'float64'),
-                                         mode=self._mode)
+        self._dev = engine.make_sampler(distribution.bind(self._device), np.ascontiguousarray(X0), Vinit=V0,
+                                        seed=self.seed, first_particle_id=first,
+                                        dtype=self._dtype or getattr(distribution, 'state_dtype', 'float64'),
+                                        mode=self._mode)
         # HMCState.__init__ evaluates E and dEdX once on every particle (hmc_state.py:28-39)
         distribution.E_count += self.nbatch
         distribution.dEdX_count += self.nbatch

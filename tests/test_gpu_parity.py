@@ -527,9 +527,107 @@ def test_lambda_distribution_checks_the_expressions_against_the_callables():
     with pytest.raises(_lib.EngineError) as info:
         MarkovJumpHMC(distribution=broken, epsilon=0.1, beta=0.1)
     assert "undeclared identifier 'q'" in str(info.value)
-    opaque = LambdaDistribution(energy_func=E, energy_grad_func=dEdX, init=X0)        # matches no built-in family
-    with pytest.raises(NotImplementedError):
-        MarkovJumpHMC(distribution=opaque, epsilon=0.1, beta=0.1)
+    with pytest.raises(NotImplementedError):                                          # no callables, no expressions
+        MarkovJumpHMC(distribution=LambdaDistribution(init=X0), epsilon=0.1, beta=0.1)
+
+
+def _dense_quadratic(D, seed):
+    """E(x) = x^T A x / 2 with a DENSE symmetric positive definite A: not separable, not expressible through a few
+    per-particle statistics -- only the callables can evaluate it."""
+    rs = np.random.RandomState(seed)
+    Q = rs.randn(D, D)
+    A = Q.dot(Q.T) / D + 0.5 * np.eye(D)
+
+    def E(X):
+        return 0.5 * np.sum(X * A.dot(X), axis=0).reshape((1, -1))
+
+    def dEdX(X):
+        return A.dot(X)
+    return A, E, dEdX
+
+
+@pytest.mark.parametrize('cls_name,D,N', [('MarkovJumpHMC', 6, 90), ('MarkovJumpHMC', 37, 70), ('ControlHMC', 9, 64),
+                                          ('HMC', 5, 40), ('ContinuousTimeHMC', 12, 50)])
+def test_lambda_distribution_with_opaque_callables(cls_name, D, N):
+    """README.md:27-36: LambdaDistribution(energy_func, energy_grad_func, init) with callables the engine has no device
+    form of (a dense quadratic form).  State, leapfrog arithmetic, jump decision, commit and counters stay on the
+    device; the gradient comes from the Python callable once per leapfrog step (mjhmc_traj_*).  The run must follow
+    the oracle on the same callables and the same Philox streams: transitions exact, state to 1e-10, the evaluation
+    counters exact."""
+    from mjhmc_amd import _lib
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import LambdaDistribution
+    A, E, dEdX = _dense_quadratic(D, D + N)
+    X0 = np.random.RandomState(N).randn(D, N) * 1.5
+    calls = {'E': 0, 'g': 0}
+
+    def E_c(X):
+        calls['E'] += 1
+        return E(X)
+
+    def g_c(X):
+        calls['g'] += 1
+        return dEdX(X)
+    d = LambdaDistribution(energy_func=E_c, energy_grad_func=g_c, init=X0)            # two callables and nothing else
+    assert d.device_energy()[0] == _lib.E_HOST
+    kw = dict(epsilon=0.25, beta=0.4, num_leapfrog_steps=5)
+    extra = dict(resample=False) if cls_name not in ('ControlHMC', 'HMC') else {}
+    s = getattr(M, cls_name)(distribution=d, seed=19, **kw, **extra)
+    en = orc.LambdaEnergy(E, dEdX)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(19, np.arange(N)), **kw, **extra)
+    assert close(s.state.V, o.state.V) and close(s.state.EX, o.state.EX) and close(s.state.dEdX, o.state.dEdX)
+    for t in range(10):
+        before = dict(calls)
+        s.sampling_iteration()
+        o.sampling_iteration()
+        assert calls['g'] - before['g'] == 5 and calls['E'] - before['E'] == 1       # one call-back per leapfrog step
+        if cls_name == 'MarkovJumpHMC':
+            assert np.array_equal(s._dev.read(8), o.last_transition), t
+            assert np.array_equal(s.state.cache_active, o.state.shadow_ok), t
+        if cls_name in ('MarkovJumpHMC', 'ContinuousTimeHMC'):
+            assert close(s.dwelling_times, o.dwelling_times), t
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), t
+        assert close(s.state.EX, o.state.EX) and close(s.state.EV, o.state.EV) and close(s.state.dEdX, o.state.dEdX), t
+        assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count), t
+        assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count), t
+    assert s.r_count + s.f_count + s.l_count + s.fl_count > 0
+    # sample(): the device ring and, for the jump processes, the dwell-time resampling
+    np.random.seed(3)
+    out = s.sample(6)
+    np.random.seed(3)
+    want = o.sample(6)
+    assert out.shape == want.shape and close(out, want)
+    # HMCState assignment re-evaluates E and dE/dX of the new positions through the callables
+    st = s.state.copy()
+    st.X = st.X * 0.5
+    s.state = st
+    assert close(s.state.EX, E(st.X)) and close(s.state.dEdX, dEdX(st.X))
+
+
+def test_opaque_callables_meet_a_non_finite_rate_like_the_reference():
+    """markov_jump_hmc.py:376-389 with host-evaluated energies: a huge step makes exp(H0 - H1) overflow for some
+    particle, the attempt is not committed, epsilon is halved / L doubled until it goes through -- as the oracle does."""
+    import contextlib
+    import io
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import LambdaDistribution
+    D, N = 5, 64
+    A, E, dEdX = _dense_quadratic(D, 1)
+    X0 = np.random.RandomState(2).randn(D, N) * 30.0
+    d = LambdaDistribution(energy_func=E, energy_grad_func=dEdX, init=X0)
+    kw = dict(epsilon=1.3, beta=0.3, num_leapfrog_steps=4)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        s = MarkovJumpHMC(distribution=d, seed=5, resample=False, **kw)
+        o = orc.MarkovJumpHMC(orc.LambdaEnergy(E, dEdX), X0, rng=orc.PhiloxRNG(5, np.arange(N)), resample=False, **kw)
+        for t in range(3):
+            s.sampling_iteration()
+            o.sampling_iteration()
+            assert np.array_equal(s._dev.read(8), o.last_transition), t
+            assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), t
+    assert buf.getvalue().count('doubling back') > 0
+    assert (s.epsilon, s.num_leapfrog_steps) == (1.3, 4)
+    assert (s.l_count, s.f_count, s.r_count) == (o.l_count, o.f_count, o.r_count)
 
 
 def test_lambda_distribution_recognises_a_diagonal_gaussian():

@@ -1,0 +1,176 @@
+"""GPU, counter RNG: distribution-level checks of the energies the reference builds symbolically (ProductOfT: Theano,
+Funnel: TensorFlow 0.x) and that therefore cannot be pinned by running the reference.  These tests use NO oracle and no
+restated algebra -- only facts that follow from the reference's own formulas:
+
+ProductOfT, E = sum_j (nu_j + 1)/2 * log(1 + ((W^T x + b)_j / nu_j)^2)   (mjhmc/misc/distributions.py:420-433).
+    With W invertible the change of variables y = W^T x + b has a constant Jacobian and the density factorises:
+    p(y_j) ~ (1 + y_j^2 / nu_j^2)^(-(nu_j + 1)/2), i.e.  y_j / sqrt(nu_j) ~ Student-t(nu_j), independently.
+    (The reference's own gen_init_X, :437-445, draws Student-t(nu_j) for y_j itself and maps through inv(W), not
+    inv(W^T): it is not the law of this energy; the negative controls below show the test tells the two apart.)
+Funnel as documented, x_0 ~ N(0, scale^2), x_k | x_0 ~ N(0, e^{x_0})   (mjhmc/misc/tf_distributions.py:143-147,171-173):
+    x_0 / scale ~ N(0, 1) and x_k * e^{-x_0 / 2} ~ N(0, 1).
+
+A sampler whose energy, accept / jump rule or momentum refresh were wrong would not leave these laws invariant: chains
+started FROM the law must still follow it after many iterations, and chains started away from it must arrive there.
+The GRADIENT is not tested by that (any reversible volume-preserving proposal keeps the law): it is tested by energy
+conservation -- the leapfrog error |H(L z) - H(z)| must be small and shrink 4x when epsilon halves -- with a negative
+control in which the gradient is deliberately doubled.
+
+Thresholds: Kolmogorov-Smirnov p-values at fixed seeds, Bonferroni-style: every coordinate's p > 1e-4 (36 or 10
+coordinates: a correct sampler fails a run with probability < 0.4 %), negative controls p < 1e-6 (median over the
+coordinates).
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+from tests.helpers import ref_init_weights
+
+pytestmark = pytest.mark.gpu
+P_MIN = 1e-4
+
+
+def _pot_model(D=36):
+    W, lognu = ref_init_weights(D, D)          # the reference recipe (search/MJHMC_poe_36/mjhmc_objective.py:15-23)
+    W = (W + np.eye(D)).astype(np.float32).astype(np.float64)
+    assert np.linalg.cond(W) < 1e4
+    nu = np.exp(lognu).astype(np.float32).astype(np.float64)
+    return W, lognu, nu
+
+
+def _pot_exact_draw(W, nu, N, rs):
+    t = np.stack([rs.standard_t(nu[j], size=N) for j in range(len(nu))])
+    return np.linalg.solve(W.T, t * np.sqrt(nu)[:, None])       # x = W^-T y, b = 0
+
+
+def _pot_pvalues(W, nu, X, df_scale=1.0, y_scale=None):
+    y = W.T.dot(X)
+    t = y / (np.sqrt(nu)[:, None] if y_scale is None else y_scale)
+    return np.array([stats.kstest(t[j], 't', args=(nu[j] * df_scale,)).pvalue for j in range(len(nu))])
+
+
+def _run(cls_name, dist, n_iter, **kw):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    s = getattr(M, cls_name)(distribution=dist, **kw)
+    for _ in range(n_iter):
+        s.sampling_iteration()
+    return s
+
+
+@pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC'])
+def test_product_of_t_stationary_law(cls_name):
+    from mjhmc_amd.misc.distributions import ProductOfT
+    D, N = 36, 8192
+    W, lognu, nu = _pot_model(D)
+    rs = np.random.RandomState(2026)
+    X_exact = _pot_exact_draw(W, nu, N, rs)
+    assert _pot_pvalues(W, nu, X_exact).min() > P_MIN                         # the test statistic on an exact draw
+
+    def dist_from(X0):
+        class Fixed(ProductOfT):
+            def gen_init_X(self):
+                self.Xinit = X0
+        return Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W)
+
+    kw = dict(epsilon=0.25, beta=0.3, num_leapfrog_steps=6, seed=11)
+    # (1) started from the law: still the law after 80 iterations, and the chain has moved
+    s = _run(cls_name, dist_from(X_exact), 80, **kw)
+    X = s.state.X
+    moved = np.mean(np.abs(X - X_exact) > 1e-3)
+    assert moved > 0.9, moved
+    p = _pot_pvalues(W, nu, X)
+    assert p.min() > P_MIN, ('stationarity', p.min(), int(p.argmin()))
+    # (2) started away from the law (every particle at half its distance from the mode): arrives there.  (Student-t
+    # tails with 2.1 < nu < 4.1 fill slowly under Gaussian momenta: 2000 iterations.)
+    X_bad = 0.5 * X_exact
+    assert np.median(_pot_pvalues(W, nu, X_bad)) < 1e-6
+    s2 = _run(cls_name, dist_from(X_bad), 2000, **kw)
+    p2 = _pot_pvalues(W, nu, s2.state.X)
+    assert p2.min() > P_MIN, ('convergence', p2.min(), int(p2.argmin()))
+    # negative controls: the same samples against laws that are NOT this energy's
+    assert np.median(_pot_pvalues(W, nu, X, y_scale=nu[:, None])) < 1e-6       # u_j = y_j / nu_j itself taken for Student-t(nu_j)
+    assert np.median(_pot_pvalues(W, nu, X, y_scale=1.0)) < 1e-6               # y_j ~ t(nu_j) unscaled (the reference's gen_init_X)
+    acc = s.l_count / float(80 * N) if cls_name == 'MarkovJumpHMC' else s.fl_count / float(80 * N)
+    assert acc > 0.5, acc                                                     # the trajectories are accepted: E and dE/dX agree
+
+
+def _funnel_exact_draw(D, N, scale, rs):
+    x0 = scale * rs.randn(1, N)
+    return np.vstack([x0, np.exp(x0 / 2.) * rs.randn(D - 1, N)])
+
+
+def _funnel_pvalues(X, scale):
+    z = np.vstack([X[:1] / scale, X[1:] * np.exp(-X[:1] / 2.)])
+    return np.array([stats.kstest(z[k], 'norm').pvalue for k in range(X.shape[0])])
+
+
+@pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC'])
+def test_funnel_stationary_law(cls_name):
+    from mjhmc_amd.misc.distributions import Funnel
+    D, N, scale = 10, 8192, 1.5
+    rs = np.random.RandomState(77)
+    X_exact = _funnel_exact_draw(D, N, scale, rs)
+    assert _funnel_pvalues(X_exact, scale).min() > P_MIN
+
+    def dist_from(X0):
+        class Fixed(Funnel):
+            def gen_init_X(self):
+                self.Xinit = X0
+        return Fixed(scale=scale, nbatch=N, ndims=D)
+
+    kw = dict(epsilon=0.15, beta=0.3, num_leapfrog_steps=8, seed=5)
+    s = _run(cls_name, dist_from(X_exact), 120, **kw)
+    X = s.state.X
+    assert np.mean(np.abs(X - X_exact) > 1e-6) > 0.9
+    p = _funnel_pvalues(X, scale)
+    assert p.min() > P_MIN, ('stationarity', p.min(), int(p.argmin()))
+    # started from a standard normal in every coordinate (x_0 too narrow, x_k not scaled by the neck): arrives at the law
+    X_bad = rs.randn(D, N)
+    assert _funnel_pvalues(X_bad, scale).min() < 1e-6
+    s2 = _run(cls_name, dist_from(X_bad), 1500, **kw)
+    p2 = _funnel_pvalues(s2.state.X, scale)
+    assert p2.min() > P_MIN, ('convergence', p2.min(), int(p2.argmin()))
+    # negative controls: the same samples against a funnel of another scale, and against no neck at all
+    assert _funnel_pvalues(X, 2.0 * scale)[0] < 1e-6
+    assert np.median([stats.kstest(X[k], 'norm').pvalue for k in range(1, D)]) < 1e-6
+
+
+def _energy_error(en, X, V, eps, L, dtype):
+    E0, _ = en.eval(X, want_E=True, want_grad=False, dtype=dtype)
+    Xo, Vo, EX, EV, _ = en.leapfrog(X, V, eps, L, want_grad=False, dtype=dtype)
+    H0 = E0 + 0.5 * np.sum(V ** 2, axis=0)
+    return np.abs((EX + EV) - H0)
+
+
+def test_leapfrog_conserves_energy_second_order_and_a_wrong_gradient_does_not():
+    """dE/dX is the gradient of E: the leapfrog error |H(L z) - H(z)| is O(eps^2) -- small, and 4x smaller at eps / 2 --
+    for ProductOfT (float32 matrix cores), the funnel (float64) and the funnel stated as coupled expressions; the SAME
+    expressions with the gradient doubled (negative control) break both properties."""
+    from mjhmc_amd import engine, _lib
+    ctx = engine.context(0)
+    rs = np.random.RandomState(3)
+    # ProductOfT
+    D, N = 36, 4096
+    W, lognu, nu = _pot_model(D)
+    en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], W.ravel(), nu, np.zeros(D)]))
+    X, V = _pot_exact_draw(W, nu, N, rs), rs.randn(D, N)
+    e1 = np.median(_energy_error(en, X, V, 0.1, 8, 'float32'))
+    e2 = np.median(_energy_error(en, X, V, 0.05, 16, 'float32'))
+    assert e1 < 0.05 and 3.0 < e1 / e2 < 5.0, (e1, e2)
+    # Funnel: built-in functor and the coupled-expression form, right and (negative control) wrong
+    D, N, scale = 10, 4096, 1.5
+    X, V = _funnel_exact_draw(D, N, scale, rs), rs.randn(D, N)
+    good = dict(stats=['d == 0 ? x : 0.0', 'd == 0 ? 0.0 : x*x'], energy='0.0',
+                energy0='S[0]*S[0]/(2*p[0]*p[0]) + 0.5*exp(-S[0])*S[1] + 0.5*(p[1]-1)*S[0]',
+                grad='d == 0 ? x/(p[0]*p[0]) - 0.5*exp(-x)*S[1] + 0.5*(p[1]-1) : x*exp(-S[0])')
+    wrong = dict(good, grad='2.0*(' + good['grad'] + ')')
+    builtin = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, D, [scale])
+    expr = engine.DeviceEnergy.from_expr(ctx, D, good['energy'], good['grad'], [scale, float(D)], good['stats'], good['energy0'])
+    bad = engine.DeviceEnergy.from_expr(ctx, D, wrong['energy'], wrong['grad'], [scale, float(D)], wrong['stats'], wrong['energy0'])
+    for e in (builtin, expr):
+        a = np.median(_energy_error(e, X, V, 0.05, 8, 'float64'))
+        b = np.median(_energy_error(e, X, V, 0.025, 16, 'float64'))
+        assert a < 0.02 and 3.5 < a / b < 4.5, (a, b)
+    a = np.median(_energy_error(bad, X, V, 0.05, 8, 'float64'))
+    b = np.median(_energy_error(bad, X, V, 0.025, 16, 'float64'))
+    assert a > 0.05 and not (3.0 < a / b < 5.0), (a, b)
