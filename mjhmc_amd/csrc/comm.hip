@@ -255,9 +255,7 @@ static int ring_unpack(mjhmc_sampler* s, const char* recv, size_t blk, int world
     }
     off += cnt;
   }
-  HIPCHK(hipMemcpyAsync(host_out, s->stage, elems * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  return 0;
+  return copy_to_host(s, s->stage, host_out, elems * sizeof(double));
 }
 
 // pack of the column gather: the n_local ring columns this rank owns (local pool indices slot * N + column)
@@ -291,9 +289,7 @@ static int columns_unpack(mjhmc_sampler* s, const char* recv, size_t blk, int wo
     if (cnt) TRY(download_cols(s, recv + (size_t)r * blk, nullptr, cnt, host_out, elems, total, 1, off, false));
     off += cnt;
   }
-  HIPCHK(hipMemcpyAsync(host_out, s->stage, elems * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  return 0;
+  return copy_to_host(s, s->stage, host_out, elems * sizeof(double));
 }
 
 static int shard_totals(const int64_t* counts, int world, int64_t least, int64_t* total, int64_t* mx) {

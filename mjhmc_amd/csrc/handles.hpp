@@ -131,6 +131,8 @@ struct mjhmc_sampler {
   double last_total_ms = 0, last_jump_ms = 0;
   int last_jump_launches = 0;
   bool timing_pending = false;
+  void* pipe_pin[2] = {nullptr, nullptr};       // pinned double buffer of the pipelined device -> host copies (copy_to_host)
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};
   HostTraj* ht = nullptr;         // MJHMC_E_HOST: trajectory workspace (mjhmc_traj_*)
   bool host_energy_set = false;   // MJHMC_E_HOST: EX and dE/dX of the current state are the caller's (mjhmc_host_set_energy)
 };
@@ -153,3 +155,6 @@ int ensure_stage(mjhmc_sampler* s, size_t elems);
 // row(k) = dev_idx ? dev_idx[k] : k; copy_out: then copy host_elems doubles of the stage to `host` and synchronise
 int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_idx, int64_t ncols, double* host,
                   size_t host_elems, int64_t rs, int64_t cs, int64_t off, bool copy_out);
+// device -> pageable host memory on the sampler's stream, synchronised; big blocks go through a pinned double buffer
+// with the host-side copy spread over several threads
+int copy_to_host(mjhmc_sampler* s, const void* dev_src, void* host_dst, size_t bytes);

@@ -450,6 +450,7 @@ int mjhmc_traj_step(mjhmc_sampler* s, const double* grad, int last, double* X_ou
     hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->X, (const double*)t->V, s->eps, ne);
     HIPCHK(hipGetLastError());
     t->steps += 1;
+    TRY(ensure_stage(s, (size_t)s->D * n));
     return download_cols(s, t->X, nullptr, n, X_out, (size_t)s->D * n, n, 1, 0, true);
   }
   HIPCHK(hipGetLastError());

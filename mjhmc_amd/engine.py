@@ -212,9 +212,12 @@ class DeviceSampler(object):
     def advance_tick(self, n=1):
         check(self.lib.mjhmc_advance_tick(self.handle, int(n)), self.lib)
 
-    def read(self, field):
+    def read(self, field, out=None):
         D, N = self.ndims, self.nparticles
-        if field in (_lib.F_X, _lib.F_V, _lib.F_DEDX):
+        if out is not None:
+            if field not in (_lib.F_X, _lib.F_V, _lib.F_DEDX) or out.shape != (D, N) or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError('out: a C-contiguous float64 (ndims, nparticles) array for a matrix field')
+        elif field in (_lib.F_X, _lib.F_V, _lib.F_DEDX):
             out = np.empty((D, N))
         elif field in (_lib.F_CACHE, _lib.F_TRANS):
             out = np.empty(N, dtype=np.uint8)
@@ -246,9 +249,14 @@ class DeviceSampler(object):
             check(self.lib.mjhmc_ring_gather(self.handle, ptr(idx), idx.size, ptr(out)), self.lib)
         return out
 
-    def ring_read(self, slot0, n, stacked=False):
+    def ring_read(self, slot0, n, stacked=False, out=None):
+        """``out``: a caller-owned C-contiguous float64 array of the result's shape to fill (a ring of samples is GBs: a
+        fresh array per call costs an allocation and a page fault per 4 KiB of it)."""
         shape = (self.ndims, self.nparticles, n) if stacked else (self.ndims, n * self.nparticles)
-        out = np.empty(shape)
+        if out is None:
+            out = np.empty(shape)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError('out must be a C-contiguous float64 array of shape %r' % (shape,))
         check(self.lib.mjhmc_ring_read(self.handle, int(slot0), int(n), 1 if stacked else 0, ptr(out)), self.lib)
         return out
 

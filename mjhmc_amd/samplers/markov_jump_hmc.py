@@ -253,20 +253,21 @@ class HMCBase(object):
             self._iter_evals = []
             self._one(-1, replay)
 
-    def _stack(self, n_samples, preserve_order):
+    def _stack(self, n_samples, preserve_order, out=None):
         if self._comm is not None and self._comm.on_device:
             # the one data-path collective: device rings all-gathered over RCCL, re-tiled on the receiving GPU
             return self._comm.allgather_ring(self._dev, 0, n_samples, bool(preserve_order), self._plan.counts)
-        local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order))
+        local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order), out=out if self._comm is None else None)
         if self._comm is None:
             return local
         from ..parallel import assemble_stacked
         return assemble_stacked(self._comm, self._plan, local, n_samples, bool(preserve_order))
 
-    def sample(self, n_samples=1000, preserve_order=False, replay=None):
-        """markov_jump_hmc.py:150-173."""
+    def sample(self, n_samples=1000, preserve_order=False, replay=None, out=None):
+        """markov_jump_hmc.py:150-173.  ``out`` (extension): a preallocated C-contiguous float64 array of the result's
+        shape, (ndims, n_samples * nbatch) or (ndims, nbatch, n_samples), filled and returned instead of a fresh one."""
         self._record(n_samples, replay)
-        return self._stack(n_samples, preserve_order)
+        return self._stack(n_samples, preserve_order, out)
 
     def _record(self, n_samples, replay=None):
         """Run n_samples iterations, snapshotting X after each into device ring slots [0, n_samples)."""
@@ -357,9 +358,10 @@ class ContinuousTimeHMC(HMCBase):
         super(ContinuousTimeHMC, self).burn_in()
         self._read_dwell()
 
-    def sample(self, n_samples=1000, preserve_order=False, num_steps=None, replay=None):
+    def sample(self, n_samples=1000, preserve_order=False, num_steps=None, replay=None, out=None):
         """markov_jump_hmc.py:293-338.  ``num_steps`` is accepted as an alias of ``n_samples``
-        (the README calls ``sample(num_steps=10)``, README.md:36)."""
+        (the README calls ``sample(num_steps=10)``, README.md:36).  ``out`` (extension, ``resample=False`` only): a
+        preallocated array to fill, see HMCBase.sample."""
         if num_steps is not None:
             n_samples = num_steps
         if self.resample:
@@ -384,7 +386,7 @@ class ContinuousTimeHMC(HMCBase):
             self._last_resample_idx = sample_idx
             return self._dev.ring_gather(sample_idx)
         self._record(n_samples, replay)
-        return self._stack(n_samples, preserve_order)
+        return self._stack(n_samples, preserve_order, out)
 
     def _record(self, n_samples, replay=None):
         super(ContinuousTimeHMC, self)._record(n_samples, replay)
