@@ -76,7 +76,16 @@ int pick_shape(int D, int dtype, Shape* out) {
       C = 8;
       G = pow2ceil((s.CH + 7) / 8);
     }
-    if (G > 64) return fail(MJHMC_ERR_UNSUPPORTED, "ndims too large for the register-resident jump kernel");
+    if (G > 64) {
+      // more dims than 64 lanes x 16 elements hold: float64 samplers of the built-in elementwise energies take the
+      // multi-pass path (host_energy.hip: state in HBM between the substeps); others have no such form
+      if (dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "ndims too large for the register-resident float32 kernels (float64 has a multi-pass path)");
+      s.E = 0;
+      s.logG = 0;
+      s.wide = true;
+      *out = s;
+      return 0;
+    }
   }
   s.E = C * VEC;
   s.logG = ilog2(G);
@@ -395,16 +404,21 @@ static int upload_matrix(mjhmc_sampler* s, const double* host, void* dst) {
 constexpr size_t kPipeChunk = (size_t)32 << 20;
 constexpr int kCopyThreads = 8;
 
+static int ensure_pipe(mjhmc_sampler* s) {
+  for (int i = 0; i < 2; ++i) {
+    if (!s->pipe_pin[i]) HIPCHK(hipHostMalloc(&s->pipe_pin[i], kPipeChunk, hipHostMallocDefault));
+    if (!s->pipe_ev[i]) HIPCHK(hipEventCreateWithFlags(&s->pipe_ev[i], hipEventDisableTiming));
+  }
+  return 0;
+}
+
 int copy_to_host(mjhmc_sampler* s, const void* dev_src, void* host_dst, size_t bytes) {
   if (bytes < 2 * kPipeChunk) {
     HIPCHK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
   }
-  for (int i = 0; i < 2; ++i) {
-    if (!s->pipe_pin[i]) HIPCHK(hipHostMalloc(&s->pipe_pin[i], kPipeChunk, hipHostMallocDefault));
-    if (!s->pipe_ev[i]) HIPCHK(hipEventCreateWithFlags(&s->pipe_ev[i], hipEventDisableTiming));
-  }
+  TRY(ensure_pipe(s));
   const size_t nchunk = (bytes + kPipeChunk - 1) / kPipeChunk;
   auto issue = [&](size_t k) -> int {
     const size_t off = k * kPipeChunk, len = std::min(kPipeChunk, bytes - off);
@@ -513,7 +527,8 @@ static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout,
 }
 
 static int run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
-  if (s->en->is_host()) return host_run_eval(s, V, Vgen, EVout);  // E and dE/dX are the caller's (mjhmc_host_set_energy)
+  // host energies (E and dE/dX are the caller's, mjhmc_host_set_energy) and wide rows (multi-pass device kernels)
+  if (s->en->is_host() || s->sh.wide) return wide_run_eval(s, X, Gout, Eout, V, Vgen, EVout);
   if (s->en->is_pot()) return run_eval_pot(s, X, Gout, Eout, V, Vgen, EVout);
   if (s->en->is_sic()) return run_eval_sic(s, X, Gout, Eout, V, Vgen, EVout);
   return s->dtype == MJHMC_F64 ? run_eval_t<double>(s, X, Gout, Eout, V, Vgen, EVout)
@@ -593,20 +608,17 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         rc = fail(MJHMC_ERR_INVALID, "DIAG_GAUSS expects ndims diagonal entries");
         break;
       }
-      if (ndims > kParamPad) {
-        rc = fail(MJHMC_ERR_UNSUPPORTED, "ndims too large");
-        break;
-      }
-      std::vector<double> h64(kParamPad, 0.0);
-      std::vector<float> h32(kParamPad, 0.f);
+      const size_t npad = std::max<size_t>(kParamPad, (size_t)ndims);  // (more than kParamPad dims: the multi-pass path)
+      std::vector<double> h64(npad, 0.0);
+      std::vector<float> h32(npad, 0.f);
       for (int i = 0; i < ndims; ++i) {
         h64[i] = params[i];
         h32[i] = (float)params[i];
       }
-      if (hipMalloc(&e->dev64, kParamPad * sizeof(double)) != hipSuccess ||
-          hipMalloc(&e->dev32, kParamPad * sizeof(float)) != hipSuccess ||
-          hipMemcpy(e->dev64, h64.data(), kParamPad * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-          hipMemcpy(e->dev32, h32.data(), kParamPad * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      if (hipMalloc(&e->dev64, npad * sizeof(double)) != hipSuccess ||
+          hipMalloc(&e->dev32, npad * sizeof(float)) != hipSuccess ||
+          hipMemcpy(e->dev64, h64.data(), npad * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(e->dev32, h32.data(), npad * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(MJHMC_ERR_HIP, "allocating DIAG_GAUSS parameters failed");
       e->ep.dev_f64 = e->dev64;
       e->ep.dev_f32 = e->dev32;
@@ -872,7 +884,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       HIPCHK(hipMalloc(&s->Vbuf[i], mb));
       HIPCHK(hipMemsetAsync(s->Xbuf[i], 0, mb, s->stream));
       HIPCHK(hipMemsetAsync(s->Vbuf[i], 0, mb, s->stream));
-      if (e->is_pot() || (e->is_host() && i == 0)) {  // these keep dE/dX as part of the state, like HMCState.dEdX
+      if (e->is_pot() || ((e->is_host() || s->sh.wide) && i == 0)) {  // these keep dE/dX as part of the state, like HMCState.dEdX
         HIPCHK(hipMalloc(&s->Gbuf[i], mb));
         HIPCHK(hipMemsetAsync(s->Gbuf[i], 0, mb, s->stream));
       }
@@ -898,6 +910,8 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
     HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
     HIPCHK(hipEventCreate(&s->ev_total[0]));
     HIPCHK(hipEventCreate(&s->ev_total[1]));
+    // a state matrix big enough for the pipelined host copies: their pinned buffers now, not inside the first read
+    if ((size_t)s->D * s->N * sizeof(double) >= 2 * kPipeChunk) TRY(ensure_pipe(s));
     // everything mjhmc_iterate needs is created here, so a timed call never allocates
     s->stats_cap = 1024;
     HIPCHK(hipMalloc((void**)&s->stats, (size_t)s->stats_cap * 4 * sizeof(long long)));
@@ -941,7 +955,7 @@ int mjhmc_checkpoint(mjhmc_sampler* s) {
   const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
   // ProductOfT keeps dE/dX of the current state (HMCState.dEdX) and the jump kernel does not recompute it: it is
   // part of the state a rollback must put back
-  const int nck = (s->en->is_pot() || s->en->is_host()) ? 7 : 6;
+  const int nck = (s->en->is_pot() || s->en->is_host() || s->sh.wide) ? 7 : 6;
   const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
   const void* src[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
                         s->Gbuf[s->vcur]};
@@ -959,7 +973,7 @@ int mjhmc_restore(mjhmc_sampler* s) {
   if (!s->ck_valid) return fail(MJHMC_ERR_INVALID, "no checkpoint taken");
   HIPCHK(hipSetDevice(s->ctx->device));
   const size_t mb = mat_bytes(s), vb = (size_t)s->Npad * ssize(s), db = (size_t)s->Npad * sizeof(double);
-  const int nck = (s->en->is_pot() || s->en->is_host()) ? 7 : 6;
+  const int nck = (s->en->is_pot() || s->en->is_host() || s->sh.wide) ? 7 : 6;
   const size_t sizes[7] = {mb, mb, vb, vb, vb, db, mb};
   s->Xcur = s->Xbuf[0];
   void* dst[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
@@ -1767,6 +1781,7 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   if (s->en->is_host())
     return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy is driven step by step: mjhmc_traj_begin / _step / _finish");
   HIPCHK(hipSetDevice(s->ctx->device));
+  if (s->sh.wide) return multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
   return s->dtype == MJHMC_F64
              ? iterate_t<double>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done)
              : iterate_t<float>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
@@ -1799,7 +1814,7 @@ int mjhmc_read(mjhmc_sampler* s, int field, void* host_dst, size_t nbytes) {
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       TRY(ensure_stage(s, mat));
       const void* src = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
-      if (field == MJHMC_F_DEDX && (s->en->is_pot() || s->en->is_host())) {
+      if (field == MJHMC_F_DEDX && (s->en->is_pot() || s->en->is_host() || s->sh.wide)) {
         src = s->Gbuf[s->vcur];
       } else if (field == MJHMC_F_DEDX && s->en->is_sic()) {
         if (!s->scratch) HIPCHK(hipMalloc(&s->scratch, (size_t)s->Npad * s->D * sizeof(float)));
@@ -2148,6 +2163,9 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
       a.chalf = (float)(-eps / 2.);
       sic_launch_leap(a, e->sic_model(), w.stream);
       HIPCHK(hipGetLastError());
+    } else if (w.sh.wide) {
+      TRY(wide_leapfrog(&w, (const double*)buf[0], (const double*)buf[1], (double*)buf[2], (double*)buf[3], (double*)buf[4],
+                        (double*)buf[5], (double*)buf[6], eps, n_steps));
     } else if (dtype == MJHMC_F64) {
       TRY(leap_t<double>(w, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], eps, n_steps));
     } else {

@@ -67,6 +67,9 @@ struct mjhmc_energy {
 
 struct Shape {
   int E, logG, pitch, CH, esize;
+  // ndims beyond the register-resident elementwise kernels (> 64 lanes x 16 elements): the sampler runs the multi-pass
+  // path of host_energy.hip, state in HBM between the substeps (float64, built-in elementwise energies)
+  bool wide = false;
 };
 
 
@@ -146,6 +149,11 @@ inline size_t mat_bytes(const mjhmc_sampler* s) { return (size_t)s->Npad * row_b
 // host_energy.hip
 void host_traj_free(mjhmc_sampler* s);
 int host_run_eval(mjhmc_sampler* s, const void* V, void* Vgen, void* EVout);
+int wide_run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout);
+int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
+                      const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
+int wide_leapfrog(mjhmc_sampler* w, const double* X, const double* V, double* Xo, double* Vo, double* G, double* EX,
+                  double* EV, double eps, int n_steps);
 
 // lanes-per-particle / elements-per-lane selection of the elementwise kernels for ndims = D
 int pick_shape(int D, int dtype, Shape* out);

@@ -14,6 +14,12 @@
 //   traj_finish  caller's E at the end points -> H of the proposals -> decide -> commit (or, on a non-finite rate,
 //                nothing: the attempt is not committed, markov_jump_hmc.py:376-389)
 // It is slow by construction (a host round trip per leapfrog step); kernels here are plain one-thread-per-element loops.
+//
+// The same multi-pass machinery, with the state in HBM between the substeps and the gradient from a device kernel
+// instead of a call-back, serves the built-in elementwise energies when ndims exceeds what the register-resident jump
+// kernel holds (> 1024 float64 dims: 64 lanes x 16 elements): `wide` samplers (Shape::wide), driven by
+// multipass_iterate from mjhmc_iterate.  The reference accepts any ndims (hmc_state.py:86-100 are plain array
+// operations); so does the engine, on this slower path.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -39,6 +45,10 @@ struct HostTraj {
   int phase = 0;  // 0 idle, 1 begun (stepping), 2 last kick done
   int steps = 0;
 };
+
+int traj_begin_impl(mjhmc_sampler* s, int64_t* n_cols);
+int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double* replay_exp, const double* replay_unif,
+                     int ring_slot, mjhmc_iter_stats* st);
 
 namespace {
 
@@ -91,6 +101,93 @@ __global__ void hk_gen_v(double* __restrict__ V, RngKey key, int64_t first_pid, 
   normal_pair(key, (uint32_t)(first_pid + p), (uint32_t)pr, z0, z1);
   V[p * pitch + 2 * pr] = z0;
   if (2 * pr + 1 < D) V[p * pitch + 2 * pr + 1] = z1;
+}
+
+// ---- built-in elementwise energies on rows of any length: one wavefront per row, E and dE/dX in one pass ------------
+struct WideEnergy {
+  int kind;
+  double a, b, c;        // the functor constants of elementwise.hpp (IsoGaussF, RoughWellF, MMGaussF, FunnelNealF, FunnelRefF)
+  const double* jdiag;   // DIAG_GAUSS
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void hk_energy_grad(const double* __restrict__ X, double* __restrict__ G, double* __restrict__ E, int64_t nrows,
+                               int D, int pitch, const WideEnergy w) {
+  const int64_t r = blockIdx.x;
+  if (r >= nrows) return;
+  const int lane = threadIdx.x;
+  const double* x = X + r * pitch;
+  double* g = G ? G + r * pitch : nullptr;
+  const double pi = 3.141592653589793;
+  double e = 0.0;
+  switch (w.kind) {
+    case MJHMC_E_ISO_GAUSS: {  // a = 1/sigma^2, b = 1/(2 sigma^2)
+      double s = 0.0;
+      for (int d = lane; d < D; d += 64) {
+        const double xv = x[d];
+        s = __builtin_fma(xv, xv, s);
+        if (g) g[d] = xv * w.a;
+      }
+      e = wave_sum(s) * w.b;
+      break;
+    }
+    case MJHMC_E_DIAG_GAUSS: {
+      double s = 0.0;
+      for (int d = lane; d < D; d += 64) {
+        const double xv = x[d], j = w.jdiag[d];
+        s = __builtin_fma(xv, j * xv, s);
+        if (g) g[d] = j * xv;
+      }
+      e = wave_sum(s) / 2.0;
+      break;
+    }
+    case MJHMC_E_ROUGH_WELL: {  // a = s1^2, b = 2 s1^2, c = s2 (distributions.py:295-304, operation order as written there)
+      double s = 0.0;
+      for (int d = lane; d < D; d += 64) {
+        const double xv = x[d];
+        s += (xv * xv) / w.b + cos(xv * 2.0 * pi / w.c);
+        if (g) g[d] = xv / w.a + -sin(xv * 2.0 * pi / w.c) * 2.0 * pi / w.c;
+      }
+      e = wave_sum(s);
+      break;
+    }
+    case MJHMC_E_MM_GAUSS: {  // a = 2 * separation (distributions.py:323-335)
+      const double common = exp(4.0 * w.a * x[0]);
+      double sa = 0.0, sb = 0.0;
+      for (int d = lane; d < D; d += 64) {
+        const double xv = x[d], sp = d == 0 ? w.a : 0.0;
+        sa += (xv + sp) * (xv + sp);
+        sb += (xv - sp) * (xv - sp);
+        if (g) g[d] = (2.0 * ((xv - sp) * common + sp + xv)) / (common + 1.0);
+      }
+      e = -log(exp(-wave_sum(sa)) + exp(-wave_sum(sb)));
+      break;
+    }
+    case MJHMC_E_FUNNEL_NEAL:    // a = 1/scale^2, b = (D-1)/2 (tf_distributions.py:143-147)
+    case MJHMC_E_FUNNEL_REF: {   // a = 1/scale^2, b = D-1     (tf_distributions.py:157-165, as coded)
+      const double x0 = x[0], ex = exp(-x0);
+      double s = 0.0;
+      for (int d = lane; d < D; d += 64) {
+        const double xv = x[d];
+        if (d > 0) s = __builtin_fma(xv, xv, s);
+      }
+      const double S = wave_sum(s);
+      const bool neal = w.kind == MJHMC_E_FUNNEL_NEAL;
+      if (g)
+        for (int d = lane; d < D; d += 64) {
+          if (d == 0) g[0] = neal ? (x0 * w.a - 0.5 * ex * S + w.b) : (-2.0 * w.b * x0 * w.a + ex * S);
+          else g[d] = neal ? x[d] * ex : -2.0 * x[d] * ex;
+        }
+      e = neal ? (x0 * x0 * (0.5 * w.a) + 0.5 * ex * S + w.b * x0) : (-(w.b * x0 * x0 * w.a) - ex * S);
+      break;
+    }
+    default: break;
+  }
+  if (E && lane == 0) E[r] = e;
 }
 
 struct DecideArgs {
@@ -314,6 +411,31 @@ int upload_rows(mjhmc_sampler* s, const double* host, int64_t n, double* dst) {
   return 0;
 }
 
+int wide_energy_of(const mjhmc_energy* en, WideEnergy* w) {
+  const EnergyParams& ep = en->ep;
+  w->kind = ep.kind;
+  w->a = w->b = w->c = 0.0;
+  w->jdiag = (const double*)ep.dev_f64;
+  switch (ep.kind) {
+    case MJHMC_E_ISO_GAUSS: w->a = 1.0 / (ep.p[0] * ep.p[0]); w->b = 1.0 / (2.0 * (ep.p[0] * ep.p[0])); return 0;
+    case MJHMC_E_DIAG_GAUSS: return 0;
+    case MJHMC_E_ROUGH_WELL: w->a = ep.p[0] * ep.p[0]; w->b = 2.0 * (ep.p[0] * ep.p[0]); w->c = ep.p[1]; return 0;
+    case MJHMC_E_MM_GAUSS: w->a = 2.0 * ep.p[0]; return 0;
+    case MJHMC_E_FUNNEL_NEAL: w->a = 1.0 / (ep.p[0] * ep.p[0]); w->b = 0.5 * (ep.ndims - 1); return 0;
+    case MJHMC_E_FUNNEL_REF: w->a = 1.0 / (ep.p[0] * ep.p[0]); w->b = (double)(ep.ndims - 1); return 0;
+    default: return mjhmc_fail(MJHMC_ERR_UNSUPPORTED, "ndims too large for this energy's register-resident kernels, and it has no multi-pass form");
+  }
+}
+
+// E (nrows) and dE/dX (rows) of rows X on the device; either output may be NULL
+int wide_eval_rows(mjhmc_sampler* s, const double* X, double* G, double* E, int64_t nrows) {
+  WideEnergy w;
+  TRY(wide_energy_of(s->en, &w));
+  hipLaunchKernelGGL(hk_energy_grad, dim3((unsigned)nrows), dim3(64), 0, s->stream, X, G, E, nrows, s->D, s->sh.pitch, w);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int need_traj(mjhmc_sampler* s) {
   if (s->ht) return 0;
   HostTraj* t = new HostTraj();
@@ -390,6 +512,12 @@ int mjhmc_traj_begin(mjhmc_sampler* s, int64_t* n_cols) {
   if (!s->host_energy_set)
     return mjhmc_fail(MJHMC_ERR_INVALID, "E and dE/dX of the current state are unknown: call mjhmc_host_set_energy first");
   HIPCHK(hipSetDevice(s->ctx->device));
+  return traj_begin_impl(s, n_cols);
+}
+
+}  // extern "C"
+
+int traj_begin_impl(mjhmc_sampler* s, int64_t* n_cols) {
   TRY(need_traj(s));
   HostTraj* t = s->ht;
   const int pitch = s->sh.pitch;
@@ -427,9 +555,11 @@ int mjhmc_traj_begin(mjhmc_sampler* s, int64_t* n_cols) {
   t->n_cols = s->N + t->n_cold;
   t->phase = 1;
   t->steps = 0;
-  *n_cols = t->n_cols;
+  if (n_cols) *n_cols = t->n_cols;
   return 0;
 }
+
+extern "C" {
 
 int mjhmc_traj_step(mjhmc_sampler* s, const double* grad, int last, double* X_out) {
   TRY(check_host(s));
@@ -466,11 +596,20 @@ int mjhmc_traj_finish(mjhmc_sampler* s, const double* E, const double* replay_no
   if (!E) return mjhmc_fail(MJHMC_ERR_INVALID, "E is NULL");
   if (ring_slot >= s->ring_slots) return mjhmc_fail(MJHMC_ERR_INVALID, "ring slot out of range");
   HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipMemcpyAsync(t->E, E, (size_t)t->n_cols * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  return traj_finish_impl(s, replay_normal, replay_exp, replay_unif, ring_slot, st);
+}
+
+}  // extern "C"
+
+// t->E holds the energies of the end points (device); decide + commit
+int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double* replay_exp, const double* replay_unif,
+                     int ring_slot, mjhmc_iter_stats* st) {
+  HostTraj* t = s->ht;
   const int64_t n = t->n_cols;
   const int pitch = s->sh.pitch;
   const bool replay = s->mode == MJHMC_MODE_CONTROL ? (replay_unif != nullptr) : (replay_exp != nullptr);
   if (replay && !replay_normal) return mjhmc_fail(MJHMC_ERR_INVALID, "replay needs the normals as well");
-  HIPCHK(hipMemcpyAsync(t->E, E, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(hk_kinetic, dim3((unsigned)n), dim3(64), 0, s->stream, (const double*)t->V, t->EVw, n, s->D, pitch);
   if (replay) {
     if (!t->noise) HIPCHK(hipMalloc((void**)&t->noise, (size_t)s->Npad * pitch * sizeof(double)));
@@ -580,4 +719,86 @@ int mjhmc_traj_finish(mjhmc_sampler* s, const double* E, const double* replay_no
   return 0;
 }
 
-}  // extern "C"
+// ---- wide samplers: built-in elementwise energies with ndims beyond the register-resident kernels -------------------
+
+// run_eval of api.hip for a host energy or a wide sampler: the kinetic energy of V (or the tick-0 momentum) always; E and
+// dE/dX from the device kernel for a wide sampler, the caller's (mjhmc_host_set_energy) for a host energy
+int wide_run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
+  if (!s->en->is_host() && X && (Gout || Eout)) TRY(wide_eval_rows(s, (const double*)X, (double*)Gout, (double*)Eout, s->N));
+  return host_run_eval(s, V, Vgen, EVout);
+}
+
+// one kick / drift pass of the proposal columns: [V += c g_new]; unless last: V += c g; X += eps V
+static int traj_advance(mjhmc_sampler* s, bool closing_kick, bool last) {
+  HostTraj* t = s->ht;
+  const int64_t ne = t->n_cols * s->sh.pitch;
+  const double c = -s->eps / 2.;
+  if (closing_kick) hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->V, (const double*)t->G, c, ne);
+  if (!last) {
+    hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->V, (const double*)t->G, c, ne);
+    hipLaunchKernelGGL(hk_axpy, grid1(ne), dim3(256), 0, s->stream, t->X, (const double*)t->V, s->eps, ne);
+    t->steps += 1;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// mjhmc_iterate for a wide sampler: n_iter sampling iterations, each L x (kick, drift, device gradient) over the proposal
+// columns in HBM, then decide + commit -- the contract of iterate_t (stops at the first attempt with a non-finite rate)
+int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
+                      const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
+  const size_t DN = (size_t)s->D * s->N;
+  int done = 0;
+  HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
+  for (int i = 0; i < n_iter; ++i) {
+    TRY(traj_begin_impl(s, nullptr));
+    HostTraj* t = s->ht;
+    for (int l = 0; l < s->L; ++l) {
+      TRY(traj_advance(s, l > 0, false));
+      TRY(wide_eval_rows(s, t->X, t->G, l == s->L - 1 ? t->E : nullptr, t->n_cols));
+    }
+    TRY(traj_advance(s, s->L > 0, true));
+    if (s->L == 0) TRY(wide_eval_rows(s, t->X, nullptr, t->E, t->n_cols));
+    t->phase = 2;
+    mjhmc_iter_stats st;
+    TRY(traj_finish_impl(s, replay_normal ? replay_normal + (size_t)i * DN : nullptr,
+                         replay_exp ? replay_exp + (size_t)i * 3 * s->N : nullptr,
+                         replay_unif ? replay_unif + (size_t)i * (2 * s->N + 1) : nullptr,
+                         ring_slot0 >= 0 ? ring_slot0 + i : -1, &st));
+    if (per_iter) per_iter[i] = st;
+    if (st.nonfinite) break;
+    done += 1;
+  }
+  HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  s->last_jump_launches = std::min(done + 1, n_iter);
+  s->timing_pending = true;
+  if (n_done) *n_done = done;
+  return 0;
+}
+
+// mjhmc_leapfrog for a wide shape: n_steps of hmc_state.py:86-100 on rows X, V (device), literal operation order
+int wide_leapfrog(mjhmc_sampler* w, const double* X, const double* V, double* Xo, double* Vo, double* G, double* EX,
+                  double* EV, double eps, int n_steps) {
+  const int64_t ne = w->Npad * w->sh.pitch, nv = w->N * w->sh.pitch;
+  double* g = G;
+  if (!g) HIPCHK(hipMalloc((void**)&g, (size_t)ne * sizeof(double)));
+  auto body = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(Xo, X, (size_t)ne * sizeof(double), hipMemcpyDeviceToDevice, w->stream));
+    HIPCHK(hipMemcpyAsync(Vo, V, (size_t)ne * sizeof(double), hipMemcpyDeviceToDevice, w->stream));
+    TRY(wide_eval_rows(w, Xo, g, EX, w->N));
+    const double c = -eps / 2.;
+    for (int l = 0; l < n_steps; ++l) {
+      hipLaunchKernelGGL(hk_axpy, grid1(nv), dim3(256), 0, w->stream, Vo, (const double*)g, c, nv);
+      hipLaunchKernelGGL(hk_axpy, grid1(nv), dim3(256), 0, w->stream, Xo, (const double*)Vo, eps, nv);
+      TRY(wide_eval_rows(w, Xo, g, EX, w->N));
+      hipLaunchKernelGGL(hk_axpy, grid1(nv), dim3(256), 0, w->stream, Vo, (const double*)g, c, nv);
+    }
+    if (EV) hipLaunchKernelGGL(hk_kinetic, dim3((unsigned)w->N), dim3(64), 0, w->stream, (const double*)Vo, EV, w->N, w->D, w->sh.pitch);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(w->stream));
+    return 0;
+  };
+  const int rc = body();
+  if (!G && g) (void)hipFree(g);
+  return rc;
+}

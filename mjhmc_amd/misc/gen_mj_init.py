@@ -112,12 +112,28 @@ def cache_initialization(distribution, directory, **kwargs):
     return path
 
 
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """Unpickling runs whatever callables the file names.  The cache files hold tuples of NumPy arrays and floats:
+    only the three globals an ndarray pickle needs are resolved, anything else is refused."""
+
+    _ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+                ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+                ('numpy', 'ndarray'), ('numpy', 'dtype'),
+                ('_codecs', 'encode')}      # how protocol-2 pickles written by Python 3 carry an array's bytes
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super(_ArraysOnlyUnpickler, self).find_class(module, name)
+        raise pickle.UnpicklingError('initialisation cache: refusing to resolve %s.%s (arrays and floats only)' % (module, name))
+
+
 def load_reference_initialization(path):
     """A cache file written by the REFERENCE (mjhmc/misc/gen_mj_init.py:54-73 under Python 2, e.g. the files it ships in
     initializations/): returns (mjhmc_endpt, emc_var_estimate, true_var_estimate, control_endpt); older files hold only
-    the first three (control_endpt is then None)."""
+    the first three (control_endpt is then None).  The file is read with an unpickler that resolves nothing but
+    ndarray / dtype reconstruction, so a crafted file cannot run code; still, load files you trust."""
     with open(path, 'rb') as cache_file:
-        t = pickle.load(cache_file, encoding='latin1')       # Python 2 str -> bytes of the ndarray payloads
+        t = _ArraysOnlyUnpickler(cache_file, encoding='latin1').load()   # Python 2 str -> bytes of the ndarray payloads
     if len(t) == 4:
         mj, emc_var, true_var, ctl = t
     elif len(t) == 3:
@@ -132,4 +148,4 @@ def load_initialization(distribution, directory):
     """Distribution.load_cache (mjhmc/misc/distributions.py:182-195)."""
     path = os.path.join(directory, '{}_{}.pickle'.format(type(distribution).__name__, stable_digest(distribution)))
     with open(path, 'rb') as cache_file:
-        return pickle.load(cache_file)
+        return _ArraysOnlyUnpickler(cache_file).load()

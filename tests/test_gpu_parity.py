@@ -895,12 +895,68 @@ def test_unsupported_shapes_fail_loudly():
     from mjhmc_amd import _lib
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
     from mjhmc_amd.misc.distributions import TestGaussian, SparseImageCode
-    with pytest.raises(_lib.EngineError):                      # > 1024 float64 dims: no register-resident kernel
-        MarkovJumpHMC(distribution=TestGaussian(ndims=1100, nbatch=4), epsilon=0.1, beta=0.1)
     B = np.random.RandomState(0).randn(64, 128)
     d = SparseImageCode(n_patches=1, n_batches=4, n_basis=128, basis=B, imgs=np.zeros((64, 1)))
     with pytest.raises(_lib.EngineError):                      # only the 256 x 1024 dictionary shape is built
         MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.1)
+
+
+@pytest.mark.parametrize('cls_name,kind,D,N', [('MarkovJumpHMC', 'iso', 1100, 70), ('MarkovJumpHMC', 'diag', 5000, 33),
+                                               ('MarkovJumpHMC', 'funnel', 1500, 40), ('ControlHMC', 'rough', 1030, 50),
+                                               ('ContinuousTimeHMC', 'mm', 1300, 20)])
+def test_more_dims_than_the_register_kernels_hold(cls_name, kind, D, N):
+    """hmc_state.py:86-100 are plain array operations: the reference takes any ndims.  Beyond 1024 float64 dims (64 lanes x
+    16 elements) the engine switches to its multi-pass path -- state in HBM between the substeps, one wavefront per row
+    (csrc/host_energy.hip: multipass_iterate) -- and must follow the oracle exactly as the register kernels do."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc import distributions as Dm
+    rs = np.random.RandomState(D + N)
+    if kind == 'iso':
+        X0, en, kw = rs.randn(D, N), orc.IsoGaussian(1.3), dict(epsilon=0.1, beta=0.3, num_leapfrog_steps=5)
+        mk = lambda: Dm.TestGaussian(ndims=D, nbatch=N, sigma=1.3)                       # noqa: E731
+    elif kind == 'diag':
+        X0, en, kw = rs.randn(D, N), orc.DiagGaussian(D, 2), dict(epsilon=0.1, beta=0.3, num_leapfrog_steps=4)
+        mk = lambda: Dm.Gaussian(ndims=D, nbatch=N, log_conditioning=2)                 # noqa: E731
+    elif kind == 'funnel':
+        x0 = 0.5 * rs.randn(N)
+        X0 = np.vstack([x0, np.exp(x0 / 2) * rs.randn(D - 1, N)])
+        en, kw = orc.FunnelNeal(3.0), dict(epsilon=0.02, beta=0.3, num_leapfrog_steps=4)
+        mk = lambda: Dm.Funnel(ndims=D, nbatch=N, scale=3.0)                            # noqa: E731
+    elif kind == 'rough':
+        X0, en, kw = 3.0 * rs.randn(D, N), orc.RoughWell(100.0, 4.0), dict(epsilon=0.3, beta=0.3, num_leapfrog_steps=3)
+        mk = lambda: Dm.RoughWell(ndims=D, nbatch=N, scale1=100, scale2=4)              # noqa: E731
+    else:
+        X0, en, kw = 0.3 * rs.randn(D, N), orc.MultimodalGaussian(D, 1), dict(epsilon=0.02, beta=0.3, num_leapfrog_steps=3)
+        mk = lambda: Dm.MultimodalGaussian(ndims=D, nbatch=N, separation=1)          # noqa: E731
+
+    def fixed():
+        d = mk()
+        d.Xinit = X0
+        d.gen_init_X = lambda: setattr(d, 'Xinit', X0)
+        d.init_X = lambda: setattr(d, 'Xinit', X0)
+        return d
+    d = fixed()
+    assert close(d.E(X0)[0], en.E_val(X0)[0]) and close(d.dEdX(X0), en.dEdX_val(X0))     # mjhmc_eval on wide rows
+    extra = dict(resample=False) if cls_name != 'ControlHMC' else {}
+    s = getattr(M, cls_name)(distribution=d, seed=23, **kw, **extra)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(23, np.arange(N)), **kw, **extra)
+    for t in range(5):
+        s.sampling_iteration()
+        o.sampling_iteration()
+        if cls_name == 'MarkovJumpHMC':
+            assert np.array_equal(s._dev.read(8), o.last_transition), t
+            assert close(s.dwelling_times, o.dwelling_times), t
+        assert close(s.state.X, o.state.X) and close(s.state.V, o.state.V), t
+        assert close(s.state.EX, o.state.EX) and close(s.state.EV, o.state.EV) and close(s.state.dEdX, o.state.dEdX), t
+        assert (s.l_count, s.f_count, s.r_count, s.fl_count) == (o.l_count, o.f_count, o.r_count, o.fl_count), t
+        assert (d.E_count, d.dEdX_count) == (en.E_count, en.dEdX_count), t
+    out = s.sample(3, preserve_order=True)                           # batched call + the sample ring
+    for t in range(3):
+        o.sampling_iteration()
+    assert out.shape == (D, N, 3) and close(out[:, :, 2], o.state.X)
+    Z = s.state.copy().L()                                           # mjhmc_leapfrog on wide rows
+    Zo = o.state.clone().L()
+    assert close(Z.X, Zo.X) and close(Z.V, Zo.V) and close(Z.EX, Zo.EX) and close(Z.EV, Zo.EV)
 
 
 # ---------------------------------------------------------------------------------------------

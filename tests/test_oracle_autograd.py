@@ -134,3 +134,25 @@ def test_reference_written_initialisation_files_load():
     assert np.array_equal(mj, r['sic_mj_X']) and np.array_equal(ctl, r['sic_ctl_X'])
     mj, _, _, _ = load_reference_initialization(os.path.join(root, 'Funnel_3713081631925750456.pickle'))
     assert mj.shape == (10, 1000) and np.isnan(mj).any()          # the shipped funnel run diverged
+
+
+def test_initialisation_cache_loader_resolves_arrays_only(tmp_path):
+    """The cache files are pickles; the loaders resolve ndarray / dtype reconstruction and nothing else, so a file that
+    names another callable is refused instead of executed."""
+    import os
+    import pickle
+    import numpy as np
+    from mjhmc_amd.misc.gen_mj_init import load_reference_initialization
+
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ('echo should-never-run > %s' % (tmp_path / 'ran'),))
+    bad = tmp_path / 'bad.pickle'
+    bad.write_bytes(pickle.dumps((Evil(), 1.0, 2.0), protocol=2))
+    with pytest.raises(pickle.UnpicklingError):
+        load_reference_initialization(str(bad))
+    assert not (tmp_path / 'ran').exists()
+    good = tmp_path / 'good.pickle'
+    good.write_bytes(pickle.dumps((np.arange(6.0).reshape(2, 3), np.float64(1.5), 2.5, np.ones((2, 3))), protocol=2))
+    mj, a, b, ctl = load_reference_initialization(str(good))
+    assert mj.shape == (2, 3) and (a, b) == (1.5, 2.5) and ctl.shape == (2, 3)
