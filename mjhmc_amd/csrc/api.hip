@@ -862,11 +862,16 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   s->seed = seed;
   int rc = 0;
   if (e->is_pot()) {
-    if (dtype != MJHMC_F32) {
+    if (dtype == MJHMC_F64) {
+      // the reference's own arithmetic: float64 HMCState arrays around the float32 force (distributions.py:408-415,
+      // hmc_state.py:29-38) -- the multi-pass path, the force from the float32 matrix-core evaluation kernel
+      s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};
+    } else if (dtype != MJHMC_F32) {
       delete s;
-      return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs in float32 (the reference evaluates it in float32)");
+      return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs with float32 or float64 state");
+    } else {
+      s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
     }
-    s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   } else if (e->is_sic()) {
     s->sh = Shape{0, 0, s->D, s->D / 8, 2};  // a particle row = n_patches x 1024 bfloat16
   } else {
@@ -2058,8 +2063,8 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   w.D = e->ep.ndims;
   w.dtype = dtype;
   if (e->is_pot()) {
-    if (dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T evaluates in float32");
-    w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
+    if (dtype == MJHMC_F64) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};  // float64 in and out, float32 force
+    else w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   } else if (e->is_sic()) {
     w.sh = Shape{0, 0, w.D, w.D / 8, 2};
   } else {
@@ -2100,7 +2105,6 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
   if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
   if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
-  if (e->is_pot() && dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T integrates in float32");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   if (e->is_host()) return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy has no device leapfrog operator");
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -2112,7 +2116,8 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
   w.first_pid = 0;
   w.D = e->ep.ndims;
   w.dtype = dtype;
-  if (e->is_pot()) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
+  if (e->is_pot() && dtype == MJHMC_F64) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};
+  else if (e->is_pot()) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
   else if (e->is_sic()) w.sh = Shape{0, 0, w.D, w.D / 8, 2};
   else TRY(pick_shape(w.D, dtype, &w.sh));
   void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // X, V, X', V', G, EX, EV
@@ -2129,7 +2134,7 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
     if (EV_out) HIPCHK(hipMalloc(&buf[6], vb));
     TRY(upload_matrix(&w, X, buf[0]));
     TRY(upload_matrix(&w, V, buf[1]));
-    if (e->is_pot()) {
+    if (e->is_pot() && !w.sh.wide) {
       PotLeapArgs a;
       a.X = (const float*)buf[0];
       a.V = (const float*)buf[1];

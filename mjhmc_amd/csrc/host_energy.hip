@@ -40,6 +40,7 @@ struct HostTraj {
   int* kmove = nullptr;     // [Npad] decision of the attempt
   double* dtmp = nullptr;   // [Npad] dwelling time of the attempt
   double* hnew = nullptr;   // [3 Npad] EX, EV, H_flf of the successor
+  float* pot32[3] = {nullptr, nullptr, nullptr};  // ProductOfT with float64 state: float32 X, dE/dX rows and E of the force evaluation
   int n_cold = 0;
   int64_t n_cols = 0;
   int phase = 0;  // 0 idle, 1 begun (stepping), 2 last kick done
@@ -427,8 +428,69 @@ int wide_energy_of(const mjhmc_energy* en, WideEnergy* w) {
   }
 }
 
+__global__ void hk_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+__global__ void hk_widen(const float* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i];
+}
+
+// ProductOfT as the reference runs it (distributions.py:408-415 with hmc_state.py:29-38): float64 HMCState arrays around
+// a float32 force -- the inputs are downcast (allow_input_downcast=True), E and dE/dX come back as float32.  The force is
+// the float32 matrix-core evaluation kernel of dense_pot.hip on a float32 copy of the rows.
+int pot_eval_rows_f64(mjhmc_sampler* s, const double* X, double* G, double* E, int64_t nrows) {
+  const int pitch = s->sh.pitch;
+  const int64_t rows_pad = (nrows + 63) / 64 * 64, ne = rows_pad * pitch;
+  float* tmp[3] = {nullptr, nullptr, nullptr};
+  float** buf = tmp;
+  const bool own = !(s->ht && rows_pad <= 2 * s->Npad);
+  if (!own) {
+    buf = s->ht->pot32;
+    if (!buf[0]) {
+      const size_t cap = (size_t)2 * s->Npad;
+      HIPCHK(hipMalloc((void**)&buf[0], cap * pitch * sizeof(float)));
+      HIPCHK(hipMalloc((void**)&buf[1], cap * pitch * sizeof(float)));
+      HIPCHK(hipMalloc((void**)&buf[2], cap * sizeof(float)));
+    }
+  } else {
+    HIPCHK(hipMalloc((void**)&buf[0], (size_t)ne * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&buf[1], (size_t)ne * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&buf[2], (size_t)rows_pad * sizeof(float)));
+  }
+  auto body = [&]() -> int {
+    HIPCHK(hipMemsetAsync(buf[0], 0, (size_t)ne * sizeof(float), s->stream));  // rows beyond nrows: zeros, never NaN garbage
+    hipLaunchKernelGGL(hk_narrow, grid1(nrows * pitch), dim3(256), 0, s->stream, X, buf[0], nrows * pitch);
+    PotEvalArgs a;
+    a.X = buf[0];
+    a.G = G ? buf[1] : nullptr;
+    a.E = E ? buf[2] : nullptr;
+    a.EV = nullptr;
+    a.V = nullptr;
+    a.V_gen = nullptr;
+    a.N = nrows;
+    a.ntiles = rows_pad / 32;
+    a.first_pid = 0;
+    a.D = s->D;
+    a.key = RngKey{0u, 0u, 0u, 0u};
+    pot_launch_eval(a, s->en->pot_model(), s->stream);
+    if (G) hipLaunchKernelGGL(hk_widen, grid1(nrows * pitch), dim3(256), 0, s->stream, (const float*)buf[1], G, nrows * pitch);
+    if (E) hipLaunchKernelGGL(hk_widen, grid1(nrows), dim3(256), 0, s->stream, (const float*)buf[2], E, nrows);
+    HIPCHK(hipGetLastError());
+    if (own) HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+  };
+  const int rc = body();
+  if (own)
+    for (float* b : tmp)
+      if (b) (void)hipFree(b);
+  return rc;
+}
+
 // E (nrows) and dE/dX (rows) of rows X on the device; either output may be NULL
 int wide_eval_rows(mjhmc_sampler* s, const double* X, double* G, double* E, int64_t nrows) {
+  if (s->en->is_pot()) return pot_eval_rows_f64(s, X, G, E, nrows);
   WideEnergy w;
   TRY(wide_energy_of(s->en, &w));
   hipLaunchKernelGGL(hk_energy_grad, dim3((unsigned)nrows), dim3(64), 0, s->stream, X, G, E, nrows, s->D, s->sh.pitch, w);
@@ -468,7 +530,8 @@ int check_host(mjhmc_sampler* s) {
 void host_traj_free(mjhmc_sampler* s) {
   HostTraj* t = s->ht;
   if (!t) return;
-  void* bufs[] = {t->X, t->V, t->G, t->E, t->EVw, t->noise, t->cold, t->coldpos, t->kmove, t->dtmp, t->hnew};
+  void* bufs[] = {t->X, t->V, t->G, t->E, t->EVw, t->noise, t->cold, t->coldpos, t->kmove, t->dtmp, t->hnew,
+                  t->pot32[0], t->pot32[1], t->pot32[2]};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete t;

@@ -352,13 +352,19 @@ class Funnel(Distribution):
 class ProductOfT(Distribution):
     """Product of Student-t experts (distributions.py:373-453).  The reference builds E and its
     gradient with Theano in float32; here both GEMMs of the gradient run on the MI355X matrix
-    cores (exact-f32 MFMA).  ndims == nbasis <= 512, as the reference's initialiser requires (:391-392)."""
+    cores (exact-f32 MFMA).  ndims == nbasis <= 512, as the reference's initialiser requires (:391-392).
 
-    def __init__(self, ndims=36, nbasis=36, nbatch=100, lognu=None, W=None, b=None):
+    ``state_dtype`` (extension): 'float32' (default) keeps the particle state in float32 too -- the fused tile kernel,
+    BASELINE configs[2]; 'float64' is the reference's own arithmetic, float64 ``HMCState`` arrays around the float32
+    force (:408-415 with hmc_state.py:29-38), on the engine's multi-pass path (state in HBM between the substeps)."""
+
+    def __init__(self, ndims=36, nbasis=36, nbatch=100, lognu=None, W=None, b=None, state_dtype='float32'):
         if ndims != nbasis:
             raise NotImplementedError("Initializer only works for ndims == nbasis")
+        if state_dtype not in ('float32', 'float64'):
+            raise ValueError("ProductOfT state_dtype must be 'float32' or 'float64'")
         self.nbasis = nbasis
-        self.state_dtype = 'float32'
+        self.state_dtype = state_dtype'
         self.backend = 'hip-mfma'
         if W is None:
             W = np.eye(ndims, nbasis)

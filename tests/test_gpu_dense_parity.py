@@ -134,6 +134,46 @@ def test_sic_single_evaluation(tag, P, n, cauchy, src):
     assert rel(G, g[tag + '_g']) < 2e-2, rel(G, g[tag + '_g'])
 
 
+@pytest.mark.parametrize('cls_name,D,N', [('MarkovJumpHMC', 36, 256), ('MarkovJumpHMC', 300, 70), ('ControlHMC', 36, 100)])
+def test_pot_with_the_references_arithmetic_float64_state_float32_force(cls_name, D, N):
+    """distributions.py:408-415 with hmc_state.py:29-38: the reference integrates float64 HMCState arrays around a float32
+    Theano force.  ProductOfT(state_dtype='float64') does the same on the device (float32 matrix-core force on a
+    downcast copy of the state, float64 kick / drift) and is compared with the oracle run WITHOUT any state rounding:
+    the only difference left is the summation order inside the float32 matrix products."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import ProductOfT
+    W, lognu = ref_init_weights(D, D)
+    W = W + np.eye(D)
+    X0 = load('ref_init_states')['pot36_X'][:, :N] if D == 36 else np.random.RandomState(5).randn(D, N)
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0
+    d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W, state_dtype='float64')
+    en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float32)
+    assert rel(d.E(X0)[0], en.E_val(X0)[0]) < 4e-6 and rel(d.dEdX(X0), en.dEdX_val(X0)) < 2e-5
+    kw = dict(epsilon=0.1, beta=0.3, num_leapfrog_steps=6)
+    if cls_name == 'MarkovJumpHMC':
+        s = M.MarkovJumpHMC(distribution=d, seed=17, resample=False, **kw)
+        o = orc.MarkovJumpHMC(en, X0, resample=False, rng=orc.PhiloxRNG(17, np.arange(N)), **kw)
+        assert np.array_equal(s.state.V, o.state.V)                  # float64 normals, no rounding anywhere
+        _resync(s, o)
+        ties = 0
+        for t in range(6):
+            ties += check_iteration(s, o, delta_rel=4e-6, x_tol=1e-6, e_rtol=4e-6, tag='pot f64 state it %d' % t)
+            _resync(s, o)
+        assert ties <= 0.002 * 6 * N + 2, ties
+        assert s.state.X.dtype == np.float64 and np.abs(s.state.X - s.state.X.astype(np.float32)).max() > 0   # not float32 values
+    else:
+        s = M.ControlHMC(distribution=d, seed=17, **kw)
+        o = orc.ControlHMC(en, X0, rng=orc.PhiloxRNG(17, np.arange(N)), **kw)
+        for t in range(6):
+            check_control_iteration(s, o, delta_rel=4e-6, x_tol=1e-6, e_rtol=4e-6, tag='pot f64 control it %d' % t)
+            _resync(s, o)
+    out = s.sample(3, preserve_order=True) if cls_name == 'ControlHMC' else s.sample(3, preserve_order=True)
+    assert out.shape == (D, N, 3) and np.isfinite(out).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # sampling iterations from the states the reference ships, transitions proven equal up to near ties
 # ---------------------------------------------------------------------------------------------
