@@ -364,7 +364,7 @@ class ProductOfT(Distribution):
         if state_dtype not in ('float32', 'float64'):
             raise ValueError("ProductOfT state_dtype must be 'float32' or 'float64'")
         self.nbasis = nbasis
-        self.state_dtype = state_dtype'
+        self.state_dtype = state_dtype
         self.backend = 'hip-mfma'
         if W is None:
             W = np.eye(ndims, nbasis)
