@@ -51,6 +51,11 @@ WORKLOADS = {
     'c3': dict(name='C3 ProductOfT ndims=nbasis=512 nparticles=100000 L=20 fp32 (state and force; the reference '
                     'keeps a float64 state around its float32 force)', kind='pot', D=512, N=100000,
                L=20, eps=0.05, beta=0.1, dtype='float32', params=None),
+    # the same workload in the reference's own arithmetic (float64 HMCState arrays around the float32 force,
+    # distributions.py:408-415 + hmc_state.py:29-38): the engine's multi-pass path (state in HBM between the substeps)
+    'c3f64': dict(name='C3 ProductOfT ndims=nbasis=512 nparticles=100000 L=20, float64 state around the float32 force '
+                       '(the reference\'s arithmetic; multi-pass path)', kind='pot', D=512, N=100000,
+                  L=20, eps=0.05, beta=0.1, dtype='float64', params=None),
     # BASELINE.json configs[3]
     'c4': dict(name='C4 Neal funnel ndims=32 nparticles=1000000 L=15 fp64', kind='funnel', D=32, N=1000000,
                L=15, eps=0.05, beta=0.1, dtype='float64', params=[3.0]),
@@ -62,7 +67,7 @@ WORKLOADS = {
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
 }
-DTYPE_TAG = {'float64': 'f64', 'float32': 'f32 state and force (the reference: f64 state arrays around its f32 Theano force)',
+DTYPE_TAG = {'float64': 'f64 state (ProductOfT: around the f32 matrix-core force)', 'float32': 'f32 state and force (the reference: f64 state arrays around its f32 Theano force)',
              'bfloat16': 'bf16 state / f32 accumulate'}
 
 
@@ -402,8 +407,10 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         tf = flops / (kern_it_ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
                 'traffic': measured_traffic(key, 1),
-                'kernel': ('pot_jump_kernel + pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel + sic_flf_kernel')
-                          + ' (one sampling iteration = both kernels, launched as two half-batches on two streams)',
+                'kernel': ('pot_eval_kernel (float32 matrix-core force) + float64 kick / drift / decide / commit passes, one sampling iteration'
+                           if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
+                           ('pot_jump_kernel + pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel + sic_flf_kernel')
+                           + ' (one sampling iteration = both kernels, launched as two half-batches on two streams)'),
                 'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'algorithmic_flops_per_launch': flops,
                 'hbm': {'algorithmic_bytes_per_launch': 6.0 * w['D'] * esize * n_rank,
                         'achieved': 6.0 * w['D'] * esize * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s',
@@ -477,7 +484,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         out['cpu_baseline'] = cpu_baseline(w, cpu_seconds)
         out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
     if w['kind'] == 'pot':
-        out['config']['arithmetic'] = 'float32 state and float32 MFMA force (dtype of the sampler: %s)' % w['dtype']
+        out['config']['arithmetic'] = ('float32 state and float32 MFMA force (fused tile kernel)' if w['dtype'] == 'float32' else
+                                       'float64 state around the float32 MFMA force: the reference\'s arithmetic (multi-pass path)')
     return out
 
 
@@ -634,7 +642,7 @@ def main(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=64)     # iterations per mjhmc_iterate call (one fused launch of the elementwise kernels)
     ap.add_argument('--warmup', type=int, default=64)
-    ap.add_argument('--workload', default='all', choices=sorted(WORKLOADS) + ['all'])
+    ap.add_argument('--workload', default='all', choices=sorted(WORKLOADS) + ['all'])      # c3f64: C3 in the reference's arithmetic
     ap.add_argument('--head', default='c3', choices=['c2', 'c3', 'c4', 'c5'],
                     help='top-level workload of the line (default: C3, the workload of BASELINE.json\'s numeric target)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
@@ -647,7 +655,7 @@ def main(argv=None):
     if args.spawn_check:
         return spawn_report()
     rig = Rig(args)
-    keys = ['c2', 'c3', 'c4', 'c5'] if args.workload == 'all' else [args.workload]
+    keys = ['c2', 'c3', 'c3f64', 'c4', 'c5'] if args.workload == 'all' else [args.workload]
     head = args.head if args.head in keys else keys[0]
     keys = [head] + [k for k in keys if k != head]
     rig.head = head
@@ -662,9 +670,9 @@ def main(argv=None):
 
     # run order: the two vector-pipe / HBM workloads first, then the matrix-core ones -- whichever is the head.  (Measured:
     # C2 right after the ProductOfT run reads 7 % slower than on a chip that has not just run 20 s of dense MFMA work.)
-    for key in [k for k in ('c1', 'c2', 'c4', 'c3', 'c5') if k in keys]:
+    for key in [k for k in ('c1', 'c2', 'c4', 'c3', 'c3f64', 'c5') if k in keys]:
         steps, warm = budget(key)
-        cpu_s = 0 if args.no_cpu_baseline else (12.0 if key == head else 6.0)
+        cpu_s = 0 if (args.no_cpu_baseline or key == 'c3f64') else (12.0 if key == head else 6.0)
         results[key] = run_workload(rig, key, steps, warm, cpu_s, args.scaling)
         if results[key] is not None:
             results[key]['steps'] = steps
@@ -704,6 +712,12 @@ def main(argv=None):
         if len(keys) > 1:
             out['workloads'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world, scaling=args.scaling)
                                 for k, v in results.items()}
+        if 'c3f64' in results and results['c3f64'] and c3 is not None and 'cpu_baseline' in c3:
+            # the CPU baseline of C3 IS this arithmetic (float64 state, float32 force): the like-for-like ratio
+            r = results['c3f64']
+            r['config']['gpu_over_cpu'] = r['value'] / c3['cpu_baseline']['value']
+            out['workloads']['c3f64']['config']['gpu_over_cpu'] = r['config']['gpu_over_cpu']
+            out['target']['gpu_over_cpu_same_arithmetic'] = r['config']['gpu_over_cpu']
         if strong:
             out['strong'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world) for k, v in strong.items()}
         print(json.dumps(out))
