@@ -76,6 +76,12 @@ def main():
                 big = [v for k, vals in cs.items() if MAIN[w] in k and k.rstrip().endswith('true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)') for v in vals]
                 n_units = max(len(big), 1) / float(launches_per_iteration(p, 'true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)'))
                 per[c] = sum(big) / n_units            # a fused launch runs as several parts on as many streams
+            elif w == 'c2nofuse':
+                # `bench.py --workload c2 --steps 1`: the timed calls are single iterations (never fused); its warm-up is one
+                # fused call (three parts on three streams) -- only the one-iteration launches count here
+                fused_tag = 'true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)'
+                single = [v for k, vals in cs.items() if MAIN[w] in k and not k.rstrip().endswith(fused_tag) for v in vals]
+                per[c] = sum(single) / max(len(single), 1)
             else:
                 n_units = len(main) / float(launches_per_iteration(p, MAIN[w]))
                 per[c] = sum(ours) / n_units            # every kernel of an iteration, per iteration
