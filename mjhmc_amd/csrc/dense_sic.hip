@@ -12,16 +12,35 @@
 // only the energy sums and the jump decision couple the P columns of a particle.  A tile is 32 columns holding
 // floor(32 / P) whole particles (P = 9: 27 of the 32 columns work).
 //
-// One workgroup = 8 waves (two per SIMD) owns a tile of 32 columns.  Wave w holds coefficient rows
-// [128w, 128w+128) of X and V as fp32 MFMA accumulator tiles (4 blocks of 32 rows) and image rows
-// [32w, 32w+32) of the residual (1 block).  v_mfma_f32_32x32x16_bf16 throughout:
-//   GEMM1  resid[i][n] = sum_c B[i][c] a[c][n] - y[i]     64 k-steps x 1 block  per wave
-//   GEMM2  V[c][n]    += sum_i B[i][c] (s * resid[i][n])  16 k-steps x 4 blocks per wave
-// GEMM2 accumulates straight into the momentum registers: the kick "V += s * dE/dX" is the MFMA's C
-// operand, with the step scale s = -eps/2 (first/last half kick) or -eps (the two half kicks between
-// drifts, merged) folded into the bf16 residual when it is published.  Accumulator registers 8t..8t+7
-// converted to bf16 are directly the B fragment of k-step t (rows 16t + 8(j>>2) + 4h + (j&3)); the
-// dictionary is pre-permuted on the host into that k-order ("A1", "A2"), 16 contiguous bytes per lane.
+// ROUND 3: ONE pass over the dictionary per leapfrog step.  Both products of a step read the same matrix -- the kick
+// needs B^T (rows = coefficients), the next residual needs B (rows = pixels) -- and the dictionary (512 KB in bf16)
+// cannot stay in a CU, so a 32-column tile is bound by the rate at which its CU can pull dictionary bytes out of L2
+// (measured 36-41 B/clk/CU, 0.6 of the L2 peak, whatever the prefetch depth).  Rounds 1-2 streamed it twice per step.
+// Now a block of 32 coefficient rows (all 256 pixels: 16 KB) is loaded ONCE and used for both:
+//
+//   one workgroup = 8 waves (two per SIMD, 256 registers each) owns a tile of 32 columns; wave w holds coefficient rows
+//   [128 w, 128 w + 128) of X and V as fp32 MFMA accumulator tiles (4 blocks of 32 rows) and pixel rows [32 w, 32 w + 32)
+//   of the residual (1 block).  The waves form two groups, {0..3} and {4..7} (a SIMD holds one wave of each).  A leapfrog
+//   step is 8 ROUNDS; round r belongs to group r & 1, whose four waves each OWN one block of it (block r >> 1 of theirs):
+//     owners   G2   V_block += B^T[block] . (s * resid)       16 v_mfma_f32_32x32x16_bf16, A = the block's image read row-wise
+//              drift X_block += eps * V_block; publish bf16(X_block) as two B fragments
+//     (the other group meanwhile adds the prior's force of ITS next block: vector work beside the owners' matrix work)
+//                                                                                                        (barrier A)
+//     all 8    G1   resid'[32 w ..] += B[32 w .., the round's four blocks] . X(those blocks):  8 MFMAs per wave,
+//              A = the SAME LDS images read TRANSPOSED (ds_read_b64_tr_b16)                            (barrier B)
+//     owners   start the LDS-DMA of their next block into the image they have just finished with
+//   so the kick of step n (residual of step n) and the residual of step n + 1 come out of one stream of the dictionary:
+//   L + 2 passes per trajectory instead of 2 L + 2.  Image buffers: 2 groups x 4 owners x 16 KB of LDS, filled by
+//   `global_load_lds_dwordx4` (no VGPR destination) while the OTHER group's round runs -- across rounds, passes and tiles.
+//   (A first form of this with 4 waves of 512 registers, every wave owning a block in every round, was correct and 1.6x
+//   SLOWER than the two-pass kernel: hipcc splits 512 registers into 256 vector + 256 accumulation registers, vector
+//   instructions cannot touch the latter, and the kernel spent its time on v_accvgpr moves, spills and exposed LDS
+//   latency with nothing else on the SIMD to cover it.)
+//
+// Accumulator registers 8s..8s+7 converted to bf16 are directly the B fragment of k-step s (rows 16s + 8(j>>2) + 4h +
+// (j&3)); the dictionary is pre-permuted on the host into that k-order ("A2": [k-step of 16 pixels][half][coefficient]
+// [8 pixels]).  Inside an LDS image the 64 16-byte chunks of a k-step are PERMUTED (the DMA's per-lane source offset
+// does it for free) so that the row read of G2 (ds_read_b128) and the transposed read of G1 are both bank-conflict free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,15 +49,24 @@
 
 #include "dense_sic.hpp"
 
+// timing experiments (tools/sic_variants.sh): parts of a round switched off -- results are then garbage.  0 = the product.
+#ifndef SICV
+#define SICV 0
+#endif
+
 namespace mjhmc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
 
 constexpr int kP = 32;
 constexpr int kI = kSicImg;     // 256
+constexpr int kW = 8;           // waves per workgroup, two per SIMD
+constexpr int kG = 4;           // waves per group = blocks per round
 // NB = 32-row blocks of X and V per wave = n_coeffs / 256 (4: the 1024-atom dictionary, 2: the 512-atom one)
 #define kC (256 * NB)
 
@@ -46,10 +74,13 @@ __device__ __forceinline__ int acc_row(int q, int h) { return (q & 3) + 8 * (q >
 
 template <int NB>
 struct CTile {
-  f32x16 b[NB];  // this wave's 32 NB coefficient rows x 32 particles
+  f32x16 b[NB];  // this wave's 32 NB coefficient rows x 32 columns
+};
+struct RTile {
+  f32x16 b[1];    // this wave's 32 pixel rows of the residual
 };
 
-// bf16 state rows [*][1024]: lane (c, h) reads its 16 groups of 4 consecutive coefficients (8 bytes each)
+// bf16 state rows [*][n_coeffs]: lane (c, h) reads its 16 groups of 4 consecutive coefficients (8 bytes each)
 template <int NB>
 __device__ __forceinline__ void ctile_load(const __bf16* base, int64_t p, int w, int h, CTile<NB>& t) {
   const __bf16* row = base + (size_t)p * kC + 32 * NB * w + 4 * h;
@@ -77,41 +108,44 @@ __device__ __forceinline__ void ctile_store(__bf16* base, int64_t p, int w, int 
     }
 }
 
-constexpr int kRing = 8;    // dictionary fragments (1 KB each) a wave keeps in flight / staged
-constexpr int kYLds = 12;   // patches whose pixels fit the LDS copy (more: read from global memory)
+// dE/dX is handed out in float32
+template <int NB>
+__device__ __forceinline__ void ctile_store_f32(float* base, int64_t p, int w, int h, const CTile<NB>& t) {
+  float* row = base + (size_t)p * kC + 32 * NB * w + 4 * h;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = t.b[b][4 * g + k];
+      *reinterpret_cast<f32x4*>(row + 32 * b + 8 * g) = o;
+    }
+}
+
+constexpr int kYLds = 4;    // patches whose pixels fit the LDS copy (more: read from global memory at the head of a pass)
 
 // ALL of the workgroup's LDS is this one object (a second __shared__ object beside an LDS-DMA target makes hipcc
 // drain the DMA queue before LDS reads, cdna_hip_programming.md section 5)
-template <int NB>
 struct SicShared {
-  f32x4 pubA[8][NB][2][64];   // 64 KB: a as B fragments, [wave][block][k-step half][lane]
-  f32x4 pubR[8][2][64];       // 16 KB: scaled residual as B fragments
-  f32x4 ring[8][kRing][64];   // 64 KB: per-wave ring of dictionary (A operand) fragments, filled by LDS-DMA
-  float ys[kYLds * kI];       // 12 KB: the patches
+  f32x4 img[2][kG][16][64];   // 128 KB: dictionary block images, [owner group = round parity][owner][k-step][chunk position]
+  f32x4 pubR[16][64];         // 16 KB: the scaled residual as B fragments [k-step][lane], written at the head of a pass
+  f32x4 pubX[kG][2][64];      //  8 KB: a round's drifted coefficient blocks as B fragments [wave][k-step][lane]
+  float ys[kYLds * kI];       //  4 KB: the patches
   int ypatch[kP];             // byte offset of column c's patch inside ys (the column -> patch map does not depend on the tile)
-  float red[2][8][kP];
+  float red[2][kW][kP];
   float colsum[kP];           // per-column energies, summed over a particle's columns when n_patches > 1
   int move[kP];
   unsigned tally[4];
 };
+static_assert(sizeof(SicShared) <= 160 * 1024, "LDS budget of a CU");
 
 // ---- the dictionary stream -----------------------------------------------------------------------------------------
-// Both GEMMs of a leapfrog step read the whole dictionary (512 KB in each fragment order) from L2, 64 KB per wave
-// and GEMM, one 1 KB fragment per MFMA.  Loading a fragment into registers right before its MFMA exposes a full L2
-// round trip per MFMA (and every register spent on prefetch spills elsewhere: the kernel sits at the 256-VGPR budget).
-// So the fragments go through LDS instead: `global_load_lds_dwordx4` (no VGPR destination) fills a per-wave ring of
-// kRing slots, kRing fragments ahead of the MFMA that consumes them.  The fragment sequence of a wave is fixed --
-// GEMM1 (64 fragments), GEMM2 (64), GEMM1, ... -- so the ring runs ahead ACROSS the GEMMs, the barriers between them
-// and the tiles of the persistent loop: L2 latency is paid once per kernel.  Each wave reads only the slots it filled
-// itself: ordering is the wave's own counted `s_waitcnt vmcnt(kRing - 1)`, no barrier.  The DMA is inline asm, so
-// hipcc neither counts it nor drains it at `__syncthreads()`; its own waits (for loads it does count) can only
-// over-wait, because the counter completes in issue order.
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
-// lane l's 16 bytes at (sbase + voff) land at lds_dst + 16 l.  sbase is wave-uniform (scalar registers: its arithmetic
-// is free), voff the lane's byte offset (ONE loop-invariant VGPR): per-lane 64-bit source pointers would cost two
-// VGPRs per in-flight address, spill, and every spill reload is a counted load that drains the ring
+// lane l's 16 bytes at (sbase + voff) land at lds_dst + 16 l.  sbase is wave-uniform (scalar registers), voff the lane's
+// byte offset; the DMA is inline asm, so hipcc neither counts it nor drains it at a barrier
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -124,50 +158,72 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-constexpr unsigned kFrag1 = 2 * kI * 16;  // bytes between consecutive GEMM1 fragments (k-steps) of a lane
-#define kFrag2 (2u * kC * 16u)            // bytes between consecutive GEMM2 k-steps; blocks of a k-step are 512 B apart
+#define kFrag2 (2u * kC * 16u)   // bytes between consecutive k-steps of A2; the blocks of a k-step are 512 B apart
+
+// Chunk position inside a k-step image.  A k-step image holds, for 16 pixels, 64 chunks of 16 bytes: chunk (hs, c) =
+// the 8 pixels {8(j>>2) + 4 hs + (j&3)} of coefficient c (0..31 inside the block).  It sits at position
+//     pos = 32 hs + 16 (c >> 4) + 4 (((c >> 2) & 3) ^ (hs + 2 (ks & 1))) + (c & 3)
+// (16-byte units).  Row read of G2, lane (c, h) takes chunk (h, c): inside each of ds_read_b128's 16-lane groups the four
+// values of (c >> 2) & 3 are distinct, XOR-ing a constant keeps them so.  Transposed read of G1: a 32-lane half takes, for
+// 4 consecutive coefficients, both pixel halves of two consecutive k-steps -- (c >> 2) & 3 is fixed there and the XOR
+// term spreads (hs, ks & 1) over the four 64-byte bank groups.  Both reads are conflict free.
+__device__ __forceinline__ int chunk_pos(int hs, int c, int ks_odd) {
+  return 32 * hs + 16 * (c >> 4) + 4 * (((c >> 2) & 3) ^ (hs + 2 * ks_odd)) + (c & 3);
+}
 
 struct AStream {
-  const char* a1;   // GEMM1 fragments: A1[k-step][h][image row][8 bf16]           (wave-uniform base)
-  const char* a2;   // GEMM2 fragments: A2[k-step][h][coefficient row][8 bf16]
-  unsigned v1, v2;  // this lane's byte offset inside a GEMM1 / GEMM2 fragment
-  unsigned lds0;    // LDS byte address of this wave's ring
-  int only1;        // the kernel runs GEMM1 only (an evaluation without gradient): the sequence is GEMM1, GEMM1, ...
+  const char* a2w;     // A2 (+ copy) at this wave's first block: wave-uniform
+  unsigned voff[2];    // byte offset, inside a k-step of A2, of the chunk that lands at THIS lane's position (even / odd k-step)
+  unsigned img_own;    // LDS byte address of this wave's image buffer, img[w >> 2][w & 3]
+  unsigned row[2];     // byte offset of this lane's G2 row-read chunk inside a k-step image (even / odd k-step)
+  unsigned tr[2];      // byte offset of this lane's G1 transposed reads inside an owner's block image, first / second half of
+                       // the fragment, at k-step 2 w + (lane group & 1) and k-step-of-coefficients 0
 };
 
-// GEMM1 fragment (k-step) `pos` < kRing into ring slot pos: the head of the stream
-__device__ __forceinline__ void astream_issue(const AStream& s, int pos) {
-  glds16(s.a1 + (size_t)pos * kFrag1, s.v1, s.lds0 + (unsigned)pos * 1024u);
+// block T (compile time) of this wave into its image buffer
+template <int NB, int T>
+__device__ __forceinline__ void issue_block(const AStream& s) {
+  if (SICV == 4 || SICV == 9) return;
+  const char* src = s.a2w + (T % NB) * 512;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
 }
 
 template <int NB>
-__device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared<NB>& sh, int w, int c, int h, bool only1) {
+__device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& sh, int w, int lane) {
   AStream s;
   const size_t copy = (size_t)((blockIdx.x >> 3) % (unsigned)mdl.copies) * (size_t)(kI * kC * 2);  // blocks b, b + 8 share an XCD
-  s.a1 = reinterpret_cast<const char*>(mdl.A1) + copy;
-  s.a2 = reinterpret_cast<const char*>(mdl.A2) + copy;
-  s.v1 = (unsigned)(h * kI + 32 * w + c) * 16u;
-  s.v2 = (unsigned)(h * kC + 32 * NB * w + c) * 16u;
-  s.lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&sh.ring[w][0][0]));
-  s.only1 = only1 ? 1 : 0;
+  s.a2w = reinterpret_cast<const char*>(mdl.A2) + copy + (size_t)(32 * NB * w) * 16;
+  // (the pointer is wave-uniform; read through the first lane so that it lives in scalar registers)
+  s.a2w = (const char*)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long)s.a2w >> 32)) << 32) |
+                        (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long)s.a2w));
+  s.img_own = __builtin_amdgcn_readfirstlane(lds_addr(&sh.img[w >> 2][w & 3][0][0]));
+  const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < kRing; ++j) astream_issue(s, j);  // the first GEMM1 fragments
+  for (int p = 0; p < 2; ++p) {
+    // which chunk lands at position `lane` of an image of k-step parity p (the inverse of chunk_pos)
+    const int hs = lane >> 5, x = (lane >> 2) & 3;
+    const int cc = 16 * ((lane >> 4) & 1) + 4 * (x ^ (hs + 2 * p)) + (lane & 3);
+    s.voff[p] = (unsigned)(hs * kC + cc) * 16u;
+    s.row[p] = (unsigned)chunk_pos(h, c, p) * 16u;
+  }
+  {  // transposed reads: 16-lane group g = lane >> 4 serves MFMA rows 16 (g & 1) .. + 15 of lane half g >> 1
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    const int hh = g >> 1, ko = g & 1;  // the fragment's lane half; parity of the k-step these 16 pixel rows live in
+#pragma unroll
+    for (int u = 0; u < 2; ++u)        // coefficients 8 u + 4 hh + q of a 16-coefficient k-step; pixels 4 pp .. 4 pp + 3
+      s.tr[u] = (unsigned)chunk_pos(pp & 1, 8 * u + 4 * hh + q, ko) * 16u + (unsigned)(pp >> 1) * 8u + (unsigned)ko * 1024u +
+                (unsigned)(2 * w) * 1024u;
+  }
+  issue_block<NB, 0>(s);   // the head of the stream
   return s;
 }
 
 // before the wave exits: no DMA may still be writing LDS that the next workgroup will own
 __device__ __forceinline__ void astream_close() { wait_vm<0>(); }
 
-// a GEMM1 whose GEMM2 is not run (a trajectory of zero steps): put the ring back on GEMM1's first fragments
-__device__ __forceinline__ void astream_rewind(const AStream& s) {
-  wait_vm<0>();
-#pragma unroll
-  for (int j = 0; j < kRing; ++j) astream_issue(s, j);
-}
-
 // the patches into LDS (once per kernel)
-template <int NB>
-__device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared<NB>& sh) {
+__device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared& sh) {
   if (mdl.P <= kYLds)
     for (int i = threadIdx.x; i < mdl.P * kI; i += blockDim.x) sh.ys[i] = mdl.y[i];
   if (threadIdx.x < kP) {  // col_of: column c works on patch min(c, cpt - 1) % P
@@ -175,15 +231,6 @@ __device__ __forceinline__ void stage_patches(const SicModel& mdl, SicShared<NB>
     sh.ypatch[threadIdx.x] = ((threadIdx.x < cpt ? (int)threadIdx.x : cpt - 1) % mdl.P) * kI * (int)sizeof(float);
   }
   __syncthreads();
-}
-
-// this lane's index in its wave, produced by instructions the compiler must re-issue wherever it is asked for: addresses
-// derived from it are RECOMPUTED inside the leapfrog loop (two vector instructions) instead of being kept live across it
-// -- at the 256-register budget they were spilled, and every spill reload is a counted load that drains the ring
-__device__ __forceinline__ unsigned lane_id_here() {
-  unsigned l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
 }
 
 // what column c of a tile works on
@@ -223,131 +270,178 @@ __device__ __forceinline__ f32x4 frag_of(const f32x16& acc, int s, float scale) 
   return __builtin_bit_cast(f32x4, f);
 }
 
-// residual of the tile at the X held in x (GEMM1).  Leaves it in `res` (fp32 accumulator layout).
-template <int NB, bool YG>
-__device__ __forceinline__ void sic_residual(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
-                                             int lane, int patch, const CTile<NB>& x, f32x16& res) {
-  constexpr int kSteps = 16 * NB;  // GEMM1 k-steps = fragments per wave
+
+// ---- one pass over the dictionary ---------------------------------------------------------------------------------------
+constexpr int kPassG1 = 0;     // residual only:  R = B x - y                                  (head of a trajectory; E(x))
+constexpr int kPassFused = 1;  // kick with the residual held, drift, residual at the new x    (one leapfrog step)
+constexpr int kPassG2 = 2;     // kick only                                                    (closing half kick; dE/dX)
+
+// R = -y[patch][this wave's 32 pixel rows]
+__device__ __forceinline__ void resid_init(const SicModel& mdl, SicShared& sh, int w, int h, int c, int patch, RTile& R) {
+  using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
+  using glb_f32x4 = __attribute__((address_space(1))) const f32x4;
+  const int off = 32 * w + 4 * h;
+  if (mdl.P <= kYLds) {
+    lds_f32x4* yv = (lds_f32x4*)(unsigned long)(lds_addr(sh.ys) + (unsigned)sh.ypatch[c] + 4u * (unsigned)off);
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    sh.pubA[w][b][0][lane] = frag_of(x.b[b], 0, 1.0f);
-    sh.pubA[w][b][1][lane] = frag_of(x.b[b], 1, 1.0f);
-  }
-  __syncthreads();
-  {  // res starts at -y[i]
-    using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
-    using lds_int = __attribute__((address_space(3))) const int;
-    using glb_f32x4 = __attribute__((address_space(1))) const f32x4;
-    if constexpr (!YG) {
-      // the patches are in LDS (n_patches <= kYLds): ds_read_b128 from an address rebuilt here from the lane index --
-      // nothing counted in vmcnt, nothing kept in a register across the loop.  (A pointer selected at run time between
-      // LDS and global memory is generic: its loads are flat_load, waited for with vmcnt(0), which drained the
-      // dictionary ring at the head of every GEMM1.)
-      const unsigned lid = lane_id_here();
-      unsigned ya = lds_addr(sh.ys) + (unsigned)__builtin_amdgcn_readfirstlane(128 * w) + ((lid >> 5) << 4);
-      if (mdl.P > 1) ya += (unsigned)*(lds_int*)(unsigned long)(lds_addr(sh.ypatch) + ((lid & 31u) << 2));
-      lds_f32x4* yv = (lds_f32x4*)(unsigned long)ya;
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = yv[2 * g];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = yv[2 * g];
+      for (int k = 0; k < 4; ++k) R.b[0][4 * g + k] = -v[k];
+    }
+  } else {  // n_patches 5..32: from global memory (counted loads: the waits on the DMA stream only get longer)
+    glb_f32x4* yv = (glb_f32x4*)(__attribute__((address_space(1))) const float*)(mdl.y + kI * patch + off);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
-      }
-    } else {  // n_patches 13..32: global loads (counted: this instantiation drains the ring once per GEMM1)
-      glb_f32x4* yv = (glb_f32x4*)(__attribute__((address_space(1))) const float*)(mdl.y + kI * patch + 32 * w + 4 * h);
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = yv[2 * g];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = yv[2 * g];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) res[4 * g + k] = -v[k];
-      }
+      for (int k = 0; k < 4; ++k) R.b[0][4 * g + k] = -v[k];
     }
   }
-  // 16 NB k-steps; the fragment of k-step ks is in ring slot ks % kRing, and its slot is refilled with the fragment
-  // kRing positions further down the stream as soon as it has been read.  The LDS reads of k-step ks + 1 are issued
-  // before the MFMA of k-step ks (one register set ahead), so an MFMA never waits for the LDS round trip.
-  const f32x4* ring = &sh.ring[w][0][lane];
-  f32x4 fa, fb, na, nb;
-  wait_vm<kRing - 1>();
-  fa = ring[0];
-  fb = sh.pubA[0][0][0][lane];
-  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi, bool last) {
-    // refill: wave-uniform address of the fragment that goes into slot 0; slot j gets refill + (j % NB) step + (j / NB) step_hi
-#pragma unroll
-    for (int j = 0; j < kRing; ++j) {
-      const int ks = ch * kRing + j;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fa, fb are here; slot j has been read: it may be refilled
-      __builtin_amdgcn_sched_barrier(0);
-      glds16(refill + (j % NB) * step + (j / NB) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
-      if (!(last && j == kRing - 1)) {
-        wait_vm<kRing - 1>();  // fragment ks + 1 has landed
-        const int kn = ks + 1;
-        na = ring[((j + 1) & (kRing - 1)) * 64];
-        nb = sh.pubA[kn / (2 * NB)][(kn >> 1) % NB][kn & 1][lane];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), res,
-                                                    0, 0, 0);
-      fa = na;
-      fb = nb;
-    }
-  };
-#pragma unroll 1
-  for (int ch = 0; ch < kSteps / kRing - 1; ++ch)
-    chunk(ch, as.a1 + (size_t)(ch + 1) * kRing * kFrag1, as.v1, kFrag1, NB * kFrag1, false);
-  if (as.only1) chunk(kSteps / kRing - 1, as.a1, as.v1, kFrag1, NB * kFrag1, true);  // the next GEMM1's first fragments
-  else chunk(kSteps / kRing - 1, as.a2, as.v2, 512, kFrag2, true);  // GEMM2's first: (k-step 0, blocks 0..NB-1), (k-step 1, ...), ...
 }
 
-// acc[c][n] += sum_i B[i][c] * (scale * res[i][n]) + scale * prior'(x)   (GEMM2 into the caller's tile)
-template <bool CAUCHY, int NB>
-__device__ __forceinline__ void sic_kick(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
-                                         int lane, const f32x16& res, const CTile<NB>& x, float scale, CTile<NB>& acc) {
-  constexpr int kPos = 16 * NB;         // GEMM2 stream positions per wave: 16 k-steps x NB blocks
-  constexpr int kKs = kRing / NB;       // k-steps per chunk of kRing positions
-  sh.pubR[w][0][lane] = frag_of(res, 0, scale * mdl.invP);  // d/da_p of the MEAN over patches
-  sh.pubR[w][1][lane] = frag_of(res, 1, scale * mdl.invP);
-  {  // the prior's force first (x is not read again until the drift): lambda * 2a / (1 + a^2), or lambda * sign(a)
-    const float sl = scale * mdl.lambda;
+// the prior's force of one block: lambda * 2a / (1 + a^2), or lambda * sign(a)
+template <bool CAUCHY>
+__device__ __forceinline__ void prior_kick(const SicModel& mdl, const f32x16& xb, float scale, f32x16& acc) {
+  const float sl = scale * mdl.lambda;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float a = x.b[b][q];
-        if (CAUCHY) acc.b[b][q] += (sl * 2.0f) * a * __builtin_amdgcn_rcpf(1.0f + a * a);  // v_rcp_f32: 1 ulp
-        else acc.b[b][q] += sl * (a > 0.f ? 1.0f : (a < 0.f ? -1.0f : 0.0f));
-      }
+  for (int q = 0; q < 16; ++q) {
+    const float a = xb[q];
+    if (CAUCHY) acc[q] += (sl * 2.0f) * a * __builtin_amdgcn_rcpf(1.0f + a * a);  // v_rcp_f32: 1 ulp
+    else acc[q] += sl * (a > 0.f ? 1.0f : (a < 0.f ? -1.0f : 0.0f));
   }
-  __syncthreads();
-  const f32x4* ring = &sh.ring[w][0][lane];
-  // stream positions 8 ch + j = (k-step kKs ch + j / NB, block j % NB); refilled kRing positions ahead: the same
-  // (j / NB, block) of chunk ch + 1, or, from the last chunk, the next GEMM1's first fragments.  The dictionary fragment
-  // of position + 1 is read from the ring before the MFMA of this position.
-  f32x4 fa, na;
-  wait_vm<kRing - 1>();
-  fa = ring[0];
-  auto chunk = [&](int ch, const char* refill, unsigned voff, unsigned step, unsigned step_hi, bool last) {
-    f32x4 fb[kKs];
+}
+
+// G2 of an owner's round: acc (a block of V, or of dE/dX) += B^T[block] . (the scaled residual held in pubR)
+__device__ __forceinline__ void round_g2(SicShared& sh, const AStream& as, int lane, f32x16& acc) {
+  using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
+  // the operands of k-step ks + 1 are read before the MFMA of k-step ks; the fences keep hipcc from hoisting all the
+  // reads to the top (registers) or sinking them to their uses (an LDS round trip in front of every MFMA)
+  const unsigned base = as.img_own;
+  const unsigned rb0 = lds_addr(&sh.pubR[0][0]) + 16u * (unsigned)lane;
+  // kAhead k-steps of operands in flight: during an owner's G2 its SIMD partner has no matrix work, so nothing but the
+  // wave's own earlier reads covers the LDS round trip
+  constexpr int kAhead = (SICV == 11) ? 2 : ((SICV == 12) ? 5 : 3);
+  f32x4 fa[kAhead], fb[kAhead];
 #pragma unroll
-    for (int t = 0; t < kKs; ++t) fb[t] = sh.pubR[(kKs * ch + t) >> 1][(kKs * ch + t) & 1][lane];
+  for (int k = 0; k < kAhead; ++k) {
+    fa[k] = *(lds_f32x4*)(unsigned long)(base + (unsigned)k * 1024u + as.row[k & 1]);
+    fb[k] = *(lds_f32x4*)(unsigned long)(rb0 + (unsigned)k * 1024u);
+  }
 #pragma unroll
-    for (int j = 0; j < kRing; ++j) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fa (and fb) are here; slot j may be refilled
-      __builtin_amdgcn_sched_barrier(0);
-      glds16(refill + (j % NB) * step + (j / NB) * step_hi, voff, as.lds0 + (unsigned)j * 1024u);
-      if (!(last && j == kRing - 1)) {
-        wait_vm<kRing - 1>();
-        na = ring[((j + 1) & (kRing - 1)) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc.b[j % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                              __builtin_bit_cast(bf16x8, fb[j / NB]), acc.b[j % NB], 0, 0, 0);
-      fa = na;
+  for (int ks = 0; ks < 16; ++ks) {
+    const f32x4 a = fa[ks % kAhead], b = fb[ks % kAhead];
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + kAhead < 16) {
+      fa[ks % kAhead] = *(lds_f32x4*)(unsigned long)(base + (unsigned)(ks + kAhead) * 1024u + as.row[(ks + kAhead) & 1]);
+      fb[ks % kAhead] = *(lds_f32x4*)(unsigned long)(rb0 + (unsigned)(ks + kAhead) * 1024u);
     }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ f32x4 frag_scaled(const f32x16& acc, int s, float scale) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (__bf16)(acc[8 * s + j] * scale);
+  return __builtin_bit_cast(f32x4, f);
+}
+
+// G1 of one round: R += B[this wave's 32 pixel rows, the round's four blocks] . X(those blocks)
+template <int RD>
+__device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int lane, RTile& R) {
+  using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
+  using lds_i16x4 = __attribute__((address_space(3))) i16x4;
+  const unsigned img0 = lds_addr(&sh.img[RD & 1][0][0][0]);
+  const unsigned xb0 = lds_addr(&sh.pubX[0][0][0]) + 16u * (unsigned)lane;
+  // MFMA n = 2 i + s: the fragment A[pixel row][8 coefficients of k-step s of owner i's block] is two transposed
+  // 4-coefficient pieces; the operands of MFMA n + 1 are read before MFMA n
+  auto ops_of = [&](int n, i16x4& lo, i16x4& hi, f32x4& xf) {
+    const unsigned at = img0 + (unsigned)(n >> 1) * 16384u + (unsigned)(n & 1) * 256u;
+    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(unsigned long)(at + as.tr[0]));
+    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(unsigned long)(at + as.tr[1]));
+    xf = *(lds_f32x4*)(unsigned long)(xb0 + (unsigned)n * 1024u);
   };
-#pragma unroll 1
-  for (int ch = 0; ch < kPos / kRing - 1; ++ch) chunk(ch, as.a2 + (size_t)(kKs * (ch + 1)) * kFrag2, as.v2, 512, kFrag2, false);
-  chunk(kPos / kRing - 1, as.a1, as.v1, kFrag1, NB * kFrag1, true);  // the next GEMM1's fragments 0..7: consecutive k-steps
+  i16x4 lo, hi, nlo, nhi;
+  f32x4 xf, nxf;
+  ops_of(0, lo, hi, xf);
+#pragma unroll
+  for (int n = 0; n < 2 * kG; ++n) {
+    if (SICV != 10) __builtin_amdgcn_sched_barrier(0);
+    nlo = lo;
+    nhi = hi;
+    nxf = xf;
+    if (n + 1 < 2 * kG) ops_of(n + 1, nlo, nhi, nxf);
+    const auto a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    R.b[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, xf), R.b[0], 0, 0, 0);
+    if (SICV != 10) __builtin_amdgcn_sched_barrier(0);
+    lo = nlo;
+    hi = nhi;
+    xf = nxf;
+  }
+}
+
+// One round of a pass (RD compile time: the register blocks it touches and the image group are static).  Round RD belongs
+// to group RD & 1: each of its four waves owns block RD >> 1 of its coefficient rows.
+template <int KIND, bool CAUCHY, int NB, int RD>
+__device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int lane,
+                                           CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
+  constexpr int T = RD >> 1;
+  const bool own = (w >> 2) == (RD & 1);   // wave-uniform
+  if (own) {
+    if (SICV != 7) wait_vm<0>();                // this wave's block image has landed (issued a round ago)
+    if constexpr (KIND != kPassG1) {
+      if (SICV != 2 && SICV != 9) round_g2(sh, as, lane, acc.b[T]);
+    }
+    if constexpr (KIND == kPassG2) {
+      issue_block<NB, T + 1>(as);   // nobody else reads this image in a kick-only pass
+    } else {
+      if constexpr (KIND == kPassFused) x.b[T] = x.b[T] + eps * acc.b[T];   // drift (acc is V)
+      if (SICV != 6) {
+        sh.pubX[w & 3][0][lane] = frag_scaled(x.b[T], 0, 1.0f);
+        sh.pubX[w & 3][1][lane] = frag_scaled(x.b[T], 1, 1.0f);
+      }
+    }
+  } else if constexpr (KIND != kPassG1 && RD + 1 < 2 * NB) {
+    // beside the owners' matrix work: the prior's force of the block this wave owns in the NEXT round
+    if (SICV != 5 && SICV != 9) prior_kick<CAUCHY>(mdl, x.b[(RD + 1) >> 1], scale, acc.b[(RD + 1) >> 1]);
+  }
+  if constexpr (KIND == kPassG2) return;
+  if (SICV != 3) __syncthreads();               // barrier A: the round's four images have landed, their X blocks are published
+  if (SICV != 1 && SICV != 9) round_g1<RD>(sh, as, lane, R);
+  if (SICV != 3) __syncthreads();               // barrier B: the round's images and X fragments have been read by every wave
+  if (own) issue_block<NB, T + 1>(as);   // the owner's next block (of the next pass after the last one): lands during the other group's round
+}
+
+template <int KIND, bool CAUCHY, int NB, int RD>
+struct Rounds {
+  static __device__ __forceinline__ void run(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int lane,
+                                             CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
+    pass_round<KIND, CAUCHY, NB, RD>(mdl, sh, as, w, lane, x, acc, R, scale, eps);
+    if constexpr (RD + 1 < 2 * NB) Rounds<KIND, CAUCHY, NB, RD + 1>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps);
+  }
+};
+
+// kPassG1:    R = B x - y.
+// kPassFused: acc (= V) += scale * dE/dX at the x whose residual is R;  x += eps * V;  R = B x - y at the new x.
+// kPassG2:    acc += scale * dE/dX at the x whose residual is R (x, R unchanged).
+template <int KIND, bool CAUCHY, int NB>
+__device__ __forceinline__ void sic_pass(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h, int lane,
+                                         int patch, CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
+  if constexpr (KIND != kPassG1) {
+    // the residual, scaled by the step and by 1 / n_patches (d/da_p of the MEAN over patches), as the B operand of G2:
+    // every wave publishes its two k-steps (the last readers of pubR were the G2 rounds of the previous kick pass, which
+    // every wave has left through a barrier since)
+    const float sc = scale * mdl.invP;
+    sh.pubR[2 * w + 0][lane] = frag_scaled(R.b[0], 0, sc);
+    sh.pubR[2 * w + 1][lane] = frag_scaled(R.b[0], 1, sc);
+    if ((w >> 2) == 0) prior_kick<CAUCHY>(mdl, x.b[0], scale, acc.b[0]);   // group 0 owns round 0: nobody to do it beside
+    __syncthreads();
+  }
+  if constexpr (KIND != kPassG2) resid_init(mdl, sh, w, h, c, patch, R);
+  Rounds<KIND, CAUCHY, NB, 0>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps);
+  if constexpr (KIND == kPassG2) __syncthreads();   // every wave's G2 reads of pubR are done before the next pass rewrites it
 }
 
 __device__ __forceinline__ float half_swap_sum(float s) {
@@ -356,8 +450,7 @@ __device__ __forceinline__ float half_swap_sum(float s) {
 }
 
 // sum of a per-column value over the columns of the caller's particle (n_patches of them, consecutive)
-template <int NB>
-__device__ __forceinline__ float group_total(SicShared<NB>& sh, int w, int c, int h, int P, int g0, float col_tot) {
+__device__ __forceinline__ float group_total(SicShared& sh, int w, int c, int h, int P, int g0, float col_tot) {
   if (P == 1) return col_tot;
   if (w == 0 && h == 0) sh.colsum[c] = col_tot;
   __syncthreads();
@@ -369,11 +462,11 @@ __device__ __forceinline__ float group_total(SicShared<NB>& sh, int w, int c, in
 
 // E(x) per PARTICLE from the residuals at x:  mean_p 1/2 |res_p|^2 + lambda * prior(x)  (tf_distributions.py:257-270)
 template <bool CAUCHY, int NB>
-__device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared<NB>& sh, int w, int c, int h, const Col& col,
-                                            const f32x16& res, const CTile<NB>& x) {
+__device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, int w, int c, int h, const Col& col,
+                                            const RTile& R, const CTile<NB>& x) {
   float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) s += 0.5f * res[q] * res[q];
+  for (int q = 0; q < 16; ++q) s += 0.5f * R.b[0][q] * R.b[0][q];
   float pr = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -387,14 +480,14 @@ __device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared<NB>& 
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) tot += sh.red[0][k][c];
+  for (int k = 0; k < kW; ++k) tot += sh.red[0][k][c];
   __syncthreads();
   return group_total(sh, w, c, h, mdl.P, col.g0, tot);
 }
 
 // sum(v^2) / 2 per PARTICLE
 template <int NB>
-__device__ __forceinline__ float sic_kinetic(SicShared<NB>& sh, int w, int c, int h, int P, const Col& col, const CTile<NB>& v) {
+__device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h, int P, const Col& col, const CTile<NB>& v) {
   float s = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -405,7 +498,7 @@ __device__ __forceinline__ float sic_kinetic(SicShared<NB>& sh, int w, int c, in
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) tot += sh.red[1][k][c];
+  for (int k = 0; k < kW; ++k) tot += sh.red[1][k][c];
   __syncthreads();
   return group_total(sh, w, c, h, P, col.g0, tot) / 2.0f;
 }
@@ -415,46 +508,38 @@ __device__ __forceinline__ void round_to_state(CTile<NB>& t) {
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      // opaque: otherwise hipcc shares these conversions with the ones that published the tile as an MFMA operand two
-      // GEMMs earlier and keeps 64 single bf16 values alive (spilled) across both of them
-      asm volatile("" : "+v"(t.b[b][q]));
-      t.b[b][q] = (float)(__bf16)t.b[b][q];
-    }
+    for (int q = 0; q < 16; ++q) t.b[b][q] = (float)(__bf16)t.b[b][q];
 }
 
 // L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
-// separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place.
-template <bool CAUCHY, int NB, bool YG>
-__device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared<NB>& sh, const AStream& as, int w, int c, int h,
-                                                int lane, const Col& col, CTile<NB>& x, CTile<NB>& v, int L, float eps,
-                                                float chalf) {
-  // the step scale is wave-uniform: both values sit in scalar registers and the select is an integer s_cselect (a float
-  // select is a per-lane v_cndmask whose operand was spilled and reloaded -- a counted load -- in front of every GEMM2)
-  const int c_half = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, chalf));
-  const int c_full = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f * chalf));
-  f32x16 res;
-  sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-  if (L > 0) sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, chalf, v);
-  else astream_rewind(as);
-  for (int s = 1; s <= L; ++s) {
-    asm volatile("; MJHMC_LEAPFROG_STEP_BEGIN (tools/check_isa.sh)");
-#pragma unroll
-    for (int b = 0; b < NB; ++b) x.b[b] = x.b[b] + eps * v.b[b];
-    sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-    // the step scale is wave-uniform: selected as an integer so that it stays in a scalar register (a float select is a
-    // per-lane v_cndmask whose operand was spilled and reloaded -- a counted load -- in front of every GEMM2)
-    sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, __builtin_bit_cast(float, s < L ? c_full : c_half), v);
-    asm volatile("; MJHMC_LEAPFROG_STEP_END");
+// separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place; R = residual at x_new.
+template <bool CAUCHY, int NB>
+__device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
+                                                int lane, const Col& col, CTile<NB>& x, CTile<NB>& v, RTile& R, int L,
+                                                float eps, float chalf) {
+  sic_pass<kPassG1, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, 0.f, 0.f);
+  if (L > 0) {
+    // the step scale is wave-uniform: both values sit in scalar registers, the select is an integer s_cselect
+    const int c_half = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, chalf));
+    const int c_full = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f * chalf));
+#pragma unroll 1
+    for (int s = 1; s <= L; ++s) {
+      asm volatile("; MJHMC_LEAPFROG_STEP_BEGIN (tools/check_isa.sh)");
+      // kick (half the first time, two merged halves afterwards), drift, residual at the new position
+      sic_pass<kPassFused, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R,
+                                        __builtin_bit_cast(float, s == 1 ? c_half : c_full), eps);
+      asm volatile("; MJHMC_LEAPFROG_STEP_END");
+    }
+    sic_pass<kPassG2, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, chalf, 0.f);   // closing half kick
   }
-  // the successor position is stored in bf16 (and GEMM1 already saw bf16(x)): evaluate the prior on
+  // the successor position is stored in bf16 (and G1 already saw bf16(x)): evaluate the prior on
   // what will be stored, so EX is the energy of the stored state
   round_to_state(x);
-  return sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, res, x);
+  return sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, R, x);
 }
 
-// v += mix * (standard normals of this lane's dims of particle `pid`; dims patch * 1024 + ...), group by group: one
-// Box-Muller quadruple's temporaries at a time keeps this rare branch from dictating the kernel's register budget
+// v += mix * (standard normals of this lane's dims of particle `pid`; dims patch * n_coeffs + ...), group by group: one
+// Box-Muller quadruple's temporaries at a time
 template <int NB>
 __device__ __forceinline__ void sic_add_normals(const RngKey& key, uint32_t pid, int patch, int w, int h, float mix,
                                                 CTile<NB>& v) {
@@ -479,48 +564,38 @@ __device__ __forceinline__ void sic_add_normals(const RngKey& key, uint32_t pid,
   }
 }
 
+template <int NB>
+__device__ __forceinline__ void ctile_zero(CTile<NB>& t) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.b[b][q] = 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------
-template <bool CAUCHY, int NB, bool YG>
+template <bool CAUCHY, int NB>
 __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, const SicModel mdl) {
-  __shared__ SicShared<NB> sh;
+  __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   stage_patches(mdl, sh);
-  const AStream as = astream_open(mdl, sh, w, c, h, a.G == nullptr);
+  const AStream as = astream_open<NB>(mdl, sh, w, lane);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
-    CTile<NB> x;
+    CTile<NB> x, g;
+    RTile R;
     ctile_load(a.X, col.q, w, h, x);
-    f32x16 res;
-    sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
+    sic_pass<kPassG1, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, g, R, 0.f, 0.f);
     if (a.G) {
-      CTile<NB> g;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
-      sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
-      if (col.alive) {
-        float* row = a.G + (size_t)col.q * kC + 32 * NB * w + 4 * h;  // dE/dX is handed out in float32
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            f32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = g.b[b][4 * gq + k];
-            *reinterpret_cast<f32x4*>(row + 32 * b + 8 * gq) = o;
-          }
-      }
+      ctile_zero(g);
+      sic_pass<kPassG2, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, g, R, 1.0f, 0.f);
+      if (col.alive) ctile_store_f32(a.G, col.q, w, h, g);
     }
-    const float ex = sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, res, x);
+    const float ex = sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, R, x);
     if (a.E && w == 0 && h == 0 && col.leader) a.E[col.part] = ex;
     if (a.EV) {
       CTile<NB> v;
       if (a.V_gen) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) v.b[b][q] = 0.f;
+        ctile_zero(v);
         sic_add_normals(a.key, (uint32_t)(a.first_pid + col.part), col.patch, w, h, 1.0f, v);
         round_to_state(v);  // EV matches the stored momentum
         if (col.alive) ctile_store(a.V_gen, col.q, w, h, v);
@@ -560,24 +635,25 @@ struct FromList {
   __device__ int64_t operator()(int64_t s) const { return list[s]; }
 };
 
-template <bool CAUCHY, int NB, bool YG>
+template <bool CAUCHY, int NB>
 __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, const SicModel mdl) {
-  __shared__ SicShared<NB> sh;
+  __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
   const int ppt = kP / mdl.P;
   if ((int64_t)blockIdx.x * ppt >= ncold) return;  // nothing for this workgroup
   stage_patches(mdl, sh);
-  const AStream as = astream_open(mdl, sh, w, c, h, false);
+  const AStream as = astream_open<NB>(mdl, sh, w, lane);
   for (int64_t tile = blockIdx.x; tile * ppt < ncold; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, (int64_t)ncold, FromList{a.cold_list});  // the last tile repeats an entry
     CTile<NB> x, v;
+    RTile R;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
 #pragma unroll
     for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
-    const float ex = sic_trajectory<CAUCHY, NB, YG>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
     round_to_state(v);  // the same rounding the jump kernel applies to the forward proposal
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (w == 0 && h == 0 && col.leader) a.Hwork[col.part] = ex + ev;
@@ -588,16 +664,16 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
 
 // MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
 // the reference's sparse-coding experiments, search/control_sp_img/control_objective.py:10)
-template <bool CAUCHY, bool REPLAY, int MODE, int NB, bool YG>
+template <bool CAUCHY, bool REPLAY, int MODE, int NB>
 __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, const SicModel mdl) {
-  __shared__ SicShared<NB> sh;
+  __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   if (threadIdx.x < 4) sh.tally[threadIdx.x] = 0;
   stage_patches(mdl, sh);
-  const AStream as = astream_open(mdl, sh, w, c, h, false);
+  const AStream as = astream_open<NB>(mdl, sh, w, lane);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
     const int64_t p = col.part;
@@ -605,9 +681,10 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
     const float H0 = EX0 + EV0;
     const float Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.f;
     CTile<NB> x, v;
+    RTile R;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
-    const float EXL = sic_trajectory<CAUCHY, NB, YG>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float EXL = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
     round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
     const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
@@ -712,42 +789,21 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
 }
 
 // HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
-template <bool CAUCHY, int NB, bool YG>
+template <bool CAUCHY, int NB>
 __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, const SicModel mdl) {
-  __shared__ SicShared<NB> sh;
+  __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   stage_patches(mdl, sh);
-  const AStream as = astream_open(mdl, sh, w, c, h, false);
+  const AStream as = astream_open<NB>(mdl, sh, w, lane);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
     CTile<NB> x, v;
+    RTile R;
     ctile_load(a.X, col.q, w, h, x);
     ctile_load(a.V, col.q, w, h, v);
-    const float ex = sic_trajectory<CAUCHY, NB, YG>(mdl, sh, as, w, c, h, lane, col, x, v, a.L, a.eps, a.chalf);
+    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
     round_to_state(v);
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
-    if (a.G) {  // dE/dX of the stored end point
-      f32x16 res;
-      sic_residual<NB, YG>(mdl, sh, as, w, c, h, lane, col.patch, x, res);
-      CTile<NB> g;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) g.b[b][q] = 0.f;
-      sic_kick<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, res, x, 1.0f, g);
-      if (col.alive) {
-        float* row = a.G + (size_t)col.q * kC + 32 * NB * w + 4 * h;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            f32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = g.b[b][4 * gq + k];
-            *reinterpret_cast<f32x4*>(row + 32 * b + 8 * gq) = o;
-          }
-      }
-    }
     if (col.alive) {
       ctile_store(a.X_out, col.q, w, h, x);
       ctile_store(a.V_out, col.q, w, h, v);
@@ -755,6 +811,12 @@ __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, c
     if (w == 0 && h == 0 && col.leader) {
       if (a.EX) a.EX[col.part] = ex;
       if (a.EV) a.EV[col.part] = ev;
+    }
+    if (a.G) {  // dE/dX of the stored end point, into the registers the momentum has just left
+      sic_pass<kPassG1, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, 0.f, 0.f);
+      ctile_zero(v);
+      sic_pass<kPassG2, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, 1.0f, 0.f);
+      if (col.alive) ctile_store_f32(a.G, col.q, w, h, v);
     }
     __syncthreads();
   }
@@ -768,57 +830,53 @@ static int sic_cus() {
   return std::max(1, cus);
 }
 
-template <bool CAUCHY, int MODE, int NB, bool YG>
+template <bool CAUCHY, int MODE, int NB>
 static void sic_launch_mode(const SicJumpArgs& a, const SicModel& mdl, unsigned grid, hipStream_t st) {
   const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);
-  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB, YG>), dim3(grid), dim3(512), 0, st, a, mdl);
-  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB, YG>), dim3(grid), dim3(512), 0, st, a, mdl);
+  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
 }
 
-template <bool CAUCHY, int NB, bool YG>
+template <bool CAUCHY, int NB>
 static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
     (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
     hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
                        a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
-    hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB, YG>), dim3(grid), dim3(512), 0, st, a, mdl);
-    sic_launch_mode<CAUCHY, kModeMJHMC, NB, YG>(a, mdl, grid, st);
+    hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+    sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
   } else if (a.mode == kModeCT) {
-    sic_launch_mode<CAUCHY, kModeCT, NB, YG>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeCT, NB>(a, mdl, grid, st);
   } else {
-    sic_launch_mode<CAUCHY, kModeControl, NB, YG>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeControl, NB>(a, mdl, grid, st);
   }
 }
 
-// the prior (Cauchy / Laplace), the dictionary width (1024 / 512 atoms) and where the patches are read from (LDS for
-// n_patches <= kYLds, global memory otherwise) select the instantiation
-#define SIC_DISPATCH(CALL)                                                 \
-  do {                                                                     \
-    const bool yg = mdl.P > kYLds;                                         \
-    if (mdl.nc == 1024) {                                                  \
-      if (mdl.cauchy) { if (yg) CALL(true, 4, true); else CALL(true, 4, false); }     \
-      else { if (yg) CALL(false, 4, true); else CALL(false, 4, false); }               \
-    } else {                                                               \
-      if (mdl.cauchy) { if (yg) CALL(true, 2, true); else CALL(true, 2, false); }     \
-      else { if (yg) CALL(false, 2, true); else CALL(false, 2, false); }               \
-    }                                                                      \
+// the prior (Cauchy / Laplace) and the dictionary width (1024 / 512 atoms) select the instantiation
+#define SIC_DISPATCH(CALL)                                   \
+  do {                                                       \
+    if (mdl.nc == 1024) {                                    \
+      if (mdl.cauchy) CALL(true, 4); else CALL(false, 4);    \
+    } else {                                                 \
+      if (mdl.cauchy) CALL(true, 2); else CALL(false, 2);    \
+    }                                                        \
   } while (0)
 
 void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-#define SIC_JUMP(C, NBV, YGV) sic_launch_jump_t<C, NBV, YGV>(a, mdl, st)
+#define SIC_JUMP(C, NBV) sic_launch_jump_t<C, NBV>(a, mdl, st)
   SIC_DISPATCH(SIC_JUMP);
 }
 
 void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-#define SIC_EVAL(C, NBV, YGV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV, YGV>), dim3(grid), dim3(512), 0, st, a, mdl)
+#define SIC_EVAL(C, NBV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
   SIC_DISPATCH(SIC_EVAL);
 }
 
 void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-#define SIC_LEAP(C, NBV, YGV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV, YGV>), dim3(grid), dim3(512), 0, st, a, mdl)
+#define SIC_LEAP(C, NBV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
   SIC_DISPATCH(SIC_LEAP);
 }
 

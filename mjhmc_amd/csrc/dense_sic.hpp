@@ -12,7 +12,7 @@ constexpr int kSicImg = 256;      // img_size
 inline bool sic_coeffs_supported(int nc) { return nc == 1024 || nc == 512; }
 
 struct SicModel {
-  const void* A1;   // bf16 [nc/16 k-steps][2 halves][256 image rows][8]: B[i][c] in GEMM1's fragment k-order
+  const void* A1;   // (rounds 1-2: the dictionary in GEMM1's fragment order; the one-pass kernel reads A2 only)
   const void* A2;   // bf16 [16 k-steps][2 halves][nc coeffs][8]:         B[i][c] in GEMM2's fragment k-order
   const float* y;   // [n_patches][256] the patches
   float lambda;
