@@ -416,12 +416,14 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
                         'achieved': 6.0 * w['D'] * esize * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s',
                         'what': 'state rows read and written per iteration; nowhere near the HBM roofline'}}
         if w['kind'] == 'sic':
-            # every leapfrog step of every 32-particle tile streams both 512 KB fragment orders of the dictionary
-            # from L2 (it cannot stay in a CU): the second bound of this kernel
-            tile_steps = agg[3] / 32.0 / iters
-            l2 = tile_steps * 2 * 512 * 1024 / (kern_it_ms * 1e-3) / 1e9
+            # one pass over the 512 KB dictionary per leapfrog step of a 32-particle tile, plus two per trajectory (the
+            # residual at its head, the closing half kick): L + 2 passes per L gradient evaluations, out of L2 (the
+            # dictionary cannot stay in a CU).  Rounds 1-2 streamed it twice per step.
+            tile_grads = agg[3] / 32.0 / iters
+            l2 = tile_grads * (w['L'] + 2.0) / w['L'] * 512 * 1024 / (kern_it_ms * 1e-3) / 1e9
             roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS,
-                          'what': 'dictionary bytes streamed from L2 per launch (1 MiB per tile and leapfrog step) / time'}
+                          'what': 'dictionary bytes streamed from L2 per launch (512 KiB per tile and dictionary pass, '
+                                  'L + 2 passes per trajectory) / time'}
     else:
         abytes = algorithmic_bytes_per_particle(w['D'], esize) * n_rank          # per sampling iteration
         hbm = {'achieved': abytes / (kern_it_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
