@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT/mjhmc_amd/csrc" || exit 2
 for v in "$@"; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -disable-machine-licm -DMJHMC_JUMP_WAVES=1 \
-      -DSICV=$v -c dense_sic.hip -o /tmp/sic_v$v.o 2>/dev/null && \
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libsic_v$v.so $(ls build/*.o | grep -v "asan_\|hooks_\|dense_sic.o") /tmp/sic_v$v.o -ldl && echo built v$v ) &
+      -DSICV=$v -c dense_sic.hip -o /tmp/sic_v$v.o 2>/tmp/sic_v$v.err && \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libsic_v$v.so $(ls build/*.o | grep -v "asan_\|hooks_\|dense_sic.o") /tmp/sic_v$v.o -ldl && echo built v$v || { echo "v$v FAILED:"; grep -m3 error /tmp/sic_v$v.err; } ) &
 done
 wait
