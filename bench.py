@@ -243,6 +243,8 @@ class Rig(object):
         return StoreRendezvous(self.rank, self.world)
 
     def _gloo(self, note):
+        if os.environ.get('MJHMC_BENCH_NOTE'):
+            note = os.environ['MJHMC_BENCH_NOTE']
         self.comm_note = note
         sys.stderr.write('rank %d: %s\n' % (self.rank, note))
         import torch.distributed as dist
@@ -548,12 +550,9 @@ def sample_gather_check(rig):
         return {'ok': False, 'error': repr(exc)[:300]}
 
 
-def spawn_ranks(args, argv):
-    """`python bench.py --gpus N` with WORLD_SIZE unset: this process touches no GPU and does not load the library; it
-    starts the N ranks as child processes (never exec), each with RANK / LOCAL_RANK / WORLD_SIZE, MASTER_ADDR / MASTER_PORT
-    (only the gloo safety net reads them) and MJHMC_COMM_ID_FILE = a path in a fresh directory through which rank 0
-    publishes the RCCL id; relays rank 0's stdout (the ONE JSON line), sends the other ranks' stdout to stderr, and exits
-    non-zero if any rank does (ending the others: a rank that died would leave them waiting at the rendezvous)."""
+def _run_ranks(args, argv, extra_env, time_limit):
+    """One attempt: start the N ranks, wait.  Returns (rc, timed_out, rank-0 stdout lines, all ranks' lines for
+    --spawn-check).  Rank 0's stdout is held back until the attempt is known to have succeeded."""
     import shutil
     import socket
     import tempfile
@@ -566,22 +565,21 @@ def spawn_ranks(args, argv):
 
     def relay(r, pipe):
         for line in iter(pipe.readline, b''):
-            if args.spawn_check:
+            if args.spawn_check or r == 0:
                 collected[r].append(line)
-            elif r == 0:
-                sys.stdout.buffer.write(line)
-                sys.stdout.buffer.flush()
             else:
                 sys.stderr.buffer.write(line)
                 sys.stderr.buffer.flush()
         pipe.close()
 
-    rc = 0
+    rc, timed_out = 0, False
+    t_start = time.time()
     try:
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MJHMC_COMM_ID_FILE=os.path.join(rdv_dir, 'comm.id'),
                        MJHMC_BENCH_SPAWNED='1')
+            env.update(extra_env)
             env.pop('TORCHELASTIC_USE_AGENT_STORE', None)
             p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE)
             procs.append(p)
@@ -598,6 +596,9 @@ def spawn_ranks(args, argv):
                     if code != 0:
                         rc = code if code > 0 else 1
                         sys.stderr.write('bench.py: rank %d exited with status %d; stopping the other ranks\n' % (r, code))
+            if alive and time_limit and time.time() - t_start > time_limit:
+                rc, timed_out = 124, True
+                sys.stderr.write('bench.py: the ranks did not finish within %.0f s; stopping them\n' % time_limit)
         for r in sorted(alive):                       # only after a failure: our own children, by pid
             procs[r].terminate()
         for p in procs:
@@ -608,11 +609,44 @@ def spawn_ranks(args, argv):
                 p.wait()
         for t in relays:
             t.join(timeout=10)
-        if args.spawn_check and rc == 0:
-            reports = [json.loads(b''.join(c).decode().strip().splitlines()[-1]) for c in collected]
-            print(json.dumps({'spawn_check': reports, 'n_gpus': n, 'rendezvous_dir_fresh': True}))
     finally:
         shutil.rmtree(rdv_dir, ignore_errors=True)
+    return rc, timed_out, collected
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: this process touches no GPU and does not load the library; it
+    starts the N ranks as child processes (never exec), each with RANK / LOCAL_RANK / WORLD_SIZE, MASTER_ADDR / MASTER_PORT
+    (only the gloo safety net reads them) and MJHMC_COMM_ID_FILE = a path in a fresh directory through which rank 0
+    publishes the RCCL id; prints rank 0's stdout (the ONE JSON line), sends the other ranks' stdout to stderr, and exits
+    non-zero if any rank does (ending the others: a rank that died would leave them waiting at the rendezvous).
+
+    A scaling run must yield its line even where RCCL does not come up: when the first attempt fails or does not finish
+    within MJHMC_BENCH_RCCL_TIMEOUT seconds (default 900: a hung collective cannot be cancelled from inside a rank), the
+    ranks are started once more with the barrier / MAX and the sample gather on torch.distributed gloo (host-staged),
+    and the line says so in config.comm_note.  The timed regions contain no collective either way."""
+    if args.spawn_check:
+        rc, _, collected = _run_ranks(args, argv, {}, 300.0)
+        if rc == 0:
+            reports = [json.loads(b''.join(c).decode().strip().splitlines()[-1]) for c in collected]
+            print(json.dumps({'spawn_check': reports, 'n_gpus': args.gpus, 'rendezvous_dir_fresh': True}))
+        return rc
+    forced = os.environ.get('MJHMC_BENCH_BACKEND')
+    limit = float(os.environ.get('MJHMC_BENCH_RCCL_TIMEOUT', '900'))
+    attempts = [({}, None)] if forced else [({}, limit), ({'MJHMC_BENCH_BACKEND': 'gloo'}, None)]
+    rc = 1
+    for k, (extra, lim) in enumerate(attempts):
+        if k:
+            extra = dict(extra, MJHMC_BENCH_NOTE='first attempt (RCCL) %s; this run: barrier / MAX / sample gather through '
+                                                 'torch.distributed gloo' % why)
+        rc, timed_out, collected = _run_ranks(args, argv, extra, lim)
+        if rc == 0:
+            sys.stdout.buffer.write(b''.join(collected[0]))
+            sys.stdout.buffer.flush()
+            return 0
+        why = 'did not finish within %.0f s' % lim if timed_out else 'failed with status %d' % rc
+        if k + 1 < len(attempts):
+            sys.stderr.write('bench.py: attempt %d %s; starting the ranks again on the gloo safety net\n' % (k + 1, why))
     return rc
 
 
