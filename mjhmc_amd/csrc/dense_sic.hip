@@ -137,8 +137,30 @@ struct SicShared {
   float colsum[kP];           // per-column energies, summed over a particle's columns when n_patches > 1
   int move[kP];
   unsigned tally[4];
+#if SICV == 30
+  unsigned stamp[4][8][8];    // timing build only
+#endif
 };
 static_assert(sizeof(SicShared) <= 160 * 1024, "LDS budget of a CU");
+
+// Timing build only (tools/sic_variants.sh 30t<k>): cycle stamps (s_memtime = core clock) of four of workgroup 0's waves at
+// position k of every round of a leapfrog step's pass; tools/sic_leap_time.py reads them, tools/sic_stamps_merge.py joins
+// the builds.  ONE position per build: a stamp costs ~150 cycles (s_memtime, its wait, the LDS write), seven per round
+// distort what they measure -- plus the entry into round 0, on which the builds are aligned.  Kept in LDS during the pass:
+// a global store would queue behind the dictionary requests it is supposed to time.
+#if SICV == 30
+#ifndef SICT
+#define SICT 1
+#endif
+__device__ unsigned g_sic_stamp[4][8][8];
+#define SIC_STAMP(RD, I)                                                                                     \
+  do {                                                                                                       \
+    if (((I) == SICT || ((I) == 0 && (RD) == 0)) && blockIdx.x == 0 && lane == 0 && (w & 2) == 0)            \
+      sh.stamp[(w & 1) | ((w >> 2) << 1)][RD][I] = (unsigned)__builtin_readcyclecounter();                   \
+  } while (0)
+#else
+#define SIC_STAMP(RD, I) do { } while (0)
+#endif
 
 // ---- the dictionary stream -----------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -180,18 +202,13 @@ struct AStream {
                        // the fragment, at k-step 2 w + (lane group & 1) and k-step-of-coefficients 0
 };
 
-// k-steps [K0, K1) of block T (compile time) of this wave into its image buffer
-template <int NB, int T, int K0 = 0, int K1 = 16>
+// block T (compile time) of this wave into its image buffer
+template <int NB, int T>
 __device__ __forceinline__ void issue_block(const AStream& s) {
   if (SICV == 4 || SICV == 9) return;
   const char* src = s.a2w + (T % NB) * 512;
 #pragma unroll
-  for (int ks = K0; ks < K1; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
-}
-template <int NB, int T>
-__device__ __forceinline__ void issue_piece(const AStream& s, int ks) {   // ks compile time after unrolling
-  if (SICV == 4 || SICV == 9) return;
-  glds16(s.a2w + (T % NB) * 512 + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
+  for (int ks = 0; ks < 16; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
 }
 
 template <int NB>
@@ -317,44 +334,33 @@ __device__ __forceinline__ void prior_kick(const SicModel& mdl, const f32x16& xb
   }
 }
 
-// G2 of an owner's round: acc (a block of V, or of dE/dX) += B^T[block] . (the scaled residual held in pubR).
-// The block image's sixteen k-step pieces were issued in order and are the wave's youngest vector-memory operations:
-// k-step ks has landed once at most 15 - ks operations are outstanding -- counted waits, so the later pieces may still
-// be in flight while the first MFMAs run (anything else outstanding only makes a wait longer: completion is in order).
-template <int KS>
-__device__ __forceinline__ void g2_wait() {
-  if (SICV == 7) return;
-  wait_vm<(15 - KS)>();
-}
+// G2 of an owner's round: acc (a block of V, or of dE/dX) += B^T[block] . (the scaled residual held in pubR)
 __device__ __forceinline__ void round_g2(SicShared& sh, const AStream& as, int lane, f32x16& acc) {
   using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
-  // the operands of k-step ks + kAhead are read before the MFMA of k-step ks; the fences keep hipcc from hoisting all the
+  // the operands of k-step ks + 1 are read before the MFMA of k-step ks; the fences keep hipcc from hoisting all the
   // reads to the top (registers) or sinking them to their uses (an LDS round trip in front of every MFMA)
   const unsigned base = as.img_own;
   const unsigned rb0 = lds_addr(&sh.pubR[0][0]) + 16u * (unsigned)lane;
-  constexpr int kAhead = 3;
+  // kAhead k-steps of operands in flight: during an owner's G2 its SIMD partner has no matrix work, so nothing but the
+  // wave's own earlier reads covers the LDS round trip
+  constexpr int kAhead = (SICV == 11) ? 2 : ((SICV == 12) ? 5 : 3);
   f32x4 fa[kAhead], fb[kAhead];
-  g2_wait<kAhead - 1>();
 #pragma unroll
   for (int k = 0; k < kAhead; ++k) {
     fa[k] = *(lds_f32x4*)(unsigned long)(base + (unsigned)k * 1024u + as.row[k & 1]);
     fb[k] = *(lds_f32x4*)(unsigned long)(rb0 + (unsigned)k * 1024u);
   }
-#define G2_STEP(KS)                                                                                                         \
-  {                                                                                                                         \
-    const f32x4 a = fa[(KS) % kAhead], b = fb[(KS) % kAhead];                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    if ((KS) + kAhead < 16) {                                                                                               \
-      g2_wait<((KS) + kAhead < 16 ? (KS) + kAhead : 15)>();                                                                 \
-      fa[(KS) % kAhead] = *(lds_f32x4*)(unsigned long)(base + (unsigned)((KS) + kAhead) * 1024u + as.row[((KS) + kAhead) & 1]); \
-      fb[(KS) % kAhead] = *(lds_f32x4*)(unsigned long)(rb0 + (unsigned)((KS) + kAhead) * 1024u);                            \
-    }                                                                                                                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const f32x4 a = fa[ks % kAhead], b = fb[ks % kAhead];
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + kAhead < 16) {
+      fa[ks % kAhead] = *(lds_f32x4*)(unsigned long)(base + (unsigned)(ks + kAhead) * 1024u + as.row[(ks + kAhead) & 1]);
+      fb[ks % kAhead] = *(lds_f32x4*)(unsigned long)(rb0 + (unsigned)(ks + kAhead) * 1024u);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  G2_STEP(0) G2_STEP(1) G2_STEP(2) G2_STEP(3) G2_STEP(4) G2_STEP(5) G2_STEP(6) G2_STEP(7)
-  G2_STEP(8) G2_STEP(9) G2_STEP(10) G2_STEP(11) G2_STEP(12) G2_STEP(13) G2_STEP(14) G2_STEP(15)
-#undef G2_STEP
 }
 
 __device__ __forceinline__ f32x4 frag_scaled(const f32x16& acc, int s, float scale) {
@@ -365,11 +371,8 @@ __device__ __forceinline__ f32x4 frag_scaled(const f32x16& acc, int s, float sca
 }
 
 // G1 of one round: R += B[this wave's 32 pixel rows, the round's four blocks] . X(those blocks)
-// LATE != 0: this wave owned the previous round and still has the second half of its next block's image to request --
-// one LDS-DMA piece beside each of the eight MFMAs (sixteen requests back to back cost the issuing wave ~1000+ cycles
-// in which the other group waits for it at the round's barrier)
-template <int RD, int NB, int TNEXT>
-__device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int lane, RTile& R, bool late) {
+template <int RD>
+__device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int lane, RTile& R) {
   using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
   using lds_i16x4 = __attribute__((address_space(3))) i16x4;
   const unsigned img0 = lds_addr(&sh.img[RD & 1][0][0][0]);
@@ -393,7 +396,6 @@ __device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int l
     nxf = xf;
     if (n + 1 < 2 * kG) ops_of(n + 1, nlo, nhi, nxf);
     const auto a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    if (late) issue_piece<NB, TNEXT>(as, 8 + n);
     R.b[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, xf), R.b[0], 0, 0, 0);
     if (SICV != 10) __builtin_amdgcn_sched_barrier(0);
     lo = nlo;
@@ -408,17 +410,14 @@ template <int KIND, bool CAUCHY, int NB, int RD>
 __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int lane,
                                            CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
   constexpr int T = RD >> 1;
-  const bool own = __builtin_amdgcn_readfirstlane(w >> 2) == (RD & 1);   // wave-uniform, and the compiler knows it
-  // the previous round's owners request the second half of their next block during THIS round's G1 -- when this pass has
-  // one and the round is not the pass's first (the requests made in a pass's last two rounds are whole blocks)
-  constexpr bool kSplitPrev = KIND != kPassG2 && RD >= 1;             // round RD - 1 requested only k-steps 0..7
-  constexpr bool kSplitThis = KIND != kPassG2 && RD + 1 < 2 * NB;     // this round's owners request k-steps 0..7 now
+  const bool own = (w >> 2) == (RD & 1);   // wave-uniform
+  if constexpr (KIND == kPassFused) SIC_STAMP(RD, 0);
   if (own) {
+    if (SICV != 7) wait_vm<0>();                // this wave's block image has landed (issued a round ago)
     if constexpr (KIND != kPassG1) {
       if (SICV != 2 && SICV != 9) round_g2(sh, as, lane, acc.b[T]);
-    } else {
-      g2_wait<15>();             // no G2 in this pass: the whole image before the barrier
     }
+    if constexpr (KIND == kPassFused) SIC_STAMP(RD, 1);
     if constexpr (KIND == kPassG2) {
       issue_block<NB, T + 1>(as);   // nobody else reads this image in a kick-only pass
     } else {
@@ -427,21 +426,21 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
         sh.pubX[w & 3][0][lane] = frag_scaled(x.b[T], 0, 1.0f);
         sh.pubX[w & 3][1][lane] = frag_scaled(x.b[T], 1, 1.0f);
       }
-      g2_wait<15>();             // every piece of this wave's image has landed before the others read it
     }
   } else if constexpr (KIND != kPassG1 && RD + 1 < 2 * NB) {
     // beside the owners' matrix work: the prior's force of the block this wave owns in the NEXT round
     if (SICV != 5 && SICV != 9) prior_kick<CAUCHY>(mdl, x.b[(RD + 1) >> 1], scale, acc.b[(RD + 1) >> 1]);
   }
   if constexpr (KIND == kPassG2) return;
+  if constexpr (KIND == kPassFused) SIC_STAMP(RD, 2);
   if (SICV != 3) __syncthreads();               // barrier A: the round's four images have landed, their X blocks are published
-  // (the non-owners of this round owned the previous one: block index of their next block = (RD - 1) / 2 + 1)
-  if (SICV != 1 && SICV != 9) round_g1<RD, NB, ((RD - 1) >> 1) + 1>(sh, as, lane, R, kSplitPrev && !own);
+  if constexpr (KIND == kPassFused) SIC_STAMP(RD, 3);
+  if (SICV != 1 && SICV != 9) round_g1<RD>(sh, as, lane, R);
+  if constexpr (KIND == kPassFused) SIC_STAMP(RD, 4);
   if (SICV != 3) __syncthreads();               // barrier B: the round's images and X fragments have been read by every wave
-  if (own) {                                    // the owner's next block: lands during the other group's round
-    if constexpr (kSplitThis) issue_block<NB, T + 1, 0, 8>(as);
-    else issue_block<NB, T + 1>(as);
-  }
+  if constexpr (KIND == kPassFused) SIC_STAMP(RD, 5);
+  if (own) issue_block<NB, T + 1>(as);   // the owner's next block (of the next pass after the last one): lands during the other group's round
+  if constexpr (KIND == kPassFused) SIC_STAMP(RD, 6);
 }
 
 template <int KIND, bool CAUCHY, int NB, int RD>
@@ -471,6 +470,12 @@ __device__ __forceinline__ void sic_pass(const SicModel& mdl, SicShared& sh, con
   }
   if constexpr (KIND != kPassG2) resid_init(mdl, sh, w, h, c, patch, R);
   Rounds<KIND, CAUCHY, NB, 0>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps);
+#if SICV == 30
+  if constexpr (KIND == kPassFused) {   // (the last pass run wins)
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 256) (&g_sic_stamp[0][0][0])[threadIdx.x] = (&sh.stamp[0][0][0])[threadIdx.x];
+  }
+#endif
   if constexpr (KIND == kPassG2) __syncthreads();   // every wave's G2 reads of pubR are done before the next pass rewrites it
 }
 
@@ -852,6 +857,14 @@ __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, c
   }
   astream_close();
 }
+
+#if SICV == 30
+}  // namespace mjhmc
+extern "C" int mjhmc_sic_stamps(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mjhmc::g_sic_stamp), sizeof(mjhmc::g_sic_stamp));
+}
+namespace mjhmc {
+#endif
 
 static int sic_cus() {
   int dev = 0, cus = 0;

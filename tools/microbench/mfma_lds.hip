@@ -1,0 +1,157 @@
+// Micro-benchmarks behind DESIGN.md section 3.5: what one CU of an MI355X does with the instruction mix of the
+// SparseImageCode rounds.  Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_lds tools/microbench/mfma_lds.hip
+// Each test: one workgroup per CU, N iterations of a loop body, cycles (s_memtime) per iteration on wave 0 and the
+// wall-clock time of the launch (hipEvents), which calibrates the cycle counter.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int kIter = 20000;
+
+// MODE 0: dependent MFMA chain, no memory.  1: two independent chains in one wave.  2: chain + G2-like reads (2 x b128,
+// 3 ahead).  3: chain + G1-like reads (2 x tr_b64 + b128, 3 ahead).  4: like 3 plus 5 VALU instructions with a v_rcp.
+// 5: G1-like reads only, no MFMA.  6: G2-like reads only.
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+// MODE 7: G1 mix + one 1 KB LDS-DMA request per two MFMAs (the kernel's ratio).  8: G1 reads + the DMA, no MFMA.
+// 9: the DMA alone.  10: G1 mix + one DMA per MFMA.
+template <int MODE>
+__global__ __launch_bounds__(512) void bench(unsigned long long* out, float* sink, const char* src = nullptr) {
+  extern __shared__ f32x4 lds[];   // 128 KB
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+  __syncthreads();
+  using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
+  using lds_i16x4 = __attribute__((address_space(3))) i16x4;
+  const unsigned sh0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)lds;
+  const unsigned row = sh0 + 16u * lane + 16384u * w;          // conflict-free b128
+  const unsigned tr0 = sh0 + 16u * lane + 16384u * w, tr1 = tr0 + 8u;
+  f32x16 acc = {}, acc2 = {};
+  f32x4 fa[3], fb[3];
+  i16x4 lo[3], hi[3];
+  float side = (float)lane;
+  auto g2_ops = [&](int k, f32x4& a, f32x4& b) {
+    a = *(lds_f32x4*)(unsigned long)(row + (unsigned)(k & 7) * 1024u);
+    if (MODE != 11) b = *(lds_f32x4*)(unsigned long)(row + (unsigned)(k & 7) * 1024u + 8192u);
+  };
+  auto g1_ops = [&](int k, i16x4& l, i16x4& h, f32x4& b) {
+    l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(unsigned long)(tr0 + (unsigned)(k & 7) * 1024u));
+    h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(unsigned long)(tr1 + (unsigned)(k & 7) * 1024u));
+    b = *(lds_f32x4*)(unsigned long)(row + (unsigned)(k & 7) * 1024u + 8192u);
+  };
+  for (int k = 0; k < 3; ++k) {
+    if (MODE == 2 || MODE == 6 || MODE == 11) { fb[k] = f32x4{4, 3, 2, 1}; g2_ops(k, fa[k], fb[k]); }
+    if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8 || MODE == 10) g1_ops(k, lo[k], hi[k], fb[k]);
+    if (MODE < 2 || MODE == 9) { fa[k] = f32x4{1, 2, 3, 4}; fb[k] = f32x4{4, 3, 2, 1}; lo[k] = i16x4{1, 2, 3, 4}; hi[k] = lo[k]; }
+  }
+  __syncthreads();
+  const char* my = (const char*)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long)src >> 32)) << 32) |
+                                (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long)src)) + 65536 * w;
+  const unsigned dma_dst = __builtin_amdgcn_readfirstlane(sh0 + 65536u + 8192u * w);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int it = 0; it < kIter; it += 6) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int s = u % 3;
+      if (MODE == 9) {
+        glds16(my + 1024 * ((it + u) & 63), 16u * lane, dma_dst + 1024u * (u & 7));
+        continue;
+      }
+      if (MODE == 2 || MODE == 6 || MODE == 11) {
+        const f32x4 a = fa[s], b = fb[s];
+        __builtin_amdgcn_sched_barrier(0);
+        g2_ops(u + 3, fa[s], fb[s]);
+        if (MODE == 2 || MODE == 11) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        else { acc[0] += a[0] + b[0]; }
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (MODE >= 3) {
+        const i16x4 l = lo[s], h = hi[s];
+        const f32x4 b = fb[s];
+        __builtin_amdgcn_sched_barrier(0);
+        g1_ops(u + 3, lo[s], hi[s], fb[s]);
+        const auto a8 = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (MODE != 5 && MODE != 8) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        else { acc[0] += (float)l[0] + (float)h[0] + b[0]; }
+        if ((MODE == 7 || MODE == 8) && (u & 1)) glds16(my + 1024 * ((it + u) & 63), 16u * lane, dma_dst + 1024u * (u & 7));
+        if (MODE == 10) glds16(my + 1024 * ((it + u) & 63), 16u * lane, dma_dst + 1024u * (u & 7));
+        if (MODE == 4) side += 0.5f * side * __builtin_amdgcn_rcpf(1.0f + side * side);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s]), __builtin_bit_cast(bf16x8, fb[s]), acc, 0, 0, 0);
+        if (MODE == 1)
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[s]), __builtin_bit_cast(bf16x8, fa[s]), acc2, 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float r = side;
+  for (int q = 0; q < 16; ++q) r += acc[q] + acc2[q];
+  sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* what, int threads, int ncu, unsigned long long* d_out, float* d_sink, const char* d_src = nullptr) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  CHECK(hipFuncSetAttribute((const void*)bench<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  bench<MODE><<<ncu, threads, 128 * 1024>>>(d_out, d_sink, d_src);   // warm-up
+  CHECK(hipEventRecord(e0));
+  bench<MODE><<<ncu, threads, 128 * 1024>>>(d_out, d_sink, d_src);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipDeviceSynchronize());
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned long long cyc = 0;
+  CHECK(hipMemcpy(&cyc, d_out, 8, hipMemcpyDeviceToHost));
+  const int per = (MODE == 1) ? 2 : 1;
+  printf("%-58s waves/SIMD %d: %7.1f counts/iteration (%d MFMA each), launch %.3f ms -> counter %.2f GHz, %.1f ns/iteration\n", what,
+         threads / 256, (double)cyc / kIter, per, ms, cyc / (ms * 1e6), ms * 1e6 / kIter);
+}
+
+int main() {
+  hipDeviceProp_t p;
+  CHECK(hipGetDeviceProperties(&p, 0));
+  const int ncu = p.multiProcessorCount;
+  printf("%s, %d CUs, clock %d MHz\n", p.name, ncu, p.clockRate / 1000);
+  unsigned long long* d_out; float* d_sink;
+  CHECK(hipMalloc(&d_out, 64)); CHECK(hipMalloc(&d_sink, sizeof(float) * 512 * ncu));
+  for (int threads : {256, 512}) {
+    run<0>("dependent MFMA chain", threads, ncu, d_out, d_sink);
+    run<1>("two independent MFMA chains in one wave", threads, ncu, d_out, d_sink);
+    run<2>("chain + 2 x ds_read_b128 per MFMA (G2)", threads, ncu, d_out, d_sink);
+    run<3>("chain + 2 x ds_read_b64_tr_b16 + ds_read_b128 (G1)", threads, ncu, d_out, d_sink);
+    run<4>("G1 mix + 5 VALU with a v_rcp", threads, ncu, d_out, d_sink);
+    run<5>("G1 reads only", threads, ncu, d_out, d_sink);
+    run<6>("G2 reads only", threads, ncu, d_out, d_sink);
+    run<11>("chain + ONE ds_read_b128 per MFMA", threads, ncu, d_out, d_sink);
+  }
+  char* d_src;
+  CHECK(hipMalloc(&d_src, 1 << 20)); CHECK(hipMemset(d_src, 0, 1 << 20));
+  for (int threads : {256, 512}) {
+    run<7>("G1 mix + one 1 KB LDS-DMA per two MFMAs", threads, ncu, d_out, d_sink, d_src);
+    run<10>("G1 mix + one 1 KB LDS-DMA per MFMA", threads, ncu, d_out, d_sink, d_src);
+    run<8>("G1 reads + one LDS-DMA per two steps, no MFMA", threads, ncu, d_out, d_sink, d_src);
+    run<9>("LDS-DMA alone (1 KB per iteration and wave)", threads, ncu, d_out, d_sink, d_src);
+  }
+  // one CU only: is it the chip's power limit or the CU?
+  run<3>("G1 mix, ONE workgroup on the whole chip", 512, 1, d_out, d_sink);
+  run<0>("dependent chain, ONE workgroup on the whole chip", 512, 1, d_out, d_sink);
+  return 0;
+}
