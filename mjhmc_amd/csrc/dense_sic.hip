@@ -329,7 +329,9 @@ __device__ __forceinline__ void prior_kick(const SicModel& mdl, const f32x16& xb
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const float a = xb[q];
-    if (CAUCHY) acc[q] += (sl * 2.0f) * a * __builtin_amdgcn_rcpf(1.0f + a * a);  // v_rcp_f32: 1 ulp
+    // v_rcp_f32: 1 ulp.  Explicit FMAs (the file is compiled without contraction): this is on the critical path of a
+    // round -- the waves that run it have just stood at the vector-memory port for their 16 requests
+    if (CAUCHY) acc[q] = __builtin_fmaf((sl * 2.0f) * a, __builtin_amdgcn_rcpf(__builtin_fmaf(a, a, 1.0f)), acc[q]);
     else acc[q] += sl * (a > 0.f ? 1.0f : (a < 0.f ? -1.0f : 0.0f));
   }
 }
