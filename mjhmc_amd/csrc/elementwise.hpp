@@ -853,13 +853,13 @@ __device__ __forceinline__ double horner_sc(double r, double p, double c) {
   return p;
 }
 
-template <bool FENCED = true>
+template <bool FENCED = true, bool SC = !FENCED>
 __device__ __forceinline__ double exp_normal(double h) {
   if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);  // chain kept compact inside decide(): measured faster
   const double n = __builtin_rint(h * __longlong_as_double(0x3ff71547652b82feLL));        // h / ln 2
   double r = __builtin_fma(n, __longlong_as_double(0xbfe62e42fefa39efLL), h);             // - n ln2 (hi, lo)
   r = __builtin_fma(n, __longlong_as_double(0xbc7abc9e3b39803fLL), r);
-  if constexpr (!FENCED) {  // the funnel's force: this chain runs once per leapfrog step (decide()'s form below was
+  if constexpr (SC) {  // the funnel's force: this chain runs once per leapfrog step (decide()'s form below was
                             // measured faster there as it stands)
     double q = r * __longlong_as_double(0x3e5ade156a5dcb37LL) + __longlong_as_double(0x3e928af3fca7ab0cLL);
     q = horner_sc(r, q, __longlong_as_double(0x3ec71dee623fde64LL));
@@ -872,7 +872,9 @@ __device__ __forceinline__ double exp_normal(double h) {
     q = horner_sc(r, q, __longlong_as_double(0x3fe000000000000bLL));
     q = __builtin_fma(r, q, 1.0);
     q = __builtin_fma(r, q, 1.0);
-    return __builtin_amdgcn_ldexp(q, (int)n);
+    const double yq = __builtin_amdgcn_ldexp(q, (int)n);
+    if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);
+    return yq;
   }
   double p = r * __longlong_as_double(0x3e5ade156a5dcb37LL) + __longlong_as_double(0x3e928af3fca7ab0cLL);
   p = __builtin_fma(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
@@ -927,9 +929,12 @@ __device__ __forceinline__ float exp_neg(float x) { return expf(-x); }
 // overflows (-> inf -> the non-finite abort), is subnormal (its square root then has the reference's coarse
 // rounding) or is 0, and for NaN, the literal two-step form runs: thresholds and special values are exactly
 // those of the reference expression.
+// SC: the polynomial's constants in scalar registers (one particle per wave: the kernel is bound by its vector
+// instruction count, and hipcc's own Horner step is three vector instructions)
+template <bool SC = false>
 __device__ __forceinline__ double jump_rate(double dH) {
   if (!(dH > -708.0 && dH < 709.0)) return sqrt(exp(dH));
-  return exp_normal(0.5 * dH);
+  return exp_normal<true, SC>(0.5 * dH);
 }
 
 __device__ __forceinline__ double wait_time(double rate, double e, bool& bad) {
@@ -1065,7 +1070,8 @@ __device__ __forceinline__ void decide(const JumpArgs<T>& a, const RngKey& key, 
   if (m.G >= 4) {
     const int role = m.j;  // 0: L clock, 1: R clock (and the FLF rate), 2..: F clock
     const T dH = H0 - ((role == 1) ? Hflf : HL);
-    const double rate01 = jump_rate((double)dH);  // exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347)
+    // exp(H1 - H2) ** .5 (markov_jump_hmc.py:341-347)
+    const double rate01 = (m.wpp == 1) ? jump_rate<true>((double)dH) : jump_rate<false>((double)dH);
     l_rate = group_lane(rate01, m, 0);
     const double flf_rate = group_lane(rate01, m, 1);
     const double mn = (flf_rate != flf_rate || l_rate != l_rate) ? __builtin_nan("") : fmin(flf_rate, l_rate);
