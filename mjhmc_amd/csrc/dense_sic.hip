@@ -410,7 +410,7 @@ __device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int l
 // to group RD & 1: each of its four waves owns block RD >> 1 of its coefficient rows.
 template <int KIND, bool CAUCHY, int NB, int RD>
 __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int lane,
-                                           CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
+                                           CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps, float next_scale) {
   constexpr int T = RD >> 1;
   const bool own = (w >> 2) == (RD & 1);   // wave-uniform
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 0);
@@ -432,6 +432,13 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
   } else if constexpr (KIND != kPassG1 && RD + 1 < 2 * NB) {
     // beside the owners' matrix work: the prior's force of the block this wave owns in the NEXT round
     if (SICV != 5 && SICV != 9) prior_kick<CAUCHY>(mdl, x.b[(RD + 1) >> 1], scale, acc.b[(RD + 1) >> 1]);
+  } else if constexpr (KIND != kPassG2 && RD + 1 == 2 * NB) {
+    // the pass's last round: group 0 has no next block in this pass -- the prior's force of its block 0 for the NEXT kick
+    // (x's block 0 is final since round 0, and so is this pass's kick of it); at the head of that pass it would stand
+    // alone, 400 cycles with the other group waiting at the barrier.  next_scale == 0: no kick follows
+    if (next_scale != 0.f) {
+      if (SICV != 5 && SICV != 9) prior_kick<CAUCHY>(mdl, x.b[0], next_scale, acc.b[0]);
+    }
   }
   if constexpr (KIND == kPassG2) return;
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 2);
@@ -448,18 +455,21 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
 template <int KIND, bool CAUCHY, int NB, int RD>
 struct Rounds {
   static __device__ __forceinline__ void run(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int lane,
-                                             CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
-    pass_round<KIND, CAUCHY, NB, RD>(mdl, sh, as, w, lane, x, acc, R, scale, eps);
-    if constexpr (RD + 1 < 2 * NB) Rounds<KIND, CAUCHY, NB, RD + 1>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps);
+                                             CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps, float next_scale) {
+    pass_round<KIND, CAUCHY, NB, RD>(mdl, sh, as, w, lane, x, acc, R, scale, eps, next_scale);
+    if constexpr (RD + 1 < 2 * NB) Rounds<KIND, CAUCHY, NB, RD + 1>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps, next_scale);
   }
 };
 
 // kPassG1:    R = B x - y.
 // kPassFused: acc (= V) += scale * dE/dX at the x whose residual is R;  x += eps * V;  R = B x - y at the new x.
 // kPassG2:    acc += scale * dE/dX at the x whose residual is R (x, R unchanged).
-template <int KIND, bool CAUCHY, int NB>
+// HEAD_PRIOR: group 0's block-0 prior force is added at the head of this (kick) pass; false when the pass before has
+// done it in its last round (its `next_scale` = this pass's scale; 0 = no kick pass follows).
+template <int KIND, bool CAUCHY, int NB, bool HEAD_PRIOR = true>
 __device__ __forceinline__ void sic_pass(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h, int lane,
-                                         int patch, CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps) {
+                                         int patch, CTile<NB>& x, CTile<NB>& acc, RTile& R, float scale, float eps,
+                                         float next_scale = 0.f) {
   if constexpr (KIND != kPassG1) {
     // the residual, scaled by the step and by 1 / n_patches (d/da_p of the MEAN over patches), as the B operand of G2:
     // every wave publishes its two k-steps (the last readers of pubR were the G2 rounds of the previous kick pass, which
@@ -467,11 +477,11 @@ __device__ __forceinline__ void sic_pass(const SicModel& mdl, SicShared& sh, con
     const float sc = scale * mdl.invP;
     sh.pubR[2 * w + 0][lane] = frag_scaled(R.b[0], 0, sc);
     sh.pubR[2 * w + 1][lane] = frag_scaled(R.b[0], 1, sc);
-    if ((w >> 2) == 0) prior_kick<CAUCHY>(mdl, x.b[0], scale, acc.b[0]);   // group 0 owns round 0: nobody to do it beside
+    if (HEAD_PRIOR && (w >> 2) == 0) prior_kick<CAUCHY>(mdl, x.b[0], scale, acc.b[0]);   // group 0 owns round 0: nobody to do it beside
     __syncthreads();
   }
   if constexpr (KIND != kPassG2) resid_init(mdl, sh, w, h, c, patch, R);
-  Rounds<KIND, CAUCHY, NB, 0>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps);
+  Rounds<KIND, CAUCHY, NB, 0>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps, next_scale);
 #if SICV == 30
   if constexpr (KIND == kPassFused) {   // (the last pass run wins)
     __syncthreads();
@@ -554,7 +564,7 @@ template <bool CAUCHY, int NB>
 __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
                                                 int lane, const Col& col, CTile<NB>& x, CTile<NB>& v, RTile& R, int L,
                                                 float eps, float chalf) {
-  sic_pass<kPassG1, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, 0.f, 0.f);
+  sic_pass<kPassG1, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, 0.f, 0.f, L > 0 ? chalf : 0.f);
   if (L > 0) {
     // the step scale is wave-uniform: both values sit in scalar registers, the select is an integer s_cselect
     const int c_half = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, chalf));
@@ -563,11 +573,12 @@ __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& 
     for (int s = 1; s <= L; ++s) {
       asm volatile("; MJHMC_LEAPFROG_STEP_BEGIN (tools/check_isa.sh)");
       // kick (half the first time, two merged halves afterwards), drift, residual at the new position
-      sic_pass<kPassFused, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R,
-                                        __builtin_bit_cast(float, s == 1 ? c_half : c_full), eps);
+      sic_pass<kPassFused, CAUCHY, NB, false>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R,
+                                               __builtin_bit_cast(float, s == 1 ? c_half : c_full), eps,
+                                               __builtin_bit_cast(float, s == L ? c_half : c_full));
       asm volatile("; MJHMC_LEAPFROG_STEP_END");
     }
-    sic_pass<kPassG2, CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, chalf, 0.f);   // closing half kick
+    sic_pass<kPassG2, CAUCHY, NB, false>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, chalf, 0.f);   // closing half kick
   }
   // the successor position is stored in bf16 (and G1 already saw bf16(x)): evaluate the prior on
   // what will be stored, so EX is the energy of the stored state
