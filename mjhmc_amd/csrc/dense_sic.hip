@@ -202,14 +202,31 @@ struct AStream {
                        // the fragment, at k-step 2 w + (lane group & 1) and k-step-of-coefficients 0
 };
 
-// block T (compile time) of this wave into its image buffer
-template <int NB, int T>
+// k-steps [K0, K1) of block T (compile time) of this wave into its image buffer
+template <int NB, int T, int K0 = 0, int K1 = 16>
 __device__ __forceinline__ void issue_block(const AStream& s) {
   if (SICV == 4 || SICV == 9) return;
   const char* src = s.a2w + (T % NB) * 512;
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
+  for (int ks = K0; ks < K1; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
 }
+// the same for the wave's SIMD partner (wave w ^ 4, the other group): DIR = +1 from group 0, -1 from group 1
+template <int NB, int T, int K0, int K1, int DIR>
+__device__ __forceinline__ void issue_partner(const AStream& s) {
+  if (SICV == 4 || SICV == 9) return;
+  const char* src = s.a2w + (long)DIR * (long)(4 * 32 * NB * 16) + (T % NB) * 512;
+  const unsigned img = s.img_own + (unsigned)(DIR * 4 * 16384);
+#pragma unroll
+  for (int ks = K0; ks < K1; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], img + (unsigned)ks * 1024u);
+}
+// A step's pass: of the sixteen requests of an owner's next block the last 16 - kOwnPieces are made by its SIMD partner.
+// The waves that request stand at the vector-memory port (64 B/clk per CU: ~58 cycles per request with four waves
+// asking) and then run the prior's force: ~1300 cycles to barrier A where this round's owners need ~1000 (G2, drift,
+// publish) and wait.  The owners take over the tail of the burst after their publish.
+#ifndef SIC_OWN_PIECES
+#define SIC_OWN_PIECES ((SICV >= 70 && SICV <= 86) ? (SICV - 70) : 12)   // (timing builds 70..86: 0..16)
+#endif
+constexpr int kOwnPieces = SIC_OWN_PIECES;
 
 template <int NB>
 __device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& sh, int w, int lane) {
@@ -428,6 +445,10 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
         sh.pubX[w & 3][0][lane] = frag_scaled(x.b[T], 0, 1.0f);
         sh.pubX[w & 3][1][lane] = frag_scaled(x.b[T], 1, 1.0f);
       }
+      // the tail of the partner's request burst (it owned round RD - 1 and asked for block (RD - 1) / 2 + 1 after that
+      // round's barrier B); landed before barrier B of this round, after which the partner's G2 reads the image
+      if constexpr (KIND == kPassFused && RD >= 1 && kOwnPieces < 16)
+        issue_partner<NB, ((RD - 1) >> 1) + 1, kOwnPieces, 16, (RD & 1) ? -1 : 1>(as);
     }
   } else if constexpr (KIND != kPassG1 && RD + 1 < 2 * NB) {
     // beside the owners' matrix work: the prior's force of the block this wave owns in the NEXT round
@@ -446,9 +467,15 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 3);
   if (SICV != 1 && SICV != 9) round_g1<RD>(sh, as, lane, R);
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 4);
+  if constexpr (KIND == kPassFused && RD >= 1 && kOwnPieces < 16) {
+    if (own) wait_vm<0>();                      // (the partner's pieces: requested at least a whole G1 ago)
+  }
   if (SICV != 3) __syncthreads();               // barrier B: the round's images and X fragments have been read by every wave
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 5);
-  if (own) issue_block<NB, T + 1>(as);   // the owner's next block (of the next pass after the last one): lands during the other group's round
+  if (own) {   // the owner's next block (of the next pass after the last one): lands during the other group's round
+    if constexpr (KIND == kPassFused && RD + 1 < 2 * NB) issue_block<NB, T + 1, 0, kOwnPieces>(as);
+    else issue_block<NB, T + 1>(as);
+  }
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 6);
 }
 
