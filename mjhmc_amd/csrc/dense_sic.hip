@@ -28,7 +28,10 @@
 //                                                                                                        (barrier A)
 //     all 8    G1   resid'[32 w ..] += B[32 w .., the round's four blocks] . X(those blocks):  8 MFMAs per wave,
 //              A = the SAME LDS images read TRANSPOSED (ds_read_b64_tr_b16)                            (barrier B)
-//     owners   start the LDS-DMA of their next block into the image they have just finished with
+//     owners   start the LDS-DMA of their next block into the image they have just finished with (a step's pass: the
+//              first 12 of its 16 requests -- the SIMD partner makes the other 4 after ITS publish in the next round: the
+//              requesting waves stand at the vector-memory port, 64 B/clk per CU, and their path to barrier A was the
+//              longer one; DESIGN.md section 3.5 has the cycle accounting)
 //   so the kick of step n (residual of step n) and the residual of step n + 1 come out of one stream of the dictionary:
 //   L + 2 passes per trajectory instead of 2 L + 2.  Image buffers: 2 groups x 4 owners x 16 KB of LDS, filled by
 //   `global_load_lds_dwordx4` (no VGPR destination) while the OTHER group's round runs -- across rounds, passes and tiles.
