@@ -172,6 +172,12 @@ __device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const floa
   f32x4 bnext = bbase[lane];
 #pragma unroll 1
   for (int chunk = 0; chunk < NCH; chunk += 2) {
+#if defined(POTV) && POTV == 1   // timing build: no A loads (the MFMAs run on stale registers)
+    if (chunk == 0) a_chunk_load<NB>(mlane, 1, a1);
+    chunk_mfma<NB>(bbase, chunk, lane, a0, bnext, acc);
+    chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
+    continue;
+#endif
     a_chunk_load<NB>(mlane, chunk + 1, a1);
     __builtin_amdgcn_sched_barrier(0);
     chunk_mfma<NB>(bbase, chunk, lane, a0, bnext, acc);
@@ -263,6 +269,18 @@ struct Shared {
   int move[kP];           // transition chosen per particle
 };
 
+// Timing build only (-DPOT_STAMPS, tools/pot_stamps.sh): cycle stamps of workgroup 0's waves around the parts of a
+// gradient evaluation (the last one run wins).  Six stamps per ~170 000-cycle gradient: they do not disturb what they time.
+#ifdef POT_STAMPS
+__device__ unsigned long long g_pot_stamp[4][8];
+#define POT_STAMP(I)                                                                                  \
+  do {                                                                                                \
+    if (blockIdx.x == 0 && lane == 0) g_pot_stamp[w][I] = __builtin_readcyclecounter();              \
+  } while (0)
+#else
+#define POT_STAMP(I) do { } while (0)
+#endif
+
 // gradient of the energy at the X held in `x`; optionally the energy itself.
 // On return g holds dE/dX in the same layout as x.  Two barriers (X and H live in separate buffers:
 // a wave can only reach the next publish of a buffer after every wave has passed the barrier that
@@ -271,11 +289,14 @@ template <int NB>
 __device__ __forceinline__ void pot_gradient(const PotModel& mdl, AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
                                              int lane, const Tile<NB>& x, Tile<NB>& g, bool want_energy,
                                              float* energy_out) {
+  POT_STAMP(0);
   publish<NB>(sh.pub[0][w], lane, x);
   __syncthreads();
+  POT_STAMP(1);
   Tile<NB> u;
   rowvec_load<NB>(mdl.cb, w, h, u);                    // u starts at b_j / nu_j
   gemm_any<NB, false>(mdl, ar, sh.pub[0], w, c, h, lane, u);   // + sum_d W[d][j]/nu_j * x_d
+  POT_STAMP(2);
   if (want_energy) {                                   // E = sum_j alpha_j log(1 + u_j^2)  (distributions.py:430-432)
     using V = typename VecN<NB>::type;
     const float* al = mdl.alpha + 32 * NB * w;
@@ -297,12 +318,15 @@ __device__ __forceinline__ void pot_gradient(const PotModel& mdl, AReg<NB>& ar, 
       u.b[r][q] = uu * __builtin_amdgcn_rcpf(1.0f + uu * uu);   // phi(u) (v_rcp_f32: 1 ulp); the factor (nu+1)/nu lives in W2T
     }
   publish<NB>(sh.pub[1][w], lane, u);
+  POT_STAMP(3);
   __syncthreads();
+  POT_STAMP(4);
 #pragma unroll
   for (int r = 0; r < NB; ++r)
 #pragma unroll
     for (int q = 0; q < 16; ++q) g.b[r][q] = 0.f;
   gemm_any<NB, true>(mdl, ar, sh.pub[1], w, c, h, lane, g);
+  POT_STAMP(5);
   if (want_energy && energy_out) {
     *energy_out = sh.red[0][0][c] + sh.red[0][1][c] + sh.red[0][2][c] + sh.red[0][3][c];
   }
@@ -612,6 +636,14 @@ __global__ __launch_bounds__(256, 1) void pot_leap_kernel(const PotLeapArgs a, c
     __syncthreads();
   }
 }
+
+#ifdef POT_STAMPS
+}  // namespace mjhmc
+extern "C" int mjhmc_pot_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mjhmc::g_pot_stamp), sizeof(mjhmc::g_pot_stamp));
+}
+namespace mjhmc {
+#endif
 
 static int resident_cus() {
   int dev = 0, cus = 0;
