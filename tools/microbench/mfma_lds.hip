@@ -44,6 +44,7 @@ __global__ __launch_bounds__(512) void bench(unsigned long long* out, float* sin
   f32x4 fa[3], fb[3];
   i16x4 lo[3], hi[3];
   float side = (float)lane;
+  float sv[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
   auto g2_ops = [&](int k, f32x4& a, f32x4& b) {
     a = *(lds_f32x4*)(unsigned long)(row + (unsigned)(k & 7) * 1024u);
     if (MODE != 11) b = *(lds_f32x4*)(unsigned long)(row + (unsigned)(k & 7) * 1024u + 8192u);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(512) void bench(unsigned long long* out, float* sin
   for (int k = 0; k < 3; ++k) {
     if (MODE == 2 || MODE == 6 || MODE == 11) { fb[k] = f32x4{4, 3, 2, 1}; g2_ops(k, fa[k], fb[k]); }
     if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8 || MODE == 10) g1_ops(k, lo[k], hi[k], fb[k]);
-    if (MODE < 2 || MODE == 9) { fa[k] = f32x4{1, 2, 3, 4}; fb[k] = f32x4{4, 3, 2, 1}; lo[k] = i16x4{1, 2, 3, 4}; hi[k] = lo[k]; }
+    if (MODE < 2 || MODE == 9 || MODE >= 12) { fa[k] = f32x4{1, 2, 3, 4}; fb[k] = f32x4{4, 3, 2, 1}; lo[k] = i16x4{1, 2, 3, 4}; hi[k] = lo[k]; }
   }
   __syncthreads();
   const char* my = (const char*)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long)src >> 32)) << 32) |
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(512) void bench(unsigned long long* out, float* sin
         if (MODE == 2 || MODE == 11) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
         else { acc[0] += a[0] + b[0]; }
         __builtin_amdgcn_sched_barrier(0);
-      } else if (MODE >= 3) {
+      } else if (MODE >= 3 && MODE < 12) {
         const i16x4 l = lo[s], h = hi[s];
         const f32x4 b = fb[s];
         __builtin_amdgcn_sched_barrier(0);
@@ -91,6 +92,17 @@ __global__ __launch_bounds__(512) void bench(unsigned long long* out, float* sin
         if (MODE == 10) glds16(my + 1024 * ((it + u) & 63), 16u * lane, dma_dst + 1024u * (u & 7));
         if (MODE == 4) side += 0.5f * side * __builtin_amdgcn_rcpf(1.0f + side * side);
         __builtin_amdgcn_sched_barrier(0);
+      } else if (MODE == 12 || MODE == 13 || MODE == 14) {
+        // dependent chain + N independent vector instructions per MFMA (12: 4, 13: 8) / + one global load per MFMA (14)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s]), __builtin_bit_cast(bf16x8, fb[s]), acc, 0, 0, 0);
+        if (MODE == 14) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(src + 65536 * w + 1024 * ((it + u) & 63) + 16 * lane);
+          side += g[0];
+        } else {
+#pragma unroll
+          for (int k = 0; k < (MODE == 12 ? 4 : 8); ++k) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sv[k]) : "v"(side));
+        }
+        __builtin_amdgcn_sched_barrier(0);
       } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s]), __builtin_bit_cast(bf16x8, fb[s]), acc, 0, 0, 0);
         if (MODE == 1)
@@ -101,6 +113,7 @@ __global__ __launch_bounds__(512) void bench(unsigned long long* out, float* sin
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t1 = __builtin_readcyclecounter();
   float r = side;
+  for (int k = 0; k < 8; ++k) r += sv[k];
   for (int q = 0; q < 16; ++q) r += acc[q] + acc2[q];
   sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
@@ -149,6 +162,9 @@ int main() {
     run<10>("G1 mix + one 1 KB LDS-DMA per MFMA", threads, ncu, d_out, d_sink, d_src);
     run<8>("G1 reads + one LDS-DMA per two steps, no MFMA", threads, ncu, d_out, d_sink, d_src);
     run<9>("LDS-DMA alone (1 KB per iteration and wave)", threads, ncu, d_out, d_sink, d_src);
+    run<12>("dependent chain + 4 independent v_add per MFMA", threads, ncu, d_out, d_sink, d_src);
+    run<13>("dependent chain + 8 independent v_add per MFMA", threads, ncu, d_out, d_sink, d_src);
+    run<14>("dependent chain + one global_load_dwordx4 per MFMA", threads, ncu, d_out, d_sink, d_src);
   }
   // one CU only: is it the chip's power limit or the CU?
   run<3>("G1 mix, ONE workgroup on the whole chip", 512, 1, d_out, d_sink);
