@@ -134,6 +134,31 @@ __device__ __forceinline__ void a_chunk_load(const float* mlane, int chunk, type
   for (int q = 0; q < 16; ++q) dst[q] = *reinterpret_cast<const V*>(base + (size_t)(NB * ((q & 3) + 8 * (q >> 2))) * DIM);
 }
 
+// The same through a buffer resource: address = scalar base + the lane's constant 32-bit offset (VGPR) + the row's scalar
+// offset.  No vector instruction per load -- with 64-bit global addresses every load of the block in front of a chunk
+// needs a v_add_co / v_addc pair and a wait state, and the block is EXPOSED: the wave issues no MFMA meanwhile (a GEMM
+// took 77-78 000 cycles for 65 536 of MFMAs, 69 000 without the A loads; tools/pot_stamps.sh).
+template <int NB>
+__device__ __forceinline__ typename VecN<NB>::type buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  using V = typename VecN<NB>::type;
+  if constexpr (NB == 4) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  else if constexpr (NB == 2) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <int NB>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t a_rsrc(const float* M) {
+  constexpr int DIM = 128 * NB;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, DIM * DIM * 4, 0x00020000);
+}
+template <int NB>
+__device__ __forceinline__ void a_chunk_load_buf(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, int chunk,
+                                                 typename VecN<NB>::type (&dst)[16]) {
+  constexpr int DIM = 128 * NB;
+  const unsigned cbase = (unsigned)(32 * NB * (chunk / NB) + (chunk % NB)) * (unsigned)(DIM * 4);   // wave-uniform
+#pragma unroll
+  for (int q = 0; q < 16; ++q) dst[q] = buf_load<NB>(r, lane_bytes, cbase + (unsigned)(NB * ((q & 3) + 8 * (q >> 2)) * DIM * 4));
+}
+
 // B operands (published tiles) are read one group of four k-pairs AHEAD of the MFMAs that use them: with one wave per
 // SIMD an LDS read issued right before its MFMA stalls the matrix pipe for the whole LDS round trip.  The four waves'
 // images are contiguous, [chunk][q4][lane] x float4: group t = 4 chunk + q4.
@@ -167,6 +192,8 @@ __device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const floa
   constexpr int DIM = 128 * NB, NCH = 4 * NB;
   const size_t lane_off = (size_t)(4 * NB * h) * DIM + 32 * NB * w + NB * c;
   const float* mlane = M + lane_off;
+  const unsigned lane_bytes = (unsigned)(lane_off * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rM = a_rsrc<NB>(M), rN = a_rsrc<NB>(Mnext);
   const f32x4* bbase = &pub[0].v[0][0][0];
   typename VecN<NB>::type a1[16];
   f32x4 bnext = bbase[lane];
@@ -178,12 +205,12 @@ __device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const floa
     chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
     continue;
 #endif
-    a_chunk_load<NB>(mlane, chunk + 1, a1);
+    a_chunk_load_buf<NB>(rM, lane_bytes, chunk + 1, a1);
     __builtin_amdgcn_sched_barrier(0);
     chunk_mfma<NB>(bbase, chunk, lane, a0, bnext, acc);
     // one code path (a select, no branch: two paths made hipcc copy the 64 accumulator registers every chunk)
     const bool more = chunk + 2 < NCH;
-    a_chunk_load<NB>(more ? mlane : Mnext + lane_off, more ? chunk + 2 : 0, a0);
+    a_chunk_load_buf<NB>(more ? rM : rN, lane_bytes, more ? chunk + 2 : 0, a0);
     __builtin_amdgcn_sched_barrier(0);
     chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
   }
