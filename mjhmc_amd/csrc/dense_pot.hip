@@ -184,6 +184,35 @@ __device__ __forceinline__ void chunk_mfma(const f32x4* bbase, int chunk, int la
   }
 }
 
+// The GEMM's form of it: with the OTHER register set's next rows requested one per group of NB MFMAs (buffer loads: a
+// scalar add and the load, nothing for the vector pipe).  As a block of sixteen in front of the chunk the requests were
+// exposed -- the wave issues no MFMA meanwhile -- and with 64-bit global addresses (a v_add_co / v_addc pair and a wait state
+// per load) they cost whether blocked or spread (round 2: spread was the slower form).  A GEMM of 65 536 cycles of MFMAs:
+// 77-78 000 cycles with global loads in a block, 72 500 with buffer loads in a block, 68 000 spread (tools/pot_stamps.sh).
+template <int NB>
+__device__ __forceinline__ void chunk_mfma_ld(const f32x4* bbase, int chunk, int lane, const typename VecN<NB>::type (&a)[16],
+                                              f32x4& bnext, Tile<NB>& acc, __amdgpu_buffer_rsrc_t rs, unsigned lane_bytes,
+                                              unsigned cbase, typename VecN<NB>::type (&aload)[16]) {
+  constexpr int NG = 16 * NB, DIM = 128 * NB;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const f32x4 b4 = bnext;
+    const int t = 4 * chunk + q4 + 1;
+    bnext = bbase[(size_t)(t < NG ? t : NG - 1) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int q = 4 * q4 + qq;
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        acc.b[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<NB>(a[q], r), b4[qq], acc.b[r], 0, 0, 0);
+      aload[q] = buf_load<NB>(rs, lane_bytes, cbase + (unsigned)(NB * ((q & 3) + 8 * (q >> 2)) * DIM * 4));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // a0 enters holding chunk 0 of M (loaded before the previous epilogue, see AReg) and leaves holding chunk 0 of Mnext:
 // the next GEMM's first A rows cross the epilogue and the barrier
 template <int NB>
@@ -205,14 +234,27 @@ __device__ __forceinline__ void gemm_dim(const float* __restrict__ M, const floa
     chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
     continue;
 #endif
-    a_chunk_load_buf<NB>(rM, lane_bytes, chunk + 1, a1);
-    __builtin_amdgcn_sched_barrier(0);
-    chunk_mfma<NB>(bbase, chunk, lane, a0, bnext, acc);
-    // one code path (a select, no branch: two paths made hipcc copy the 64 accumulator registers every chunk)
+#if defined(POTV) && POTV == 6   // timing build: the requests as a block of sixteen in front of each chunk
+    {
+      a_chunk_load_buf<NB>(rM, lane_bytes, chunk + 1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_mfma<NB>(bbase, chunk, lane, a0, bnext, acc);
+      const bool more6 = chunk + 2 < NCH;
+      a_chunk_load_buf<NB>(more6 ? rM : rN, lane_bytes, more6 ? chunk + 2 : 0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
+      continue;
+    }
+#endif
+    // chunk's MFMAs read a0 while chunk + 1's rows are requested into a1, one per group of NB MFMAs; chunk + 1's read a1
+    // while chunk + 2 (or chunk 0 of the next GEMM's matrix: it crosses the epilogue and the barrier) lands in a0.
+    // One code path (selects, no branch: two paths made hipcc copy the 64 accumulator registers every chunk).
     const bool more = chunk + 2 < NCH;
-    a_chunk_load_buf<NB>(more ? rM : rN, lane_bytes, more ? chunk + 2 : 0, a0);
-    __builtin_amdgcn_sched_barrier(0);
-    chunk_mfma<NB>(bbase, chunk + 1, lane, a1, bnext, acc);
+    const int c1 = chunk + 1, c2 = more ? chunk + 2 : 0;
+    chunk_mfma_ld<NB>(bbase, chunk, lane, a0, bnext, acc, rM, lane_bytes,
+                      (unsigned)(32 * NB * (c1 / NB) + (c1 % NB)) * (unsigned)(DIM * 4), a1);
+    chunk_mfma_ld<NB>(bbase, chunk + 1, lane, a1, bnext, acc, more ? rM : rN, lane_bytes,
+                      (unsigned)(32 * NB * (c2 / NB) + (c2 % NB)) * (unsigned)(DIM * 4), a0);
   }
 }
 
