@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "autocor.hpp"
@@ -808,7 +809,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void* ptrs[] = {s->flf_list, s->flf_counts, s->Hpre, s->Hwork, s->cold_list, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
+  void* ptrs[] = {s->flf_list, s->flf_counts, s->Hpre, s->Hwork, s->cold_list, s->pot64_scratch, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
@@ -895,8 +896,10 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       }
       if (e->is_dense()) {
         if (!s->Hwork) {
-          HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * sizeof(float)));
+          HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * ssize(s)));  // float32, or float64 for ProductOfT's float64 state
           HIPCHK(hipMalloc((void**)&s->cold_list, (s->Npad + 2) * sizeof(int)));  // list + one counter per half
+          if (e->is_pot() && dtype == MJHMC_F64)   // working rows of the inverse-L pass, for two concurrent launches
+            HIPCHK(hipMalloc((void**)&s->pot64_scratch, (size_t)2 * pot64_scratch_workgroups() * 2 * 32 * row_bytes(s)));
         }
       }
       HIPCHK(hipMalloc(&s->EX[i], s->Npad * ssize(s)));
@@ -1100,6 +1103,8 @@ static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pi
   h.trans = a.trans + start;
   h.cold_list = a.cold_list + start;
   h.cold_count = a.cold_count + which;
+  if constexpr (std::is_same<A, Pot64JumpArgs>::value)   // the inverse-L pass's working rows: one set per concurrent launch
+    h.scratch = a.scratch + (size_t)which * pot64_scratch_workgroups() * 2 * 32 * (size_t)pitch;
   h.N = n;
   h.Npad = npad;
   h.first_pid = a.first_pid + start;
@@ -1574,6 +1579,63 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         } else {
           pot_launch_jump(pa, s->en->pot_model(), s->stream);
         }
+      } else {
+        // the reference's arithmetic: float64 state rows streamed through the tile kernel's epilogue (dense_pot64.hip)
+        Pot64JumpArgs pa;
+        pa.X_in = (const double*)a.X_in;
+        pa.V_in = (const double*)a.V_in;
+        pa.G_in = (const double*)s->Gbuf[vi];
+        pa.X_out = (double*)a.X_out;
+        pa.V_out = (double*)a.V_out;
+        pa.G_out = (double*)s->Gbuf[vi ^ 1];
+        pa.EX_in = (const double*)a.EX_in;
+        pa.EV_in = (const double*)a.EV_in;
+        pa.Hflf_in = (const double*)a.Hflf_in;
+        pa.Hwork = (double*)s->Hwork;
+        pa.cold_list = s->cold_list;
+        pa.cold_count = s->cold_list + s->Npad;
+        pa.EX_out = (double*)a.EX_out;
+        pa.EV_out = (double*)a.EV_out;
+        pa.Hflf_out = (double*)a.Hflf_out;
+        pa.dwell = a.dwell;
+        pa.dwell_ring = a.dwell_ring;
+        pa.trans = a.trans;
+        pa.noise = (const double*)a.noise;
+        pa.rexp = a.rexp;
+        pa.runif = a.runif;
+        pa.scratch = s->pot64_scratch;
+        pa.mode = a.mode;
+        pa.p_flip = a.p_flip;
+        pa.ctl = a.ctl;
+        pa.stats = a.stats;
+        pa.N = a.N;
+        pa.Npad = a.Npad;
+        pa.ntiles = a.Npad / 32;
+        pa.first_pid = a.first_pid;
+        pa.D = a.D;
+        pa.L = a.L;
+        pa.iter = a.iter;
+        pa.eps = s->eps;
+        pa.chalf = -s->eps / 2.;
+        pa.r_keep = std::sqrt(1. - s->beta);
+        pa.r_mix = std::sqrt(s->beta);
+        pa.p_r = a.p_r;
+        pa.key = a.key;
+        if (split_at > 0) {
+          Pot64JumpArgs h[2];
+          h[0] = half_args<Pot64JumpArgs, double>(pa, 0, split_at, split_at, (size_t)s->sh.pitch, 0);
+          h[0].G_in = pa.G_in;
+          h[0].G_out = pa.G_out;
+          h[0].ntiles = split_at / 32;
+          h[1] = half_args<Pot64JumpArgs, double>(pa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
+          h[1].G_in = pa.G_in + (size_t)split_at * s->sh.pitch;
+          h[1].G_out = pa.G_out + (size_t)split_at * s->sh.pitch;
+          h[1].ntiles = (s->Npad - split_at) / 32;
+          pot64_launch_jump(h[0], s->en->pot_model(), s->stream);
+          pot64_launch_jump(h[1], s->en->pot_model(), s->stream2);
+        } else {
+          pot64_launch_jump(pa, s->en->pot_model(), s->stream);
+        }
       }
     } else if (s->en->is_sic()) {
       if constexpr (sizeof(T) == 4) {
@@ -1786,7 +1848,11 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   if (s->en->is_host())
     return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy is driven step by step: mjhmc_traj_begin / _step / _finish");
   HIPCHK(hipSetDevice(s->ctx->device));
-  if (s->sh.wide) return multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
+  // ProductOfT with float64 state: the tile kernel with the state streamed through its epilogue (dense_pot64.hip); its
+  // multi-pass form (the same arithmetic, bit for bit) serves L = 0 and, in the test build, the A/B switch
+  const bool pot64_fused = s->sh.wide && s->en->is_pot() && s->L >= 1 && !test_env("MJHMC_POT64_MULTIPASS");
+  if (s->sh.wide && !pot64_fused)
+    return multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
   return s->dtype == MJHMC_F64
              ? iterate_t<double>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done)
              : iterate_t<float>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);

@@ -51,6 +51,40 @@ struct PotJumpArgs {
   RngKey key;
 };
 
+// The same iteration in the reference's arithmetic (dense_pot64.hip): float64 state rows around the float32 force
+struct Pot64JumpArgs {
+  const double* X_in;
+  const double* V_in;
+  const double* G_in;   // dE/dX at X_in: float32 values widened (hmc_state.py:52-53)
+  double* X_out;        // also the working rows of the trajectory
+  double* V_out;
+  double* G_out;
+  const double* EX_in;
+  const double* EV_in;
+  const double* Hflf_in;
+  double* Hwork;
+  int* cold_list;
+  int* cold_count;
+  double* EX_out;
+  double* EV_out;
+  double* Hflf_out;
+  double* dwell;
+  double* dwell_ring;
+  uint8_t* trans;
+  const double* noise;
+  const double* rexp;
+  const double* runif;
+  double* scratch;      // [workgroups][2][32][dim] working rows of the inverse-L pass (pot64_scratch_workgroups())
+  Control* ctl;
+  unsigned long long* stats;
+  int64_t N, Npad, ntiles, first_pid;
+  int D, L, iter;       // L >= 1
+  int mode;
+  double eps, chalf, r_keep, r_mix;
+  double p_r, p_flip;
+  RngKey key;
+};
+
 // stand-alone leapfrog operator on caller-supplied states (HMCState.leapfrog / L, hmc_state.py:86-100)
 struct PotLeapArgs {
   const float* X;
@@ -197,5 +231,7 @@ __device__ __forceinline__ void normal_pair_f32(const RngKey& k, uint32_t pid, u
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_eval(const PotEvalArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_leap(const PotLeapArgs& a, const PotModel& mdl, hipStream_t st);
+void pot64_launch_jump(const Pot64JumpArgs& a, const PotModel& mdl, hipStream_t st);
+int pot64_scratch_workgroups();  // workgroups a pot64 launch may run: rows of Pot64JumpArgs::scratch to provide per launch
 
 }  // namespace mjhmc

@@ -96,6 +96,7 @@ struct mjhmc_sampler {
   void* Gbuf[2] = {nullptr, nullptr};  // dEdX (dense energies keep it, like HMCState.dEdX); follows vcur
   float* Hwork = nullptr;              // dense energies: per-attempt H_flf work vector
   int* cold_list = nullptr;            // + compacted cold-particle list (Npad entries, then the counter)
+  double* pot64_scratch = nullptr;     // ProductOfT, float64 state: working rows of the inverse-L pass (two concurrent launches)
   // elementwise energies, several particles per wave: inverse-L pass over the compacted cold particles
   int* flf_list = nullptr;     // [Npad]
   int* flf_counts = nullptr;   // [flf_cap] one counter per attempt of the current mjhmc_iterate call

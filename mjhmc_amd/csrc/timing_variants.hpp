@@ -1,0 +1,17 @@
+// Compile-time hooks of the TIMING builds (tools/pot_stamps.sh, tools/run_sic_variants.sh).  The product build defines
+// none of the switches, and every macro here expands to nothing: the shipped kernel text has no timing branches.
+#pragma once
+
+// -DPOT_STAMPS: cycle stamps of workgroup 0's waves around the parts of a ProductOfT gradient evaluation (the last one
+// run wins).  Six stamps per ~150 000-cycle gradient: they do not disturb what they time.
+#ifdef POT_STAMPS
+namespace mjhmc {
+__device__ unsigned long long g_pot_stamp[4][8];
+}
+#define POT_STAMP(I)                                                                     \
+  do {                                                                                   \
+    if (blockIdx.x == 0 && lane == 0) g_pot_stamp[w][I] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define POT_STAMP(I) do { } while (0)
+#endif

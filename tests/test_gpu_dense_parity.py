@@ -134,7 +134,8 @@ def test_sic_single_evaluation(tag, P, n, cauchy, src):
     assert rel(G, g[tag + '_g']) < 2e-2, rel(G, g[tag + '_g'])
 
 
-@pytest.mark.parametrize('cls_name,D,N', [('MarkovJumpHMC', 36, 256), ('MarkovJumpHMC', 300, 70), ('ControlHMC', 36, 100)])
+@pytest.mark.parametrize('cls_name,D,N', [('MarkovJumpHMC', 36, 256), ('MarkovJumpHMC', 300, 70), ('ControlHMC', 36, 100),
+                                          ('MarkovJumpHMC', 512, 96), ('ControlHMC', 512, 40)])
 def test_pot_with_the_references_arithmetic_float64_state_float32_force(cls_name, D, N):
     """distributions.py:408-415 with hmc_state.py:29-38: the reference integrates float64 HMCState arrays around a float32
     Theano force.  ProductOfT(state_dtype='float64') does the same on the device (float32 matrix-core force on a
@@ -172,6 +173,60 @@ def test_pot_with_the_references_arithmetic_float64_state_float32_force(cls_name
             _resync(s, o)
     out = s.sample(3, preserve_order=True) if cls_name == 'ControlHMC' else s.sample(3, preserve_order=True)
     assert out.shape == (D, N, 3) and np.isfinite(out).all()
+
+
+@pytest.mark.parametrize('D,N,mode', [(36, 70, 'MJHMC'), (36, 20000, 'MJHMC'), (200, 300, 'MJHMC'), (512, 100, 'MJHMC'),
+                                      (36, 100, 'CONTROL'), (512, 70, 'CONTROL'), (200, 65, 'CTHMC')])
+def test_pot64_fused_equals_multipass(D, N, mode, monkeypatch):
+    """ProductOfT with float64 state: the tile kernel with the state rows streamed through its epilogue
+    (dense_pot64.hip -- what mjhmc_iterate runs) against the multi-pass form of the same arithmetic (host_energy.hip:
+    one row pass + one force evaluation per leapfrog step; the test build's MJHMC_POT64_MULTIPASS=1).  Same operations
+    in the same order around the same float32 GEMM code: X, V, dE/dX, E(X) and the transitions bit for bit (the kinetic
+    energy's 512 squares are added up in a different order: 1e-12), every sampler family, ragged batches, the split
+    schedule of big batches (N = 20000: two halves on two streams), one and several iterations per call, with and
+    without a sample ring."""
+    from mjhmc_amd import engine, _lib
+    ctxs = (engine.context(0), hooks_context(0))
+    W, lognu = ref_init_weights(D, D)
+    W = W + np.eye(D)
+    params = np.concatenate([[float(D)], W.ravel(), np.exp(lognu), 0.1 * np.random.RandomState(1).randn(D)])
+    ens = [engine.DeviceEnergy(c, _lib.E_PRODUCT_OF_T, D, params) for c in ctxs]
+    X0 = np.random.RandomState(3).randn(D, N)
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype='float64', mode=getattr(_lib, 'MODE_' + mode)) for en in ens]
+    fields = ('X', 'V', 'DEDX', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
+    all_stats = [[], []]
+    ring = N <= 300
+    if ring:
+        for s in pair:
+            s.ring_alloc(4)
+    for n_it, slot in ((1, -1), (3, 0), (2, -1), (1, 3)):
+        if slot >= 0 and not ring:
+            slot = -1
+        for k, s in enumerate(pair):
+            s.set_hparams(0.1, 5, 0.2, 0.3) if mode == 'CONTROL' else s.set_hparams(0.1, 5, 0.2, 1.0)
+            if k == 1:
+                monkeypatch.setenv('MJHMC_POT64_MULTIPASS', '1')
+            else:
+                monkeypatch.delenv('MJHMC_POT64_MULTIPASS', raising=False)
+            st, done = s.iterate(n_it, ring_slot0=slot)
+            assert done == n_it
+            all_stats[k] += [(t.l, t.f, t.r, t.fl, t.n_cold, t.E_evals, t.dEdX_evals) for t in st]
+        monkeypatch.delenv('MJHMC_POT64_MULTIPASS', raising=False)
+        for f in fields:
+            fa, fb = pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f))
+            if f in ('EV', 'HFLF', 'DWELL'):    # sum(V^2) is added up in a different order (tile reduction / one wavefront per row); an F clock's rate is a difference of two near-equal rates
+                assert np.allclose(fa, fb, rtol=1e-7 if f == 'DWELL' else 1e-12, atol=0, equal_nan=True), (n_it, f)
+            else:
+                assert np.array_equal(fa, fb, equal_nan=True), (n_it, f, np.abs(fa - fb).max())
+    assert all_stats[0] == all_stats[1]
+    if ring:
+        ra, rb = pair[0].ring_read(0, 4), pair[1].ring_read(0, 4)
+        assert np.array_equal(ra, rb)
+        assert np.array_equal(ra[:, -N:], pair[0].read(_lib.F_X))      # the last recorded sample is the live state
+    X = pair[0].read(_lib.F_X)
+    assert np.abs(X - X.astype(np.float32)).max() > 0         # float64 state, not float32 values
+    for s in pair:
+        s.close()
 
 
 # ---------------------------------------------------------------------------------------------
