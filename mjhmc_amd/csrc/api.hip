@@ -897,7 +897,8 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
       if (e->is_dense()) {
         if (!s->Hwork) {
           HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * ssize(s)));  // float32, or float64 for ProductOfT's float64 state
-          HIPCHK(hipMalloc((void**)&s->cold_list, (s->Npad + 2) * sizeof(int)));  // list + one counter per half
+          HIPCHK(hipMemsetAsync(s->Hwork, 0, s->Npad * ssize(s), s->stream));   // (padding rows read it and ignore it)
+          HIPCHK(hipMalloc((void**)&s->cold_list, (2 * s->Npad + 4) * sizeof(int)));  // two lists (iterations alternate) + [half][parity] counters
           if (e->is_pot() && dtype == MJHMC_F64)   // working rows of the inverse-L pass, for two concurrent launches
             HIPCHK(hipMalloc((void**)&s->pot64_scratch, (size_t)2 * pot64_scratch_workgroups() * 2 * 32 * row_bytes(s)));
         }
@@ -999,10 +1000,11 @@ int mjhmc_rollback(mjhmc_sampler* s) {
   // an iteration reads one buffer parity and writes the other: flipping the parities back IS the pre-move state
   // (X, V, EX, EV, H_flf and, for ProductOfT, dE/dX); dwell / trans hold the rolled-back attempt's values until
   // the retry overwrites them.  The RNG tick stays consumed, like the reference's already-drawn numbers.
+  s->undo_valid = false;
+  if (s->undo_multipass) return multipass_rollback(s);   // committed in place: the pre-move state is copied back
   s->Xcur = s->undo_X;
   s->vcur ^= 1;
   s->scur ^= 1;
-  s->undo_valid = false;
   return 0;
 }
 
@@ -1102,7 +1104,9 @@ static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pi
   h.dwell_ring = a.dwell_ring + start;
   h.trans = a.trans + start;
   h.cold_list = a.cold_list + start;
-  h.cold_count = a.cold_count + which;
+  h.next_list = a.next_list + start;
+  h.cold_count = a.cold_count + 2 * which;   // counters: [half][parity]
+  h.next_count = a.next_count + 2 * which;
   if constexpr (std::is_same<A, Pot64JumpArgs>::value)   // the inverse-L pass's working rows: one set per concurrent launch
     h.scratch = a.scratch + (size_t)which * pot64_scratch_workgroups() * 2 * 32 * (size_t)pitch;
   h.N = n;
@@ -1536,8 +1540,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.EV_in = a.EV_in;
         pa.Hflf_in = a.Hflf_in;
         pa.Hwork = s->Hwork;
-        pa.cold_list = s->cold_list;
-        pa.cold_count = s->cold_list + s->Npad;
+        pa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;          // iteration i reads list i & 1 ...
+        pa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;    // ... and writes the next iteration's
+        pa.cold_count = s->cold_list + 2 * s->Npad + (i & 1);
+        pa.next_count = s->cold_list + 2 * s->Npad + ((i + 1) & 1);
         pa.EX_out = a.EX_out;
         pa.EV_out = a.EV_out;
         pa.Hflf_out = a.Hflf_out;
@@ -1592,8 +1598,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.EV_in = (const double*)a.EV_in;
         pa.Hflf_in = (const double*)a.Hflf_in;
         pa.Hwork = (double*)s->Hwork;
-        pa.cold_list = s->cold_list;
-        pa.cold_count = s->cold_list + s->Npad;
+        pa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;          // iteration i reads list i & 1 ...
+        pa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;    // ... and writes the next iteration's
+        pa.cold_count = s->cold_list + 2 * s->Npad + (i & 1);
+        pa.next_count = s->cold_list + 2 * s->Npad + ((i + 1) & 1);
         pa.EX_out = (double*)a.EX_out;
         pa.EV_out = (double*)a.EV_out;
         pa.Hflf_out = (double*)a.Hflf_out;
@@ -1648,8 +1656,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         sa.EV_in = a.EV_in;
         sa.Hflf_in = a.Hflf_in;
         sa.Hwork = s->Hwork;
-        sa.cold_list = s->cold_list;
-        sa.cold_count = s->cold_list + s->Npad;
+        sa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;
+        sa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;
+        sa.cold_count = s->cold_list + 2 * s->Npad + (i & 1);
+        sa.next_count = s->cold_list + 2 * s->Npad + ((i + 1) & 1);
         sa.EX_out = a.EX_out;
         sa.EV_out = a.EV_out;
         sa.Hflf_out = a.Hflf_out;
@@ -1789,6 +1799,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);
   // commit the finished iterations
   s->undo_valid = (n_iter == 1 && done == 1);  // the input buffers of a single iteration survive it: see mjhmc_rollback
+  s->undo_multipass = false;
   s->undo_X = s->Xcur;
   if (done > 0) s->Xcur = xout[done - 1];
   s->vcur = (s->vcur + done) & 1;

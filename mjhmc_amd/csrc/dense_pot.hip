@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256, 1) void pot_eval_kernel(const PotEvalArgs a, c
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
+  stage_bias<NB>(mdl, sh);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
     Tile<NB> x, g;
@@ -69,25 +70,16 @@ __global__ __launch_bounds__(256, 1) void pot_eval_kernel(const PotEvalArgs a, c
 // inverse-L trajectory, so the cold particles (5-60 % of the batch) are gathered into dense tiles
 // first: the F L F work stays proportional to the cold fraction, as in the reference (hmc_state.py:109-119).
 // ---------------------------------------------------------------------------------------------------
-__global__ void pot_cold_list_kernel(const float* __restrict__ Hflf_in, float* __restrict__ Hwork, int64_t N,
-                                     int64_t Npad, int* __restrict__ list, int* __restrict__ count,
-                                     const Control* ctl, unsigned long long* stats) {
+// The list of the FIRST iteration of a mjhmc_iterate call comes from a scan of the cache (this kernel, once per call);
+// every later one is written by the jump kernel of the iteration before it (append_cold): no per-iteration memset, no
+// per-iteration list kernel -- a 4-byte memset behind a persistent grid waited for a workgroup to exit (20 % of the
+// summed kernel time of a C3 profile was such queue waits).
+__global__ void pot_cold_list_kernel(const float* __restrict__ Hflf_in, int64_t N, int* __restrict__ list,
+                                     int* __restrict__ count, const Control* ctl) {
   if (ctl->failed) return;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= Npad) return;
-  const float hc = Hflf_in[p];
-  Hwork[p] = hc;
-  const bool cold = (p < N) && !(hc == hc);
-  const unsigned long long m = __ballot(cold);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0) {
-    base = atomicAdd(count, (int)__popcll(m));
-    atomicAdd(&stats[3], (unsigned long long)__popcll(m));
-  }
-  base = __shfl(base, 0);
-  if (cold) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+  const float hc = p < N ? Hflf_in[p] : 0.f;
+  append_cold(list, count, (p < N) && !(hc == hc), p);
 }
 
 template <int NB>
@@ -96,8 +88,11 @@ __global__ __launch_bounds__(256, 1) void pot_flf_kernel(const PotJumpArgs a, co
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold);  // the cold tally
+  if ((int64_t)blockIdx.x * kP >= ncold) return;  // nothing for this workgroup
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
+  stage_bias<NB>(mdl, sh);
   for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
     const int slot = tile * kP + c;
     const int64_t p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
@@ -126,17 +121,21 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
   __shared__ Shared<NB> sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  // the inverse-L pass of this iteration has consumed its list: its counter is free for the iteration after the next
+  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) *a.cold_count = 0;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
+  stage_bias<NB>(mdl, sh);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
     const bool alive = p < a.N;
     const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
     const float H0 = EX0 + EV0;
     // H of the inverse-L proposal: cached, or integrated by pot_flf_kernel for the cold particles
-    const float Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.f;
+    float Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.f;
+    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
     Tile<NB> x, v, g;
     tile_load<NB>(a.X_in, p, w, h, x);
     tile_load<NB>(a.V_in, p, w, h, v);
@@ -159,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
       else
         k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, alive ? p : 0, a.N, a.runif, a.key, gate);
       any_bad |= (bad && alive);
+      if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k != 0, p);
       sh.move[c] = k | (gate ? 4 : 0);
       a.dwell[p] = best;
       a.dwell_ring[p] = best;
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, 1) void pot_leap_kernel(const PotLeapArgs a, c
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
+  stage_bias<NB>(mdl, sh);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
     Tile<NB> x, v, g;
@@ -301,9 +302,11 @@ template <int NB>
 static void launch_jump_nb(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus());
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
-    (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
-                       a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+    if (a.iter == 0) {  // first iteration of a call: both counters cleared (they are adjacent), the list from a scan
+      (void)hipMemsetAsync(a.cold_count < a.next_count ? a.cold_count : a.next_count, 0, 2 * sizeof(int), st);
+      hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.N,
+                         a.cold_list, a.cold_count, (const Control*)a.ctl);
+    }
     hipLaunchKernelGGL(pot_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
     launch_jump_mode<NB, kModeMJHMC>(a, mdl, grid, st);
   } else if (a.mode == kModeCT) {

@@ -32,6 +32,8 @@ struct PotJumpArgs {
   float* Hwork;        // [Npad] H of the inverse-L proposal for this attempt (cached or freshly integrated)
   int* cold_list;      // [Npad] compacted indices of the cold particles
   int* cold_count;
+  int* next_list;       // the NEXT iteration's cold list and counter, filled by this iteration's jump kernel
+  int* next_count;
   float* EX_out;
   float* EV_out;
   float* Hflf_out;
@@ -65,6 +67,8 @@ struct Pot64JumpArgs {
   double* Hwork;
   int* cold_list;
   int* cold_count;
+  int* next_list;       // the NEXT iteration's cold list and counter, filled by this iteration's jump kernel
+  int* next_count;
   double* EX_out;
   double* EV_out;
   double* Hflf_out;

@@ -196,8 +196,8 @@ __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double
       }
     }
   };
-  auto work4 = [&](int q4, DV(&x)[4], DV(&vin4)[4]) {
-    f32x4 px[NB];
+  // the momentum first: it needs no memory (the first pass: only its own rows), so it runs while the X loads are in flight
+  auto kick4 = [&](int q4, DV(&vin4)[4]) {
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int q = 4 * q4 + qq;
@@ -214,7 +214,17 @@ __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double
         vv = vv + t;
         if constexpr (NKICK == 2) vv = vv + t;
         v.b[r][q] = vv;
-        const double xx = dget<NB>(x[qq], r) + eps * vv;
+      }
+    }
+  };
+  auto drift4 = [&](int q4, DV(&x)[4]) {
+    f32x4 px[NB];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int q = 4 * q4 + qq;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        const double xx = dget<NB>(x[qq], r) + eps * v.b[r][q];
         dset<NB>(x[qq], r, xx);
         px[r][qq] = (float)xx;
       }
@@ -224,20 +234,26 @@ __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double
 #pragma unroll
     for (int r = 0; r < NB; ++r) pub.v[r][q4][lane] = px[r];
   };
+  // (Measured: all four kick4 first, in the shadow of the first X loads, then the drifts -- more registers live across
+  // the pass, 119 -> 283 spilled, C3 in this arithmetic 17.6 -> 18.7 ms.)
   load4(0, xa, va);
   load4(1, xb, vb);
   __builtin_amdgcn_sched_barrier(0);
-  work4(0, xa, va);
+  kick4(0, va);
+  drift4(0, xa);
   __builtin_amdgcn_sched_barrier(0);
   load4(2, xa, va);
   __builtin_amdgcn_sched_barrier(0);
-  work4(1, xb, vb);
+  kick4(1, vb);
+  drift4(1, xb);
   __builtin_amdgcn_sched_barrier(0);
   load4(3, xb, vb);
   __builtin_amdgcn_sched_barrier(0);
-  work4(2, xa, va);
+  kick4(2, va);
+  drift4(2, xa);
   __builtin_amdgcn_sched_barrier(0);
-  work4(3, xb, vb);
+  kick4(3, vb);
+  drift4(3, xb);
 }
 
 // The closing half kick of the trajectory, v += c g, and this lane's part of sum(v^2)
@@ -280,9 +296,13 @@ __device__ __forceinline__ double pot64_trajectory(const PotModel& mdl, AReg<NB>
   if (L == 1) kick_drift_pass<NB, 1, NEG, true, XLAST>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane);
   else kick_drift_pass<NB, 1, NEG, true, kXWork>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane);
   for (int s = 0; s < L; ++s) {
-    pot_gradient_published<NB>(mdl, ar, sh.s, w, c, h, lane, g, s == L - 1, ex);
+    [[maybe_unused]] const int stamp_slot = s;
+    POT_STAMP(0);
+    pot_gradient_published<NB>(mdl, ar, sh.s, w, c, h, lane, g, s == L - 1, ex, s);
+    POT_STAMP(6);
     if (s < L - 2) kick_drift_pass<NB, 2, false, false, kXWork>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
     else if (s == L - 2) kick_drift_pass<NB, 2, false, false, XLAST>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
+    POT_STAMP(7);
   }
   const double part = closing_kick<NB>(g, v, chalf);
   return column_sum<NB>(sh, w, c, h, part) / 2.0;
@@ -309,25 +329,12 @@ __device__ __forceinline__ typename DVecN<NB>::type normals_q(const RngKey& key,
 // ---------------------------------------------------------------------------------------------------
 // inverse-L pass of the cold-cache particles, compacted into dense tiles (dense_pot.hip: pot_cold_list_kernel's twin)
 // ---------------------------------------------------------------------------------------------------
-__global__ void pot64_cold_list_kernel(const double* __restrict__ Hflf_in, double* __restrict__ Hwork, int64_t N,
-                                       int64_t Npad, int* __restrict__ list, int* __restrict__ count, const Control* ctl,
-                                       unsigned long long* stats) {
+__global__ void pot64_cold_list_kernel(const double* __restrict__ Hflf_in, int64_t N, int* __restrict__ list,
+                                       int* __restrict__ count, const Control* ctl) {
   if (ctl->failed) return;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= Npad) return;
-  const double hc = Hflf_in[p];
-  Hwork[p] = hc;
-  const bool cold = (p < N) && !(hc == hc);
-  const unsigned long long m = __ballot(cold);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0) {
-    base = atomicAdd(count, (int)__popcll(m));
-    atomicAdd(&stats[3], (unsigned long long)__popcll(m));
-  }
-  base = __shfl(base, 0);
-  if (cold) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+  const double hc = p < N ? Hflf_in[p] : 0.0;
+  append_cold(list, count, (p < N) && !(hc == hc), p);
 }
 
 template <int NB>
@@ -336,8 +343,11 @@ __global__ __launch_bounds__(256, 1) void pot64_flf_kernel(const Pot64JumpArgs a
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold);  // the cold tally
+  if ((int64_t)blockIdx.x * kP >= ncold) return;  // nothing for this workgroup
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
+  stage_bias<NB>(mdl, sh.s);
   const Work<NB> wk = work_of<NB>(a.scratch, blockIdx.x, w, lane);
   for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
     const int slot = tile * kP + c;
@@ -362,10 +372,13 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
   if (a.ctl->failed) return;
   using DV = typename DVecN<NB>::type;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  // the inverse-L pass of this iteration has consumed its list: its counter is free for the iteration after the next
+  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) *a.cold_count = 0;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
+  stage_bias<NB>(mdl, sh.s);
   const Work<NB> wk = work_of<NB>(a.scratch, blockIdx.x, w, lane);
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
@@ -373,7 +386,8 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
     const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
     const double H0 = EX0 + EV0;
     // H of the inverse-L proposal: cached, or integrated by pot64_flf_kernel for the cold particles
-    const double Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.0;
+    double Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.0;
+    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
     const double* xin = lane_row<NB>(a.X_in, p, w, h);
     const double* vin = lane_row<NB>(a.V_in, p, w, h);
     const double* gin = lane_row<NB>(a.G_in, p, w, h);
@@ -434,6 +448,7 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
         k = (accept ? 1 : 0) | (flip ? 2 : 0);
       }
       any_bad |= (bad && alive);
+      if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k != 0, p);
       sh.s.move[c] = k | (gate ? 4 : 0);
       a.dwell[p] = best;
       a.dwell_ring[p] = best;
@@ -556,9 +571,11 @@ template <int NB>
 static void launch64_nb(const Pot64JumpArgs& a, const PotModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus64());
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
-    (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(pot64_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
-                       a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+    if (a.iter == 0) {  // first iteration of a call: both counters cleared (they are adjacent), the list from a scan
+      (void)hipMemsetAsync(a.cold_count < a.next_count ? a.cold_count : a.next_count, 0, 2 * sizeof(int), st);
+      hipLaunchKernelGGL(pot64_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.N,
+                         a.cold_list, a.cold_count, (const Control*)a.ctl);
+    }
     hipLaunchKernelGGL(pot64_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
     launch64_mode<NB, kModeMJHMC>(a, mdl, grid, st);
   } else if (a.mode == kModeCT) {
@@ -573,5 +590,13 @@ void pot64_launch_jump(const Pot64JumpArgs& a, const PotModel& mdl, hipStream_t 
   else if (mdl.dim == 256) launch64_nb<2>(a, mdl, st);
   else launch64_nb<4>(a, mdl, st);
 }
+
+#ifdef POT_STAMPS
+}  // namespace mjhmc
+extern "C" int mjhmc_pot64_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mjhmc::g_pot_stamp), sizeof(mjhmc::g_pot_stamp));
+}
+namespace mjhmc {
+#endif
 
 }  // namespace mjhmc

@@ -296,7 +296,16 @@ struct Shared {
   PubWave<NB> pub[2][4];  // B operands, [0] = X tile, [1] = H tile (2 x 64 KB at NB = 4)
   float red[2][4][kP];    // per-wave partial sums (energy, kinetic)
   int move[kP];           // transition chosen per particle
+  float cb[128 * NB];     // b_j / nu_j: the value every u accumulator starts from (stage_bias)
 };
+
+// b / nu into LDS, once per kernel.  Every gradient starts by initialising its 16 NB accumulator registers from it; as
+// global loads these stood right behind the barrier in front of the first MFMA (and, in the float64-state kernel,
+// behind the epilogue's stores in the in-order memory queue).  Call before the first barrier of the kernel.
+template <int NB>
+__device__ __forceinline__ void stage_bias(const PotModel& mdl, Shared<NB>& sh) {
+  for (int i = threadIdx.x; i < 128 * NB; i += 256) sh.cb[i] = mdl.cb[i];
+}
 
 
 // gradient of the energy at the X held in `x`; optionally the energy itself.
@@ -307,11 +316,12 @@ struct Shared {
 // (sh.pub[0][w], publish()'s layout) already.
 template <int NB>
 __device__ __forceinline__ void pot_gradient_published(const PotModel& mdl, AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
-                                                       int lane, Tile<NB>& g, bool want_energy, float* energy_out) {
+                                                       int lane, Tile<NB>& g, bool want_energy, float* energy_out,
+                                                       int stamp_slot = 0) {
   __syncthreads();
   POT_STAMP(1);
   Tile<NB> u;
-  rowvec_load<NB>(mdl.cb, w, h, u);                    // u starts at b_j / nu_j
+  rowvec_load<NB>(sh.cb, w, h, u);                     // u starts at b_j / nu_j (LDS copy, stage_bias)
   gemm_any<NB, false>(mdl, ar, sh.pub[0], w, c, h, lane, u);   // + sum_d W[d][j]/nu_j * x_d
   POT_STAMP(2);
   if (want_energy) {                                   // E = sum_j alpha_j log(1 + u_j^2)  (distributions.py:430-432)
@@ -353,6 +363,7 @@ template <int NB>
 __device__ __forceinline__ void pot_gradient(const PotModel& mdl, AReg<NB>& ar, Shared<NB>& sh, int w, int c, int h,
                                              int lane, const Tile<NB>& x, Tile<NB>& g, bool want_energy,
                                              float* energy_out) {
+  [[maybe_unused]] const int stamp_slot = 0;
   POT_STAMP(0);
   publish<NB>(sh.pub[0][w], lane, x);
   pot_gradient_published<NB>(mdl, ar, sh, w, c, h, lane, g, want_energy, energy_out);

@@ -687,25 +687,13 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
   astream_close();
 }
 
-__global__ void sic_cold_list_kernel(const float* __restrict__ Hflf_in, float* __restrict__ Hwork, int64_t N,
-                                     int64_t Npad, int* __restrict__ list, int* __restrict__ count, const Control* ctl,
-                                     unsigned long long* stats) {
+// the cold list of the FIRST iteration of a call (later ones: append_cold in the jump kernel; dense_pot.hip has the story)
+__global__ void sic_cold_list_kernel(const float* __restrict__ Hflf_in, int64_t N, int* __restrict__ list,
+                                     int* __restrict__ count, const Control* ctl) {
   if (ctl->failed) return;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= Npad) return;
-  const float hc = Hflf_in[p];
-  Hwork[p] = hc;
-  const bool cold = (p < N) && !(hc == hc);
-  const unsigned long long m = __ballot(cold);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0) {
-    base = atomicAdd(count, (int)__popcll(m));
-    atomicAdd(&stats[3], (unsigned long long)__popcll(m));
-  }
-  base = __shfl(base, 0);
-  if (cold) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+  const float hc = p < N ? Hflf_in[p] : 0.f;
+  append_cold(list, count, (p < N) && !(hc == hc), p);
 }
 
 struct FromList {
@@ -720,6 +708,7 @@ __global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, co
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int ncold = *a.cold_count;
   const int ppt = kP / mdl.P;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold);  // the cold tally
   if ((int64_t)blockIdx.x * ppt >= ncold) return;  // nothing for this workgroup
   stage_patches(mdl, sh);
   const AStream as = astream_open<NB>(mdl, sh, w, lane);
@@ -747,6 +736,8 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
   __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  // the inverse-L pass of this iteration has consumed its list: its counter is free for the iteration after the next
+  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) *a.cold_count = 0;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   if (threadIdx.x < 4) sh.tally[threadIdx.x] = 0;
@@ -757,7 +748,8 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
     const int64_t p = col.part;
     const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
     const float H0 = EX0 + EV0;
-    const float Hflf = MODE == kModeMJHMC ? a.Hwork[p] : 0.f;
+    float Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.f;
+    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
     CTile<NB> x, v;
     RTile R;
     ctile_load(a.X_in, col.q, w, h, x);
@@ -775,6 +767,7 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
       else if constexpr (MODE == kModeCT) k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
       else k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, p, a.N, a.runif, a.key, gate);
       sh.move[c] = k | (gate ? 4 : 0);
+      if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, col.leader && k != 0, p);
       if (col.leader) {
         any_bad |= bad;
         a.dwell[p] = best;
@@ -927,9 +920,11 @@ template <bool CAUCHY, int NB>
 static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
-    (void)hipMemsetAsync(a.cold_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.Npad + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hwork,
-                       a.N, a.Npad, a.cold_list, a.cold_count, (const Control*)a.ctl, a.stats);
+    if (a.iter == 0) {  // first iteration of a call: both counters cleared (they are adjacent), the list from a scan
+      (void)hipMemsetAsync(a.cold_count < a.next_count ? a.cold_count : a.next_count, 0, 2 * sizeof(int), st);
+      hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.N,
+                         a.cold_list, a.cold_count, (const Control*)a.ctl);
+    }
     hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
     sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
   } else if (a.mode == kModeCT) {

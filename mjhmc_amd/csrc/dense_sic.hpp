@@ -35,6 +35,8 @@ struct SicJumpArgs {
   float* Hwork;
   int* cold_list;
   int* cold_count;
+  int* next_list;       // the NEXT iteration's cold list and counter, filled by this iteration's jump kernel
+  int* next_count;
   float* EX_out;
   float* EV_out;
   float* Hflf_out;

@@ -46,6 +46,21 @@ struct Control {
 };
 
 // most sampling iterations one fused launch runs per particle (per-iteration tallies live in LDS)
+// Dense energies (tile kernels): the particles whose inverse-L cache will be cold in the NEXT iteration are known when the
+// jump kernel has decided -- every move but L clears the cache (markov_jump_hmc.py:398-412) -- so the lanes that decided
+// (one per particle) append them to the next iteration's compacted list right there: one atomic per tile.  Called under
+// divergent control flow; `cold` lanes must be active.
+__device__ __forceinline__ void append_cold(int* list, int* count, bool cold, int64_t p) {
+  const unsigned long long m = __ballot(cold);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int first = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == first) base = atomicAdd(count, (int)__popcll(m));
+  base = __shfl(base, first);
+  if (cold) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+}
+
 constexpr int kMaxFuse = 64;
 
 template <typename T>

@@ -113,6 +113,7 @@ struct mjhmc_sampler {
   bool ck_valid = false;
   void* undo_X = nullptr;   // pre-move X of the last single-iteration call (its ping-pong input, still intact)
   bool undo_valid = false;
+  bool undo_multipass = false;   // the last committed iteration ran on the multi-pass path: its undo is a copy back (host_energy.hip)
   uint8_t* trans = nullptr;
   Control* ctl = nullptr;
   long long* stats = nullptr;  // [stats_cap][4]
@@ -153,6 +154,7 @@ int host_run_eval(mjhmc_sampler* s, const void* V, void* Vgen, void* EVout);
 int wide_run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout);
 int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                       const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
+int multipass_rollback(mjhmc_sampler* s);
 int wide_leapfrog(mjhmc_sampler* w, const double* X, const double* V, double* Xo, double* Vo, double* G, double* EX,
                   double* EV, double eps, int n_steps);
 

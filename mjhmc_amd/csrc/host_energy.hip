@@ -296,12 +296,12 @@ struct CommitArgs {
   double* EXs;
   double* EVs;
   double* Hflf;
-  const double* TX;
-  const double* TV;
-  const double* TG;
+  double* TX;     // in: the proposal's end point; out: the pre-move rows (what mjhmc_rollback puts back)
+  double* TV;
+  double* TG;
   const int* kmove;
   const double* dtmp;
-  const double* hnew;
+  double* hnew;   // in: EX, EV, H_flf of the successor; out: the pre-move values
   const double* noise;  // replay normals (rows) or nullptr
   double* dwell;
   double* dwell_ring;
@@ -326,9 +326,6 @@ __global__ void hk_commit(const CommitArgs a) {
   double* x = a.X + p * a.pitch;
   double* v = a.V + p * a.pitch;
   double* g = a.G + p * a.pitch;
-  const double* tx = a.TX + p * a.pitch;
-  const double* tv = a.TV + p * a.pitch;
-  const double* tg = a.TG + p * a.pitch;
   bool take = false, flip_old = false, flip_new = false, refresh = false;
   int n0 = 0, n1 = 0, n2 = 0, n3 = 0, k = km;
   if (a.mode == kModeMJHMC) {
@@ -358,9 +355,13 @@ __global__ void hk_commit(const CommitArgs a) {
     n2 = gate;
     n3 = k == 1;
   }
+  double* tx = a.TX + p * a.pitch;
+  double* tv = a.TV + p * a.pitch;
+  double* tg = a.TG + p * a.pitch;
   double ev = 0.0;
   for (int d = lane; d < a.D; d += 64) {
-    double xv = x[d], vv = v[d];
+    const double x0 = x[d], v0 = v[d], g0 = g[d];
+    double xv = x0, vv = v0;
     if (take) {
       xv = tx[d];
       vv = tv[d];
@@ -384,14 +385,23 @@ __global__ void hk_commit(const CommitArgs a) {
     }
     v[d] = vv;
     if (a.ring_slot) a.ring_slot[p * a.pitch + d] = xv;
+    // the proposal rows are spent: they now keep the pre-move state, so that a committed single iteration can be undone
+    // without a copy having been taken (mjhmc_rollback; sharded runs whose failure happened on another rank)
+    tx[d] = x0;
+    tv[d] = v0;
+    tg[d] = g0;
   }
   if (refresh) {
     for (int o = 32; o > 0; o >>= 1) ev += __shfl_xor(ev, o);
   }
   if (lane == 0) {
+    const double ex_old = a.EXs[p], ev_old = a.EVs[p], hf_old = a.Hflf[p];
     a.EXs[p] = a.hnew[p];
     a.EVs[p] = refresh ? ev / 2.0 : a.hnew[a.Npad + p];
     a.Hflf[p] = a.hnew[2 * a.Npad + p];
+    a.hnew[p] = ex_old;
+    a.hnew[a.Npad + p] = ev_old;
+    a.hnew[2 * a.Npad + p] = hf_old;
     a.dwell[p] = a.dtmp[p];
     if (a.dwell_ring) a.dwell_ring[p] = a.dtmp[p];
     a.trans[p] = (uint8_t)k;
@@ -399,6 +409,25 @@ __global__ void hk_commit(const CommitArgs a) {
     if (n1) atomicAdd(&a.stats[1], 1ull);
     if (n2) atomicAdd(&a.stats[2], 1ull);
     if (n3) atomicAdd(&a.stats[3], 1ull);
+  }
+}
+
+// mjhmc_rollback of a multi-pass sampler: the pre-move rows and scalars hk_commit left in the proposal workspace go back
+__global__ void hk_undo(double* __restrict__ X, double* __restrict__ V, double* __restrict__ G, double* __restrict__ EX,
+                        double* __restrict__ EV, double* __restrict__ Hflf, const double* __restrict__ TX,
+                        const double* __restrict__ TV, const double* __restrict__ TG, const double* __restrict__ hold,
+                        int64_t N, int64_t Npad, int D, int pitch) {
+  const int64_t p = blockIdx.x;
+  if (p >= N) return;
+  for (int d = threadIdx.x; d < D; d += 64) {
+    X[p * pitch + d] = TX[p * pitch + d];
+    V[p * pitch + d] = TV[p * pitch + d];
+    G[p * pitch + d] = TG[p * pitch + d];
+  }
+  if (threadIdx.x == 0) {
+    EX[p] = hold[p];
+    EV[p] = hold[Npad + p];
+    Hflf[p] = hold[2 * Npad + p];
   }
 }
 
@@ -609,6 +638,7 @@ int mjhmc_traj_begin(mjhmc_sampler* s, int64_t* n_cols) {
 
 int traj_begin_impl(mjhmc_sampler* s, int64_t* n_cols) {
   TRY(need_traj(s));
+  s->undo_valid = false;   // the workspace is about to be overwritten
   HostTraj* t = s->ht;
   const int pitch = s->sh.pitch;
   t->n_cold = 0;
@@ -782,7 +812,9 @@ int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double
     HIPCHK(hipMemcpyAsync(hs, s->stats, sizeof(hs), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
   }
-  s->undo_valid = false;
+  // a committed attempt can be undone until the next one begins: hk_commit left the pre-move state in the workspace
+  s->undo_valid = !hc.failed;
+  s->undo_multipass = true;
   if (st) {
     std::memset(st, 0, sizeof(*st));
     if (s->mode == MJHMC_MODE_MJHMC) {
@@ -806,6 +838,18 @@ int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double
     st->L_used = t->steps;
     st->eps_used = s->eps;
   }
+  return 0;
+}
+
+int multipass_rollback(mjhmc_sampler* s) {
+  HostTraj* t = s->ht;
+  if (!t) return mjhmc_fail(MJHMC_ERR_INVALID, "nothing to roll back");
+  hipLaunchKernelGGL(hk_undo, dim3((unsigned)s->N), dim3(64), 0, s->stream, (double*)s->Xcur, (double*)s->Vbuf[s->vcur],
+                     (double*)s->Gbuf[s->vcur], (double*)s->EX[s->scur], (double*)s->EV[s->scur], (double*)s->Hflf[s->scur],
+                     (const double*)t->X, (const double*)t->V, (const double*)t->G, (const double*)t->hnew, s->N, s->Npad, s->D,
+                     s->sh.pitch);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s->stream));
   return 0;
 }
 
@@ -907,6 +951,7 @@ int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal,
     done += 1;
   }
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  s->undo_valid = (n_iter == 1 && done == 1);   // mjhmc_rollback's contract: the last call was ONE committed iteration
   s->last_jump_launches = std::min(done + 1, n_iter);
   s->timing_pending = true;
   if (n_done) *n_done = done;

@@ -215,3 +215,53 @@ def test_tf_distributions_import_path():
         np.random.seed(5)
         outs.append(s.sample(6))
     assert bits_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('what', ['iso', 'iso_wide', 'pot32', 'pot64', 'pot64_L0', 'host'])
+def test_rollback_undoes_a_committed_single_iteration(what):
+    """mjhmc_rollback (include/mjhmc_hip.h): after mjhmc_iterate(1) committed, the pre-move state comes back bit for bit
+    -- by flipping the ping-pong parities (register / tile kernels) or by copying back the rows the multi-pass commit
+    left in its proposal workspace (rows wider than the register kernels, ProductOfT float64 with L = 0, opaque
+    callables).  A second rollback, and one after a multi-iteration call, are refused."""
+    from mjhmc_amd import engine, _lib
+    from tests.helpers import ref_init_weights
+    ctx = engine.context(0)
+    rs = np.random.RandomState(3)
+    L = 4
+    if what.startswith('iso'):
+        D, N = (1030, 50) if what == 'iso_wide' else (24, 200)
+        en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.3])
+        s = engine.DeviceSampler(en, rs.randn(D, N), seed=5)
+    elif what.startswith('pot'):
+        D, N = 36, 100
+        W, lognu = ref_init_weights(D, D)
+        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], (W + np.eye(D)).ravel(), np.exp(lognu), np.zeros(D)]))
+        s = engine.DeviceSampler(en, rs.randn(D, N), seed=5, dtype='float32' if what == 'pot32' else 'float64')
+        if what == 'pot64_L0':
+            L = 0
+    else:
+        D, N = 12, 40
+        A = rs.randn(D, D)
+        A = A.dot(A.T) / D + np.eye(D)
+        en = engine.DeviceEnergy.host(ctx, D, lambda X: 0.5 * np.sum(X * A.dot(X), axis=0), lambda X: A.dot(X))
+        s = engine.HostEnergySampler(en, rs.randn(D, N), seed=5)
+    s.set_hparams(0.1, L, 0.2, 1.0)
+    s.iterate(2)
+    fields = [_lib.F_X, _lib.F_V, _lib.F_EX, _lib.F_EV, _lib.F_HFLF] + ([_lib.F_DEDX] if what != 'iso' else [])
+    before = [s.read(f) for f in fields]
+    tick = s.get_tick()
+    st, done = s.iterate(1)
+    assert done == 1
+    assert any(not np.array_equal(a, s.read(f), equal_nan=True) for a, f in zip(before, fields))
+    s.rollback()
+    for a, f in zip(before, fields):
+        assert np.array_equal(a, s.read(f), equal_nan=True), (what, f)
+    assert s.get_tick() == tick + 1                         # the tick stays consumed
+    with pytest.raises(_lib.EngineError):
+        s.rollback()
+    # the sampler goes on from the restored state exactly like one that never made the rolled-back attempt
+    s.iterate(2)
+    if what != 'host':                                      # (a host-evaluated energy is driven one attempt at a time)
+        with pytest.raises(_lib.EngineError):
+            s.rollback()                                    # a multi-iteration call cannot be undone this way
+    s.close()

@@ -21,9 +21,9 @@ smp.set_hparams(w['eps'], w['L'], -np.log(1 - w['beta']) * 0.5, 1.0)
 smp.iterate(3)
 smp.sync()
 lib = _lib.load()
-st = np.zeros((4, 8), dtype=np.uint64)
+st = np.zeros((4, 8, 8), dtype=np.uint64)     # [wave][slot][part]; the float32-state kernels write slot 0
 rc = lib.mjhmc_pot_stamps(st.ctypes.data_as(ctypes.c_void_p))
-st = st.astype(np.int64)
+st = st.astype(np.int64)[:, 0, :]
 names = ['enter', 'past barrier 1', 'GEMM1 done', 'phi + publish done', 'past barrier 2', 'GEMM2 done']
 print('rc', rc, ' cycles since the wave entered the gradient (MFMA time of one GEMM: 1024 x 64 = 65 536)')
 for wv in range(4):
