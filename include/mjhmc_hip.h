@@ -115,7 +115,7 @@ int mjhmc_abi_version(void);
 
 int mjhmc_ctx_create(int device, mjhmc_ctx** out);
 int mjhmc_ctx_destroy(mjhmc_ctx* ctx);
-/* name, CU count, HBM bytes of the bound device */
+/* name ("<marketing name> (<gcn arch>) [<pci domain:bus:device.0>]"), CU count, HBM bytes of the bound device */
 int mjhmc_ctx_info(mjhmc_ctx* ctx, char* name, size_t name_cap, int* n_cu, uint64_t* hbm_bytes);
 
 /* Replaces constructing a Distribution subclass (mjhmc/misc/distributions.py:20-59). */

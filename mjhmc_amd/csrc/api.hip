@@ -565,7 +565,9 @@ int mjhmc_ctx_destroy(mjhmc_ctx* ctx) {
 int mjhmc_ctx_info(mjhmc_ctx* ctx, char* name, size_t name_cap, int* n_cu, uint64_t* hbm_bytes) {
   if (!ctx) return fail(MJHMC_ERR_INVALID, "ctx is NULL");
   if (name && name_cap) {
-    std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    // ... and its PCI address, e.g. "[0000:75:00.0]": how a caller finds the device's sysfs / SMI entry
+    std::snprintf(name, name_cap, "%s (%s) [%04x:%02x:%02x.0]", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.pciDomainID,
+                  ctx->prop.pciBusID, ctx->prop.pciDeviceID);
   }
   if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;

@@ -85,3 +85,36 @@ def test_file_rendezvous_and_stale_proof_default_path(tmp_path, monkeypatch):
     assert not explicit and str(os.getppid()) in path and len(os.path.basename(path).split('_')) >= 5
     monkeypatch.setenv('MJHMC_COMM_ID_FILE', str(tmp_path / 'x.id'))
     assert default_id_path() == (str(tmp_path / 'x.id'), True)
+
+
+def _fake_run(extra_env, n=3):
+    import time
+    env = dict(_clean_env(), MJHMC_BENCH_FAKE='1', **extra_env)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, '--gpus', str(n), '--steps', '2', '--warmup', '1'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    return p, time.time() - t0
+
+
+def test_a_hung_rank_is_found_by_the_watchdog_and_the_run_switches_to_gloo():
+    """The first 8-GPU run must fail fast: the sample all-gather check runs FIRST, and the spawning parent watches the
+    ranks' milestones.  A rank that hangs where a broken collective would (MJHMC_BENCH_FAKE: no GPU, nothing loaded) is
+    found within MJHMC_BENCH_GATHER_TIMEOUT, the attempt is stopped, and FRESH processes run on the gloo safety net --
+    the line says why."""
+    p, dt = _fake_run({'MJHMC_BENCH_FAKE_HANG': '1', 'MJHMC_BENCH_GATHER_TIMEOUT': '3'})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rep = json.loads(lines[0])
+    assert rep['fake'] and 'did not finish within 3 s' in rep['comm_note'] and 'gloo' in rep['comm_note']
+    assert 'ranks [1]' in p.stderr.decode()                  # the watchdog names the rank that did not get through
+    assert dt < 60, dt                                       # found within the limit, not at the end of some global budget
+
+
+def test_a_healthy_run_is_not_disturbed_by_the_watchdog_and_a_stall_later_on_is_found_too():
+    p, dt = _fake_run({})
+    assert p.returncode == 0 and json.loads(p.stdout.decode().strip())['comm_note'] is None
+    # a rank that goes silent AFTER the gather check: the stall limit catches it
+    p, dt = _fake_run({'MJHMC_BENCH_FAKE_WORK_S': '3600', 'MJHMC_BENCH_RCCL_TIMEOUT': '3'})
+    assert p.returncode == 0 and dt < 60
+    assert 'no rank reported a milestone for 3 s' in json.loads(p.stdout.decode().strip())['comm_note']

@@ -93,6 +93,46 @@ def test_full_size_c3_product_of_t():
     assert np.array_equal(cache, s._dev.read(8) == 0)
 
 
+def test_full_size_c3_in_the_references_arithmetic():
+    """configs[2] as the reference runs it: float64 HMCState arrays around the float32 force (distributions.py:408-415,
+    hmc_state.py:29-38) on the tile kernel with the state streamed through its epilogue (csrc/dense_pot64.hip) -- the
+    line's top level.  Compared with orc.ProductOfT(force_dtype=float32) WITHOUT any state rounding: what is left is the
+    summation order inside the float32 matrix products -- 512-term float32 sums, twice per gradient, 20 gradients per
+    trajectory: 4e-6 of the state's scale."""
+    from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    from mjhmc_amd.misc.distributions import ProductOfT
+    w = bench.WORKLOADS['c3f64']
+    D, N, L, eps, beta = w['D'], w['N'], w['L'], w['eps'], w['beta']
+    W, lognu = bench.pot_model(D)
+    X0 = bench.initial_state(w, N, 0)
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0
+    d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W, state_dtype='float64')
+    s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=21, resample=False)
+    cols = np.sort(np.random.RandomState(5).choice(N, size=48, replace=False))
+    o = orc.MarkovJumpHMC(orc.ProductOfT(W, lognu=lognu, force_dtype=np.float32), X0[:, cols], epsilon=eps, beta=beta,
+                          num_leapfrog_steps=L, resample=False, rng=orc.PhiloxRNG(21, cols))
+    assert np.allclose(s.state.V[:, cols], o.state.V, rtol=0, atol=1e-13)        # float64 normals, no state rounding
+    resync(s, o, cols)
+    d.E_count = d.dEdX_count = 0
+    for it in range(3):                                     # the first with every inverse-L cache cold, then warm caches
+        n_cold = int(np.sum(~s.state.cache_active))
+        e0, g0 = d.E_count, d.dEdX_count
+        check_iteration(s, o, delta_rel=4e-6, x_tol=4e-6, e_rtol=4e-6, tag='C3 f64 it %d' % it, cols=cols)
+        assert d.E_count - e0 == N + n_cold and d.dEdX_count - g0 == (N + n_cold) * L
+        assert s.l_count + s.f_count + s.r_count == (it + 1) * N
+        if it < 2:
+            resync(s, o, cols)
+    X = s.state.X
+    assert X.dtype == np.float64 and np.abs(X[:, :64] - X[:, :64].astype(np.float32)).max() > 0          # not float32 values
+    # stored energies == energies re-evaluated from the stored state (float32 force on the downcast state, float64 sum(V^2))
+    assert np.allclose(s.state.EX[0, :2048], d.E(X[:, :2048])[0], rtol=4e-6, atol=1e-4)
+    assert np.allclose(s.state.EV[0], np.sum(s.state.V ** 2, axis=0) / 2., rtol=1e-12)
+    assert np.array_equal(s.state.cache_active, s._dev.read(8) == 0)
+
+
 @pytest.mark.parametrize('eps,n_iter', [(0.0625, 1), (0.05, 3)])
 def test_full_size_c5_sparse_image_code(eps, n_iter):
     """configs[4]: SparseImageCode, 1024 coefficients / 256-pixel patch, nparticles=200000 (the whole batch on one

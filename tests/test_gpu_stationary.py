@@ -176,3 +176,43 @@ def test_leapfrog_conserves_energy_second_order_and_a_wrong_gradient_does_not():
     a = np.median(_energy_error(bad, X, V, 0.05, 8, 'float64'))
     b = np.median(_energy_error(bad, X, V, 0.025, 16, 'float64'))
     assert a > 0.05 and not (3.0 < a / b < 5.0), (a, b)
+
+
+@pytest.mark.parametrize('nc,P,cauchy', [(1024, 1, True), (1024, 1, False), (1024, 9, True), (1024, 9, False),
+                                         (512, 1, True), (512, 1, False), (512, 9, True), (512, 9, False)])
+def test_sic_leapfrog_conserves_energy_second_order(nc, P, cauchy):
+    """An oracle-independent check of the bf16 SparseImageCode kernel (tf_distributions.py:241-272): its dE/dX is the
+    gradient of its E.  The leapfrog energy error H(L z) - H(z) through mjhmc_leapfrog (bf16 state, bf16 matrix-core
+    operands, float32 accumulation) is second order in the step: at eps / 2 and twice the steps its mean over the batch
+    is ~4x smaller.  (The MEAN: rounding the end point to bf16 adds zero-mean noise of ~0.05 per particle -- the floor
+    the median |dH| runs into below eps = 0.025, tools/sic_energy_error.py -- which averages out over 512 chains.)
+    Negative control: the same trajectories measured with the energy of a prior twice as strong (i.e. the kernel's
+    prior force is half what that H needs) -- the error is large and does not shrink."""
+    from mjhmc_amd import engine, _lib
+    from tests.helpers import sic_problem, to_bf16
+    ctx = engine.context(0)
+    B, imgs, a0 = sic_problem(3, n_patches=P, n_coeffs=nc)
+    N, D = 512, P * nc
+    rs = np.random.RandomState(1)
+    X = to_bf16(a0[:, None] + 0.1 * rs.randn(D, N))
+    V = to_bf16(rs.randn(D, N))
+
+    def energy(lam):
+        return engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, D, np.concatenate(
+            [[float(P), 256.0, float(nc), lam, 1.0 if cauchy else 0.0], B.ravel(), imgs[:, :P].T.ravel()]))
+    en, en2 = energy(0.01), energy(0.02)
+
+    def mean_dH(measure, eps, L):
+        E0, _ = measure.eval(X, want_E=True, want_grad=False, dtype='bfloat16')
+        Xo, Vo, EX, EV, _ = en.leapfrog(X, V, eps, L, want_grad=False, dtype='bfloat16')
+        if measure is en:                                   # the operator's own energies ARE those of the stored end point
+            E1, _ = en.eval(Xo, want_E=True, want_grad=False, dtype='bfloat16')
+            assert np.allclose(EX, E1, rtol=1e-5, atol=1e-4) and np.allclose(EV, 0.5 * np.sum(Vo ** 2, axis=0), rtol=1e-5)
+        else:
+            E1, _ = measure.eval(Xo, want_E=True, want_grad=False, dtype='bfloat16')
+        return float(np.mean((E1 + 0.5 * np.sum(Vo ** 2, axis=0)) - (E0 + 0.5 * np.sum(V ** 2, axis=0))))
+
+    m1, m2 = mean_dH(en, 0.1, 4), mean_dH(en, 0.05, 8)
+    assert abs(m2) < 0.25 and 3.0 < m1 / m2 < 6.5, (m1, m2)
+    w1, w2 = mean_dH(en2, 0.1, 4), mean_dH(en2, 0.05, 8)
+    assert abs(w2) > 0.5 and abs(w2) > 4 * abs(m2) and w1 / w2 < 2.0, (w1, w2)
