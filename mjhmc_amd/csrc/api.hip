@@ -80,10 +80,14 @@ int pick_shape(int D, int dtype, Shape* out) {
     if (G > 64) {
       // more dims than 64 lanes x 16 elements hold: float64 samplers of the built-in elementwise energies take the
       // multi-pass path (host_energy.hip: state in HBM between the substeps); others have no such form
-      if (dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "ndims too large for the register-resident float32 kernels (float64 has a multi-pass path)");
+      // (float32 state: the same path on float64 storage, the state rounded to float32 wherever it is written)
+      s.esize = 8;
+      s.pitch = (D + 1) / 2 * 2;
+      s.CH = s.pitch / 2;
       s.E = 0;
       s.logG = 0;
       s.wide = true;
+      s.round32 = dtype != MJHMC_F64;
       *out = s;
       return 0;
     }
@@ -91,6 +95,40 @@ int pick_shape(int D, int dtype, Shape* out) {
   s.E = C * VEC;
   s.logG = ilog2(G);
   *out = s;
+  return 0;
+}
+
+// row layout and path of a sampler (or of a one-off evaluation) of energy e with state dtype `dtype`.  On return *dtype is
+// the dtype the state is STORED in (float64 where float32 was asked for rows only the multi-pass path handles: sh->round32)
+static int shape_for(const mjhmc_energy* e, int* dtype, Shape* sh) {
+  if (e->is_pot()) {
+    if (*dtype != MJHMC_F64 && *dtype != MJHMC_F32) return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs with float32 or float64 state");
+    if (*dtype == MJHMC_F64 || e->pot_big()) {
+      // the reference's own arithmetic: float64 HMCState arrays around the float32 force (distributions.py:408-415,
+      // hmc_state.py:29-38); ndims > 512: the blocked force evaluation exists on the multi-pass path only
+      *sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};
+      sh->round32 = *dtype != MJHMC_F64;
+    } else {
+      *sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
+    }
+  } else if (e->is_sic()) {
+    *sh = Shape{0, 0, e->ep.ndims, e->ep.ndims / 8, 2};  // a particle row = n_patches x 1024 bfloat16
+  } else {
+    TRY(pick_shape(e->ep.ndims, *dtype, sh));
+  }
+  if (sh->round32) *dtype = MJHMC_F64;
+  return 0;
+}
+
+// float32-valued float64 rows (Shape::round32)
+__global__ void round32_kernel(double* __restrict__ a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (double)(float)a[i];
+}
+int round_rows32(mjhmc_sampler* s, void* rows) {
+  const int64_t n = s->Npad * (int64_t)s->sh.pitch;
+  hipLaunchKernelGGL(round32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double*)rows, n);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -634,14 +672,12 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         rc = fail(MJHMC_ERR_INVALID, "PRODUCT_OF_T expects {nbasis == ndims, W[D*K], nu[K], b[K]}");
         break;
       }
-      if (ndims > kPotDim) {
-        rc = fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T supports ndims <= 512 in this build");
-        break;
-      }
       const double* W = params + 1;
       const double* nu = W + (size_t)ndims * K;
       const double* b = nu + K;
-      const int DIM = ndims <= 128 ? 128 : (ndims <= 256 ? 256 : 512);
+      // up to 512 dims: the register-resident tile kernels; beyond: 512 x 512 blocks for the multi-pass path (pot_big_eval)
+      const int DIM = ndims <= 128 ? 128 : (ndims <= 256 ? 256 : (ndims + 511) / 512 * 512);
+      const int nb = DIM / 512;   // (>= 2: blocked storage)
       e->pot_dim = DIM;
       const size_t M = (size_t)DIM * DIM;
       std::vector<float> w1(M, 0.f), w2t(M, 0.f), cb(DIM, 0.f), al(DIM, 0.f);
@@ -652,8 +688,14 @@ int mjhmc_energy_create(mjhmc_ctx* ctx, int kind, int ndims, const double* param
         al[j] = (float)((nuj + 1.0) / 2.0);
         for (int d = 0; d < ndims; ++d) {
           const double wdj = (double)(float)W[(size_t)d * K + j];
-          w1[(size_t)d * DIM + j] = (float)(wdj / nuj);
-          w2t[(size_t)j * DIM + d] = (float)(wdj * (nuj + 1.0) / nuj);
+          if (nb < 2) {
+            w1[(size_t)d * DIM + j] = (float)(wdj / nuj);
+            w2t[(size_t)j * DIM + d] = (float)(wdj * (nuj + 1.0) / nuj);
+          } else {   // W1b[db][jb][d % 512][j % 512], W2Tb[jb][db][j % 512][d % 512]
+            const size_t db = (size_t)d / 512, jb = (size_t)j / 512, dl = (size_t)d % 512, jl = (size_t)j % 512;
+            w1[((db * nb + jb) * 512 + dl) * 512 + jl] = (float)(wdj / nuj);
+            w2t[((jb * nb + db) * 512 + jl) * 512 + dl] = (float)(wdj * (nuj + 1.0) / nuj);
+          }
         }
       }
       const void* src[4] = {w1.data(), w2t.data(), cb.data(), al.data()};
@@ -863,27 +905,12 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   s->dtype = dtype;
   s->mode = mode;
   s->seed = seed;
-  int rc = 0;
-  if (e->is_pot()) {
-    if (dtype == MJHMC_F64) {
-      // the reference's own arithmetic: float64 HMCState arrays around the float32 force (distributions.py:408-415,
-      // hmc_state.py:29-38) -- the multi-pass path, the force from the float32 matrix-core evaluation kernel
-      s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};
-    } else if (dtype != MJHMC_F32) {
-      delete s;
-      return fail(MJHMC_ERR_UNSUPPORTED, "PRODUCT_OF_T runs with float32 or float64 state");
-    } else {
-      s->sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
-    }
-  } else if (e->is_sic()) {
-    s->sh = Shape{0, 0, s->D, s->D / 8, 2};  // a particle row = n_patches x 1024 bfloat16
-  } else {
-    rc = pick_shape(s->D, dtype, &s->sh);
-  }
+  int rc = shape_for(e, &s->dtype, &s->sh);
   if (rc) {
     delete s;
     return rc;
   }
+  dtype = s->dtype;   // (the storage dtype)
   auto build = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t mb = mat_bytes(s);
@@ -901,7 +928,7 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
           HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * ssize(s)));  // float32, or float64 for ProductOfT's float64 state
           HIPCHK(hipMemsetAsync(s->Hwork, 0, s->Npad * ssize(s), s->stream));   // (padding rows read it and ignore it)
           HIPCHK(hipMalloc((void**)&s->cold_list, (2 * s->Npad + 4) * sizeof(int)));  // two lists (iterations alternate) + [half][parity] counters
-          if (e->is_pot() && dtype == MJHMC_F64)   // working rows of the inverse-L pass, for two concurrent launches
+          if (e->is_pot() && dtype == MJHMC_F64 && !e->pot_big())   // working rows of the inverse-L pass, for two concurrent launches
             HIPCHK(hipMalloc((void**)&s->pot64_scratch, (size_t)2 * pot64_scratch_workgroups() * 2 * 32 * row_bytes(s)));
         }
       }
@@ -928,11 +955,17 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
     HIPCHK(hipMalloc((void**)&s->stats, (size_t)s->stats_cap * 4 * sizeof(long long)));
     s->Xcur = s->Xbuf[0];
     TRY(upload_matrix(s, Xinit, s->Xcur));
+    if (s->sh.round32) TRY(round_rows32(s, s->Xcur));
     if (Vinit) {
       TRY(upload_matrix(s, Vinit, s->Vbuf[0]));
+      if (s->sh.round32) TRY(round_rows32(s, s->Vbuf[0]));
       TRY(run_eval(s, s->Xcur, s->Gbuf[0], s->EX[0], s->Vbuf[0], nullptr, s->EV[0]));
     } else {
       TRY(run_eval(s, s->Xcur, s->Gbuf[0], s->EX[0], nullptr, s->Vbuf[0], s->EV[0]));
+      if (s->sh.round32) {   // the generated momentum is stored in float32 too: its kinetic energy is that of what is stored
+        TRY(round_rows32(s, s->Vbuf[0]));
+        TRY(run_eval(s, nullptr, nullptr, nullptr, s->Vbuf[0], nullptr, s->EV[0]));
+      }
     }
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
@@ -1863,7 +1896,8 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   HIPCHK(hipSetDevice(s->ctx->device));
   // ProductOfT with float64 state: the tile kernel with the state streamed through its epilogue (dense_pot64.hip); its
   // multi-pass form (the same arithmetic, bit for bit) serves L = 0 and, in the test build, the A/B switch
-  const bool pot64_fused = s->sh.wide && s->en->is_pot() && s->L >= 1 && !test_env("MJHMC_POT64_MULTIPASS");
+  const bool pot64_fused = s->sh.wide && s->en->is_pot() && !s->en->pot_big() && !s->sh.round32 && s->L >= 1 &&
+                           !test_env("MJHMC_POT64_MULTIPASS");
   if (s->sh.wide && !pot64_fused)
     return multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
   return s->dtype == MJHMC_F64
@@ -1957,6 +1991,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       s->undo_valid = false;
       if (field == MJHMC_F_X) s->host_energy_set = false;  // MJHMC_E_HOST: E and dE/dX of the new X are the caller's to supply
       TRY(upload_matrix(s, (const double*)host_src, dst));
+      if (s->sh.round32) TRY(round_rows32(s, dst));
       TRY(run_eval(s, s->Xcur, s->Gbuf[s->vcur], s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
       HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
@@ -2141,14 +2176,8 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   w.first_pid = 0;
   w.D = e->ep.ndims;
   w.dtype = dtype;
-  if (e->is_pot()) {
-    if (dtype == MJHMC_F64) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};  // float64 in and out, float32 force
-    else w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
-  } else if (e->is_sic()) {
-    w.sh = Shape{0, 0, w.D, w.D / 8, 2};
-  } else {
-    TRY(pick_shape(w.D, dtype, &w.sh));
-  }
+  TRY(shape_for(e, &w.dtype, &w.sh));
+  dtype = w.dtype;
   void *Xd = nullptr, *Gd = nullptr, *Ed = nullptr;
   auto body = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -2158,6 +2187,7 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
     if (dEdX_out) HIPCHK(hipMalloc(&Gd, e->is_sic() ? (size_t)w.Npad * w.D * sizeof(float) : mb));
     if (E_out) HIPCHK(hipMalloc(&Ed, w.Npad * ssize(&w)));
     TRY(upload_matrix(&w, X, Xd));
+    if (w.sh.round32) TRY(round_rows32(&w, Xd));
     TRY(run_eval(&w, Xd, Gd, Ed, nullptr, nullptr, nullptr));
     if (E_out) TRY(read_vec(&w, Ed, E_out, (size_t)n * sizeof(double)));
     w.download_f32 = e->is_sic();
@@ -2195,10 +2225,8 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
   w.first_pid = 0;
   w.D = e->ep.ndims;
   w.dtype = dtype;
-  if (e->is_pot() && dtype == MJHMC_F64) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 2, 8, true};
-  else if (e->is_pot()) w.sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
-  else if (e->is_sic()) w.sh = Shape{0, 0, w.D, w.D / 8, 2};
-  else TRY(pick_shape(w.D, dtype, &w.sh));
+  TRY(shape_for(e, &w.dtype, &w.sh));
+  dtype = w.dtype;
   void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // X, V, X', V', G, EX, EV
   auto body = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -2213,6 +2241,10 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
     if (EV_out) HIPCHK(hipMalloc(&buf[6], vb));
     TRY(upload_matrix(&w, X, buf[0]));
     TRY(upload_matrix(&w, V, buf[1]));
+    if (w.sh.round32) {
+      TRY(round_rows32(&w, buf[0]));
+      TRY(round_rows32(&w, buf[1]));
+    }
     if (e->is_pot() && !w.sh.wide) {
       PotLeapArgs a;
       a.X = (const float*)buf[0];

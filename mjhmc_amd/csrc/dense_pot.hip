@@ -291,6 +291,94 @@ static int resident_cus() {
   return std::max(1, cus);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ndims == nbasis > 512: blocked evaluation (multi-pass path only).  C[:, cblk] (+)= M_block^T-form GEMM of B[:, bblk]:
+// one launch per 512 x 512 block of the matrix, the tile kernels' own GEMM (gemm_dim<4>) on a tile of 32 rows.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_load_ld(const float* base, int64_t ld, int64_t p, int w, int h, Tile<4>& t) {
+  const float* row = base + (size_t)p * ld + 128 * w;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * acc_row(q, h));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t.b[r][q] = v[r];
+  }
+}
+__device__ __forceinline__ void tile_store_ld(float* base, int64_t ld, int64_t p, int w, int h, const Tile<4>& t) {
+  float* row = base + (size_t)p * ld + 128 * w;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = t.b[r][q];
+    *reinterpret_cast<f32x4*>(row + 4 * acc_row(q, h)) = v;
+  }
+}
+
+// C tile (32 rows x this block's 512 columns) = [init vector | C tile] + sum over the block's 512 k-rows
+__global__ __launch_bounds__(256, 1) void pot_block_gemm_kernel(const float* __restrict__ M, const float* __restrict__ B, float* C,
+                                                                int64_t ld, const float* __restrict__ initvec, int accumulate,
+                                                                int64_t ntiles) {
+  __shared__ Shared<4> sh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  typename VecN<4>::type a0[16];
+  a_chunk_load<4>(M + (size_t)(16 * h) * 512 + 128 * w + 4 * c, 0, a0);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p = tile * kP + c;
+    Tile<4> x, acc;
+    tile_load_ld(B, ld, p, w, h, x);
+    publish<4>(sh.pub[0][w], lane, x);
+    if (accumulate) tile_load_ld(C, ld, p, w, h, acc);
+    else if (initvec) rowvec_load<4>(initvec, w, h, acc);
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc.b[r][q] = 0.f;
+    }
+    __syncthreads();
+    gemm_dim<4>(M, M, sh.pub[0], w, c, h, lane, a0, acc);   // (a0 leaves holding chunk 0 of the same block: the next tile's)
+    tile_store_ld(C, ld, p, w, h, acc);
+    __syncthreads();
+  }
+}
+
+// E = sum_j alpha_j log(1 + u_j^2) per row (distributions.py:430-432); u <- phi(u) = u / (1 + u^2) in place
+__global__ void pot_big_phi_kernel(float* __restrict__ U, float* __restrict__ E, const float* __restrict__ alpha, int dim,
+                                   int64_t rows) {
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  float* u = U + (size_t)r * dim;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < dim; j += 64) {
+    const float uu = u[j];
+    if (E) s += alpha[j] * logf(1.0f + uu * uu);
+    u[j] = uu * __builtin_amdgcn_rcpf(1.0f + uu * uu);
+  }
+  if (E) {
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) E[r] = s;
+  }
+}
+
+void pot_big_eval(const PotBigModel& m, const float* X32, float* G32, float* E32, float* U, int64_t rows_pad, hipStream_t st) {
+  const int nb = m.dim / 512;
+  const int64_t ntiles = rows_pad / 32;
+  const unsigned grid = (unsigned)std::min<int64_t>(ntiles, resident_cus());
+  const size_t blk = (size_t)512 * 512;
+  for (int jb = 0; jb < nb; ++jb)      // u[:, jb] = cb[jb] + sum_db W1[db, jb]^T x[:, db]
+    for (int db = 0; db < nb; ++db)
+      hipLaunchKernelGGL(pot_block_gemm_kernel, dim3(grid), dim3(256), 0, st, m.W1b + ((size_t)db * nb + jb) * blk,
+                         X32 + (size_t)db * 512, U + (size_t)jb * 512, (int64_t)m.dim, m.cb + (size_t)jb * 512, db > 0 ? 1 : 0, ntiles);
+  hipLaunchKernelGGL(pot_big_phi_kernel, dim3((unsigned)rows_pad), dim3(64), 0, st, U, E32, m.alpha, m.dim, rows_pad);
+  if (!G32) return;
+  for (int db = 0; db < nb; ++db)      // dE/dx[:, db] = sum_jb W2T[jb, db]^T phi(u)[:, jb]
+    for (int jb = 0; jb < nb; ++jb)
+      hipLaunchKernelGGL(pot_block_gemm_kernel, dim3(grid), dim3(256), 0, st, m.W2Tb + ((size_t)jb * nb + db) * blk,
+                         (const float*)U + (size_t)jb * 512, G32 + (size_t)db * 512, (int64_t)m.dim, (const float*)nullptr, jb > 0 ? 1 : 0,
+                         ntiles);
+}
+
 template <int NB, int MODE>
 static void launch_jump_mode(const PotJumpArgs& a, const PotModel& mdl, unsigned grid, hipStream_t st) {
   const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);

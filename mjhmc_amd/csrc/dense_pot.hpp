@@ -7,7 +7,8 @@
 
 namespace mjhmc {
 
-constexpr int kPotDim = 512;  // largest supported ndims == nbasis (rows are zero padded to 128, 256 or 512)
+constexpr int kPotDim = 512;  // largest ndims == nbasis of the register-resident tile kernels (rows are zero padded to 128, 256 or 512);
+                              // beyond it: blocked evaluation on the multi-pass path (PotBigModel, pot_big_eval)
 
 // device-resident model, float32, padded to 512 x 512
 struct PotModel {
@@ -231,6 +232,20 @@ __device__ __forceinline__ void normal_pair_f32(const RngKey& k, uint32_t pid, u
   z0 = r * c;
   z1 = r * s;
 }
+
+// ndims == nbasis > 512 (the reference takes any square size, distributions.py:379-406): the pre-scaled matrices as
+// 512 x 512 BLOCKS, each laid out like a whole 512-dim model's matrix, so that the tile kernels' GEMM runs on them as is
+struct PotBigModel {
+  const float* W1b;    // [db][jb][512][512]: block (db, jb) of W[d][j] / nu_j
+  const float* W2Tb;   // [jb][db][512][512]: block (jb, db) of (W[d][j] (nu_j + 1) / nu_j)^T
+  const float* cb;     // [dim]
+  const float* alpha;  // [dim]
+  int dim;             // ndims rounded up to a multiple of 512
+  int ndims;
+};
+// E (or nullptr) and dE/dX (or nullptr) of rows X32 [rows_pad][dim] (float32, rows_pad a multiple of 32); U: scratch of
+// the same shape.  2 (dim / 512)^2 block-GEMM launches + one elementwise pass.
+void pot_big_eval(const PotBigModel& m, const float* X32, float* G32, float* E32, float* U, int64_t rows_pad, hipStream_t st);
 
 void pot_launch_jump(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st);
 void pot_launch_eval(const PotEvalArgs& a, const PotModel& mdl, hipStream_t st);

@@ -44,8 +44,10 @@ struct mjhmc_energy {
   void* dev64 = nullptr;
   void* dev32 = nullptr;
   float* pot[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT: W1, W2T, cb, alpha (float32, padded to 512)
-  int pot_dim = kPotDim;  // rows padded to 128, 256 or 512
+  int pot_dim = kPotDim;  // rows padded to 128, 256 or 512 -- or, beyond the tile kernels, to a multiple of 512 (pot_big())
   PotModel pot_model() const { return PotModel{pot[0], pot[1], pot[2], pot[3], pot_dim, ep.ndims}; }
+  bool pot_big() const { return is_pot() && pot_dim > kPotDim; }   // matrices stored as 512 x 512 blocks, multi-pass path only
+  PotBigModel pot_big_model() const { return PotBigModel{pot[0], pot[1], pot[2], pot[3], pot_dim, ep.ndims}; }
   bool is_pot() const { return ep.kind == MJHMC_E_PRODUCT_OF_T; }
   void* sic[3] = {nullptr, nullptr, nullptr};  // SparseImageCode: A1, A2 (bf16, fragment order), y (float32 [P][256])
   float sic_lambda = 0.f;
@@ -70,6 +72,9 @@ struct Shape {
   // ndims beyond the register-resident elementwise kernels (> 64 lanes x 16 elements): the sampler runs the multi-pass
   // path of host_energy.hip, state in HBM between the substeps (float64, built-in elementwise energies)
   bool wide = false;
+  // float32 state was asked for, for rows only the multi-pass path handles: the sampler runs as a float64 one whose state
+  // is rounded to float32 at the end of every operation that writes it (the caller sees float32 values throughout)
+  bool round32 = false;
 };
 
 
@@ -155,6 +160,7 @@ int wide_run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const
 int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                       const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
 int multipass_rollback(mjhmc_sampler* s);
+int round_rows32(mjhmc_sampler* s, void* rows);   // float64 rows -> float32 values (Shape::round32), api.hip
 int wide_leapfrog(mjhmc_sampler* w, const double* X, const double* V, double* Xo, double* Vo, double* G, double* EX,
                   double* EV, double eps, int n_steps);
 

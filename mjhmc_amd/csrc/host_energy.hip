@@ -40,7 +40,8 @@ struct HostTraj {
   int* kmove = nullptr;     // [Npad] decision of the attempt
   double* dtmp = nullptr;   // [Npad] dwelling time of the attempt
   double* hnew = nullptr;   // [3 Npad] EX, EV, H_flf of the successor
-  float* pot32[3] = {nullptr, nullptr, nullptr};  // ProductOfT with float64 state: float32 X, dE/dX rows and E of the force evaluation
+  float* pot32[4] = {nullptr, nullptr, nullptr, nullptr};  // ProductOfT with float64 state: float32 X, dE/dX rows and E of the force
+                                                           // evaluation; [3]: the u / phi(u) rows of the blocked evaluation (ndims > 512)
   int n_cold = 0;
   int64_t n_cols = 0;
   int phase = 0;  // 0 idle, 1 begun (stepping), 2 last kick done
@@ -310,6 +311,7 @@ struct CommitArgs {
   unsigned long long* stats;
   int64_t N, Npad, first_pid;
   int D, pitch, mode;
+  int round32;    // the state is float32-valued (Shape::round32): successors are rounded as they are written
   double r_keep, r_mix;
   RngKey key;
 };
@@ -381,7 +383,13 @@ __global__ void hk_commit(const CommitArgs a) {
         z = (d & 1) ? z1 : z0;
       }
       vv = vv * a.r_keep + z * a.r_mix;
+      if (a.round32) vv = (double)(float)vv;
       ev += vv * vv;
+    }
+    if (a.round32) {
+      xv = (double)(float)xv;
+      vv = (double)(float)vv;
+      if (take) x[d] = xv;
     }
     v[d] = vv;
     if (a.ring_slot) a.ring_slot[p * a.pitch + d] = xv;
@@ -493,14 +501,37 @@ __global__ void hk_pot_close(double* __restrict__ V, const float* __restrict__ G
   G64[i] = g;
 }
 
+// the float32 force on rows buf[0] ([rows_pad][pitch] float32) -> dE/dX rows buf[1] (or none) and E buf[2] (or none): the
+// tile kernel's evaluation up to 512 dims, the blocked evaluation (buf[3]: its u rows) beyond
+static void pot_force32(mjhmc_sampler* s, float* const* buf, bool want_G, bool want_E, int64_t rows_pad, int64_t nrows) {
+  if (s->en->pot_big()) {
+    pot_big_eval(s->en->pot_big_model(), buf[0], want_G ? buf[1] : nullptr, want_E ? buf[2] : nullptr, buf[3], rows_pad, s->stream);
+    return;
+  }
+  PotEvalArgs a;
+  a.X = buf[0];
+  a.G = want_G ? buf[1] : nullptr;
+  a.E = want_E ? buf[2] : nullptr;
+  a.EV = nullptr;
+  a.V = nullptr;
+  a.V_gen = nullptr;
+  a.N = nrows;
+  a.ntiles = rows_pad / 32;
+  a.first_pid = 0;
+  a.D = s->D;
+  a.key = RngKey{0u, 0u, 0u, 0u};
+  pot_launch_eval(a, s->en->pot_model(), s->stream);
+}
+
 // ProductOfT as the reference runs it (distributions.py:408-415 with hmc_state.py:29-38): float64 HMCState arrays around
 // a float32 force -- the inputs are downcast (allow_input_downcast=True), E and dE/dX come back as float32.  The force is
 // the float32 matrix-core evaluation kernel of dense_pot.hip on a float32 copy of the rows.
 int pot_eval_rows_f64(mjhmc_sampler* s, const double* X, double* G, double* E, int64_t nrows) {
   const int pitch = s->sh.pitch;
   const int64_t rows_pad = (nrows + 63) / 64 * 64, ne = rows_pad * pitch;
-  float* tmp[3] = {nullptr, nullptr, nullptr};
+  float* tmp[4] = {nullptr, nullptr, nullptr, nullptr};
   float** buf = tmp;
+  const bool big = s->en->pot_big();
   const bool own = !(s->ht && rows_pad <= 2 * s->Npad);
   if (!own) {
     buf = s->ht->pot32;
@@ -509,28 +540,18 @@ int pot_eval_rows_f64(mjhmc_sampler* s, const double* X, double* G, double* E, i
       HIPCHK(hipMalloc((void**)&buf[0], cap * pitch * sizeof(float)));
       HIPCHK(hipMalloc((void**)&buf[1], cap * pitch * sizeof(float)));
       HIPCHK(hipMalloc((void**)&buf[2], cap * sizeof(float)));
+      if (big) HIPCHK(hipMalloc((void**)&buf[3], cap * pitch * sizeof(float)));
     }
   } else {
     HIPCHK(hipMalloc((void**)&buf[0], (size_t)ne * sizeof(float)));
     HIPCHK(hipMalloc((void**)&buf[1], (size_t)ne * sizeof(float)));
     HIPCHK(hipMalloc((void**)&buf[2], (size_t)rows_pad * sizeof(float)));
+    if (big) HIPCHK(hipMalloc((void**)&buf[3], (size_t)ne * sizeof(float)));
   }
   auto body = [&]() -> int {
     HIPCHK(hipMemsetAsync(buf[0], 0, (size_t)ne * sizeof(float), s->stream));  // rows beyond nrows: zeros, never NaN garbage
     hipLaunchKernelGGL(hk_narrow, grid1(nrows * pitch), dim3(256), 0, s->stream, X, buf[0], nrows * pitch);
-    PotEvalArgs a;
-    a.X = buf[0];
-    a.G = G ? buf[1] : nullptr;
-    a.E = E ? buf[2] : nullptr;
-    a.EV = nullptr;
-    a.V = nullptr;
-    a.V_gen = nullptr;
-    a.N = nrows;
-    a.ntiles = rows_pad / 32;
-    a.first_pid = 0;
-    a.D = s->D;
-    a.key = RngKey{0u, 0u, 0u, 0u};
-    pot_launch_eval(a, s->en->pot_model(), s->stream);
+    pot_force32(s, buf, G != nullptr, E != nullptr, rows_pad, nrows);
     if (G) hipLaunchKernelGGL(hk_widen, grid1(nrows * pitch), dim3(256), 0, s->stream, (const float*)buf[1], G, nrows * pitch);
     if (E) hipLaunchKernelGGL(hk_widen, grid1(nrows), dim3(256), 0, s->stream, (const float*)buf[2], E, nrows);
     HIPCHK(hipGetLastError());
@@ -587,7 +608,7 @@ void host_traj_free(mjhmc_sampler* s) {
   HostTraj* t = s->ht;
   if (!t) return;
   void* bufs[] = {t->X, t->V, t->G, t->E, t->EVw, t->noise, t->cold, t->coldpos, t->kmove, t->dtmp, t->hnew,
-                  t->pot32[0], t->pot32[1], t->pot32[2]};
+                  t->pot32[0], t->pot32[1], t->pot32[2], t->pot32[3]};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete t;
@@ -803,12 +824,21 @@ int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double
     c.D = s->D;
     c.pitch = pitch;
     c.mode = s->mode;
+    c.round32 = s->sh.round32 ? 1 : 0;
     c.r_keep = std::sqrt(1.0 - s->beta);  // hmc_state.py:125-126
     c.r_mix = std::sqrt(s->beta);
     c.key = key;
     if (replay) hipLaunchKernelGGL(hk_commit<true>, dim3((unsigned)s->N), dim3(64), 0, s->stream, c);
     else hipLaunchKernelGGL(hk_commit<false>, dim3((unsigned)s->N), dim3(64), 0, s->stream, c);
     HIPCHK(hipGetLastError());
+    if (s->sh.round32 && !s->en->is_host()) {
+      // float32-valued state: E, dE/dX and the kinetic energy are those of what is stored (as the float32 register
+      // kernels report them); one more evaluation per iteration on this fallback path, not a counted one
+      TRY(wide_eval_rows(s, (const double*)s->Xcur, (double*)s->Gbuf[s->vcur], (double*)s->EX[s->scur], s->N));
+      hipLaunchKernelGGL(hk_kinetic, dim3((unsigned)s->N), dim3(64), 0, s->stream, (const double*)s->Vbuf[s->vcur],
+                         (double*)s->EV[s->scur], s->N, s->D, pitch);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(hs, s->stats, sizeof(hs), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
   }
@@ -889,20 +919,10 @@ static int pot_trajectory_f64(mjhmc_sampler* s) {
     HIPCHK(hipMalloc((void**)&t->pot32[0], cap * pitch * sizeof(float)));
     HIPCHK(hipMalloc((void**)&t->pot32[1], cap * pitch * sizeof(float)));
     HIPCHK(hipMalloc((void**)&t->pot32[2], cap * sizeof(float)));
+    if (s->en->pot_big()) HIPCHK(hipMalloc((void**)&t->pot32[3], cap * pitch * sizeof(float)));
   }
   HIPCHK(hipMemsetAsync(t->pot32[0], 0, (size_t)rows_pad * pitch * sizeof(float), s->stream));  // rows beyond n: zeros
   const double c = -s->eps / 2.;
-  PotEvalArgs a;
-  a.X = t->pot32[0];
-  a.G = t->pot32[1];
-  a.EV = nullptr;
-  a.V = nullptr;
-  a.V_gen = nullptr;
-  a.N = n;
-  a.ntiles = rows_pad / 32;
-  a.first_pid = 0;
-  a.D = s->D;
-  a.key = RngKey{0u, 0u, 0u, 0u};
   for (int l = 0; l < s->L; ++l) {
     if (l == 0)
       hipLaunchKernelGGL(hk_pot_kick_drift<false>, grid1(ne), dim3(256), 0, s->stream, t->X, t->V, (const void*)t->G, t->pot32[0], c,
@@ -910,8 +930,7 @@ static int pot_trajectory_f64(mjhmc_sampler* s) {
     else
       hipLaunchKernelGGL(hk_pot_kick_drift<true>, grid1(ne), dim3(256), 0, s->stream, t->X, t->V, (const void*)t->pot32[1],
                          t->pot32[0], c, s->eps, 1, ne);
-    a.E = l == s->L - 1 ? t->pot32[2] : nullptr;
-    pot_launch_eval(a, s->en->pot_model(), s->stream);
+    pot_force32(s, t->pot32, true, l == s->L - 1, rows_pad, n);
     t->steps += 1;
   }
   hipLaunchKernelGGL(hk_pot_close, grid1(ne), dim3(256), 0, s->stream, t->V, (const float*)t->pot32[1], t->G, c, ne);
@@ -974,6 +993,11 @@ int wide_leapfrog(mjhmc_sampler* w, const double* X, const double* V, double* Xo
       hipLaunchKernelGGL(hk_axpy, grid1(nv), dim3(256), 0, w->stream, Xo, (const double*)Vo, eps, nv);
       TRY(wide_eval_rows(w, Xo, g, EX, w->N));
       hipLaunchKernelGGL(hk_axpy, grid1(nv), dim3(256), 0, w->stream, Vo, (const double*)g, c, nv);
+    }
+    if (w->sh.round32) {   // float32-valued state: the end point is rounded, its energies and dE/dX are those of what is handed out
+      TRY(round_rows32(w, Xo));
+      TRY(round_rows32(w, Vo));
+      TRY(wide_eval_rows(w, Xo, g, EX, w->N));
     }
     if (EV) hipLaunchKernelGGL(hk_kinetic, dim3((unsigned)w->N), dim3(64), 0, w->stream, (const double*)Vo, EV, w->N, w->D, w->sh.pitch);
     HIPCHK(hipGetLastError());

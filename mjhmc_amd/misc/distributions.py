@@ -352,11 +352,12 @@ class Funnel(Distribution):
 class ProductOfT(Distribution):
     """Product of Student-t experts (distributions.py:373-453).  The reference builds E and its
     gradient with Theano in float32; here both GEMMs of the gradient run on the MI355X matrix
-    cores (exact-f32 MFMA).  ndims == nbasis <= 512, as the reference's initialiser requires (:391-392).
+    cores (exact-f32 MFMA).  ndims == nbasis, as the reference's initialiser requires (:391-392); any size (up to 512 dims
+    on the register-resident tile kernels, beyond that block by block on the engine's multi-pass path).
 
     ``state_dtype`` (extension): 'float32' (default) keeps the particle state in float32 too -- the fused tile kernel,
     BASELINE configs[2]; 'float64' is the reference's own arithmetic, float64 ``HMCState`` arrays around the float32
-    force (:408-415 with hmc_state.py:29-38), on the engine's multi-pass path (state in HBM between the substeps)."""
+    force (:408-415 with hmc_state.py:29-38): the tile kernel with the state streamed through its epilogue."""
 
     def __init__(self, ndims=36, nbasis=36, nbatch=100, lognu=None, W=None, b=None, state_dtype='float32'):
         if ndims != nbasis:

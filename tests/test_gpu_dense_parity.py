@@ -100,6 +100,50 @@ def test_pot_single_evaluation_matches_autograd_fixture(tag, D, n, src):
     assert rel(G, g[tag + '_g']) < 8 * spread_g, (rel(G, g[tag + '_g']), spread_g)
 
 
+@pytest.mark.parametrize('D,N,state', [(768, 40, 'float64'), (1024, 70, 'float64'), (1024, 33, 'float32')])
+def test_pot_more_than_512_dims(D, N, state):
+    """distributions.py:379-406 takes any square size.  Beyond the 512 dims the register-resident tile kernels hold, the
+    force is evaluated block by block (512 x 512 blocks of the pre-scaled matrices, the tile kernels' own GEMM:
+    csrc/dense_pot.hip pot_big_eval) on the multi-pass path.  Single evaluations against the oracle's float32 force,
+    sampling iterations against the oracle in the reference's arithmetic (float64 state around the float32 force);
+    `state='float32'`: the same with the state rounded to float32 at the end of every iteration."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc.distributions import ProductOfT
+    W, lognu = ref_init_weights(D, D)
+    W = W + np.eye(D)
+    rs = np.random.RandomState(D + N)
+    X0 = rs.randn(D, N)
+    b = 0.1 * rs.randn(D)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)           # noqa: E731
+
+    class Fixed(ProductOfT):
+        def init_X(self):
+            self.Xinit = X0
+    d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W, b=b, state_dtype=state)
+    en = orc.ProductOfT(W, lognu=lognu, b=b, force_dtype=np.float32)
+    assert rel(d.E(X0)[0], en.E_val(X0)[0]) < 4e-6 and rel(d.dEdX(X0), en.dEdX_val(X0)) < 2e-5
+    en64 = orc.ProductOfT(W, lognu=lognu, b=b, force_dtype=np.float64)            # and the float64 formulas, at float32 accuracy
+    assert rel(d.E(X0)[0], en64.E_val(X0)[0]) < 2e-5 and rel(d.dEdX(X0), en64.dEdX_val(X0)) < 1e-4
+    kw = dict(epsilon=0.1, beta=0.3, num_leapfrog_steps=5)
+    s = M.MarkovJumpHMC(distribution=d, seed=17, resample=False, **kw)
+    okw = dict(state_rounding=f32) if state == 'float32' else {}
+    o = orc.MarkovJumpHMC(en, f32(X0) if state == 'float32' else X0, resample=False, rng=orc.PhiloxRNG(17, np.arange(N)), **dict(kw, **okw))
+    _resync(s, o)
+    ties = 0
+    for t in range(4):
+        ties += check_iteration(s, o, delta_rel=4e-6, x_tol=2e-6, e_rtol=4e-6, tag='pot %d %s it %d' % (D, state, t))
+        assert s.l_count + s.f_count + s.r_count == (t + 1) * N
+        _resync(s, o)
+    assert ties <= 1
+    X = s.state.X
+    assert (np.abs(X - f32(X)).max() == 0) == (state == 'float32')
+    Z = s.state.copy().L()                                     # HMCState.L() on a snapshot: the stand-alone leapfrog operator
+    Zo = o.state.clone().L()
+    assert rel(Z.X, Zo.X) < 2e-6 and rel(Z.EX, Zo.EX) < 4e-6
+    out = s.sample(3, preserve_order=True)
+    assert out.shape == (D, N, 3) and np.isfinite(out).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # SparseImageCode: single evaluations
 # ---------------------------------------------------------------------------------------------

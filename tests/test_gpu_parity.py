@@ -892,13 +892,65 @@ def test_edge_shapes_match_oracle(D, N):
 
 
 def test_unsupported_shapes_fail_loudly():
-    from mjhmc_amd import _lib
+    """What is left: input the REFERENCE rejects too (tf_distributions.py:219 asserts the dictionary shape), and dtypes
+    that name no arithmetic of an energy.  Every ndims / dtype combination of the other energies runs (below)."""
+    from mjhmc_amd import _lib, engine
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
     from mjhmc_amd.misc.distributions import TestGaussian, SparseImageCode
     B = np.random.RandomState(0).randn(64, 128)
     d = SparseImageCode(n_patches=1, n_batches=4, n_basis=128, basis=B, imgs=np.zeros((64, 1)))
-    with pytest.raises(_lib.EngineError):                      # only the 256 x 1024 dictionary shape is built
+    with pytest.raises(_lib.EngineError):                      # only the 256 x 1024 / 256 x 512 dictionary shapes exist
         MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.1)
+    ctx = engine.context(0)
+    en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, 8, [1.0])
+    with pytest.raises(_lib.EngineError):                      # bfloat16 state is SparseImageCode's arithmetic only
+        engine.DeviceSampler(en, np.zeros((8, 4)), seed=1, dtype='bfloat16')
+
+
+@pytest.mark.parametrize('kind,D,N', [('iso', 2500, 40), ('funnel', 2100, 33)])
+def test_float32_state_beyond_the_register_kernels(kind, D, N):
+    """float32 state for rows wider than the float32 register kernels hold (64 lanes x 32 elements): the multi-pass path on
+    float64 storage, the state rounded to float32 wherever it is written.  Against the oracle with the same rounding
+    (end points of every iteration), from identical inputs: transitions exact, state at float32 resolution, and every
+    stored value IS a float32."""
+    from mjhmc_amd import engine, _lib
+    rs = np.random.RandomState(D)
+    ctx = engine.context(0)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)           # noqa: E731
+    if kind == 'iso':
+        X0, en_o = rs.randn(D, N), orc.IsoGaussian(1.3)
+        en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.3])
+        eps, L = 0.1, 5
+    else:
+        x0 = 0.5 * rs.randn(N)
+        X0, en_o = np.vstack([x0, np.exp(x0 / 2) * rs.randn(D - 1, N)]), orc.FunnelNeal(3.0)
+        en = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, D, [3.0])
+        eps, L = 0.02, 4
+    s = engine.DeviceSampler(en, X0, seed=7, dtype='float32')
+    p_r = -np.log(1 - 0.3) * 0.5
+    s.set_hparams(eps, L, p_r, 1.0)
+    o = orc.MarkovJumpHMC(en_o, f32(X0), epsilon=eps, beta=0.3, num_leapfrog_steps=L, resample=False,
+                          rng=orc.PhiloxRNG(7, np.arange(N)), state_rounding=f32)
+    X, V = s.read(_lib.F_X), s.read(_lib.F_V)
+    assert np.array_equal(X, f32(X0)) and np.array_equal(V, f32(V)) and np.allclose(V, o.state.V, atol=1e-6)
+    for t in range(4):
+        o.state.X[:], o.state.V[:] = s.read(_lib.F_X), s.read(_lib.F_V)          # identical inputs every iteration
+        o.state.refresh_EX(); o.state.refresh_EV(); o.state.refresh_grad()
+        hf = s.read(_lib.F_HFLF)
+        o.state.shadow_ok[:] = ~np.isnan(hf)
+        o.state.shadow.EX[0, :] = np.nan_to_num(hf)
+        o.state.shadow.EV[0, :] = 0.0
+        st, done = s.iterate(1)
+        o.sampling_iteration()
+        assert done == 1 and np.array_equal(s.read(_lib.F_TRANS), o.last_transition), t
+        X, V = s.read(_lib.F_X), s.read(_lib.F_V)
+        assert np.array_equal(X, f32(X)) and np.array_equal(V, f32(V))           # float32 values
+        assert np.allclose(X, o.state.X, rtol=0, atol=2e-7 * max(1.0, np.abs(o.state.X).max()))
+        assert np.allclose(V, o.state.V, rtol=0, atol=2e-7 * max(1.0, np.abs(o.state.V).max()))
+        assert np.allclose(s.read(_lib.F_EX), o.state.EX[0], rtol=1e-6) and np.allclose(s.read(_lib.F_EV), o.state.EV[0], rtol=1e-6)
+    out, _ = en.eval(X0[:, :8], dtype='float32')
+    assert np.allclose(out, np.asarray(en_o.E_val(f32(X0[:, :8]))).reshape(-1), rtol=1e-10)
+    s.close()
 
 
 @pytest.mark.parametrize('cls_name,kind,D,N', [('MarkovJumpHMC', 'iso', 1100, 70), ('MarkovJumpHMC', 'diag', 5000, 33),
