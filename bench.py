@@ -791,6 +791,10 @@ def spawn_ranks(args, argv):
             extra = dict(extra, MJHMC_BENCH_NOTE='first attempt (RCCL) %s; this run: barrier / MAX / sample gather through '
                                                  'torch.distributed gloo' % why)
         rc, stopped, collected = _run_ranks(args, argv, extra, lim)     # (always fresh child processes: never re-exec a rank)
+        if rc != 0 and not stopped and extra.get('MJHMC_BENCH_BACKEND') == 'gloo':
+            # the gloo rendezvous port was picked by bind-then-close: another process may have taken it in between.  Once more, on a new one
+            sys.stderr.write('bench.py: the gloo attempt failed with status %d; once more on a fresh port\n' % rc)
+            rc, stopped, collected = _run_ranks(args, argv, extra, lim)
         if rc == 0:
             sys.stdout.buffer.write(b''.join(collected[0]))
             sys.stdout.buffer.flush()

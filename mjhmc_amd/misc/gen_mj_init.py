@@ -97,6 +97,10 @@ def stable_digest(distribution):
             if isinstance(part, (list, tuple)):
                 part = ';'.join(str(t) for t in part)
             h.update(part.encode() if isinstance(part, str) else np.ascontiguousarray(part, dtype=np.float64).tobytes())
+    elif isinstance(params, (tuple, list)) and any(callable(q) for q in params):
+        # opaque callables (LambdaDistribution on MJHMC_E_HOST): no bytes to hash -- the name the distribution was given
+        # stands for them, as in Distribution.__hash__ of the reference (distributions.py:247-251)
+        h.update(str(getattr(distribution, 'name', '')).encode())
     else:
         h.update(np.ascontiguousarray(params, dtype=np.float64).tobytes())
     return h.hexdigest()[:16]
@@ -108,7 +112,7 @@ def cache_initialization(distribution, directory, **kwargs):
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, '{}_{}.pickle'.format(type(distribution).__name__, stable_digest(distribution)))
     with open(path, 'wb') as cache_file:
-        pickle.dump(result, cache_file)
+        pickle.dump(result, cache_file, protocol=2)     # what _ArraysOnlyUnpickler (and the reference's Python 2) reads
     return path
 
 
@@ -119,6 +123,7 @@ class _ArraysOnlyUnpickler(pickle.Unpickler):
     _ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
                 ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
                 ('numpy', 'ndarray'), ('numpy', 'dtype'),
+                ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),   # protocol-5 array pickles
                 ('_codecs', 'encode')}      # how protocol-2 pickles written by Python 3 carry an array's bytes
 
     def find_class(self, module, name):

@@ -256,12 +256,19 @@ class HMCBase(object):
     def _stack(self, n_samples, preserve_order, out=None):
         if self._comm is not None and self._comm.on_device:
             # the one data-path collective: device rings all-gathered over RCCL, re-tiled on the receiving GPU
-            return self._comm.allgather_ring(self._dev, 0, n_samples, bool(preserve_order), self._plan.counts)
-        local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order), out=out if self._comm is None else None)
-        if self._comm is None:
-            return local
-        from ..parallel import assemble_stacked
-        return assemble_stacked(self._comm, self._plan, local, n_samples, bool(preserve_order))
+            res = self._comm.allgather_ring(self._dev, 0, n_samples, bool(preserve_order), self._plan.counts)
+        else:
+            local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order), out=out if self._comm is None else None)
+            if self._comm is None:
+                return local
+            from ..parallel import assemble_stacked
+            res = assemble_stacked(self._comm, self._plan, local, n_samples, bool(preserve_order))
+        if out is None:
+            return res
+        if out.shape != res.shape or out.dtype != np.float64:      # sharded run: the gathered block lands in the caller's array
+            raise ValueError('out must be a float64 array of shape %r' % (res.shape,))
+        out[...] = res
+        return out
 
     def sample(self, n_samples=1000, preserve_order=False, replay=None, out=None):
         """markov_jump_hmc.py:150-173.  ``out`` (extension): a preallocated C-contiguous float64 array of the result's

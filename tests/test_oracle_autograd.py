@@ -156,3 +156,26 @@ def test_initialisation_cache_loader_resolves_arrays_only(tmp_path):
     good.write_bytes(pickle.dumps((np.arange(6.0).reshape(2, 3), np.float64(1.5), 2.5, np.ones((2, 3))), protocol=2))
     mj, a, b, ctl = load_reference_initialization(str(good))
     assert mj.shape == (2, 3) and (a, b) == (1.5, 2.5) and ctl.shape == (2, 3)
+
+
+def test_initialisation_cache_round_trip_over_pickle_protocols_and_opaque_callables(tmp_path):
+    """The library reads back what it (or any pickle protocol's array encoding) writes, and the stable cache key exists
+    for a LambdaDistribution of opaque callables too (named by its `name`, as in the reference's __hash__)."""
+    import pickle
+    from mjhmc_amd.misc import gen_mj_init as G
+    payload = (np.arange(6.0).reshape(2, 3), np.float64(1.5), 2.5, np.ones((2, 3)))
+    for proto in range(2, pickle.HIGHEST_PROTOCOL + 1):
+        f = tmp_path / ('p%d.pickle' % proto)
+        f.write_bytes(pickle.dumps(payload, protocol=proto))
+        mj, a, b, ctl = G.load_reference_initialization(str(f))
+        assert np.array_equal(mj, payload[0]) and (a, b) == (1.5, 2.5) and np.array_equal(ctl, payload[3]), proto
+
+    class Opaque(object):                       # what stable_digest reads of a distribution
+        ndims, name = 7, 'my-energy'
+
+        def device_energy(self):
+            from mjhmc_amd import _lib
+            return _lib.E_HOST, (lambda X: X.sum(axis=0), lambda X: np.ones_like(X))
+    d1, d2 = Opaque(), Opaque()
+    d2.name = 'another'
+    assert len(G.stable_digest(d1)) == 16 and G.stable_digest(d1) == G.stable_digest(Opaque()) != G.stable_digest(d2)
