@@ -383,30 +383,35 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
   for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t p = tile * kP + c;
     const bool alive = p < a.N;
-    const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
-    const double H0 = EX0 + EV0;
-    // H of the inverse-L proposal: cached, or integrated by pot64_flf_kernel for the cold particles
-    double Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.0;
-    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
-    const double* xin = lane_row<NB>(a.X_in, p, w, h);
-    const double* vin = lane_row<NB>(a.V_in, p, w, h);
-    const double* gin = lane_row<NB>(a.G_in, p, w, h);
-    double* xo = lane_row<NB>(a.X_out, p, w, h);
-    double* vo = lane_row<NB>(a.V_out, p, w, h);
-    double* go = lane_row<NB>(a.G_out, p, w, h);
+    // (everything that is not needed during the trajectory -- the scalars of the decision, the output rows' addresses --
+    // is fetched / formed after it: the kernel sits at its 512-register budget, and what is live across the GEMM loops
+    // and the streamed passes decides whether those spill; tools/check_isa.sh gates both)
+    const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;   // this lane's elements inside a [*][DIM] matrix
     Tile<NB> g;
     VTile<NB> v;
-    tile_load_narrow<NB>(gin, g);
+    tile_load_narrow<NB>(a.G_in + roff, g);
     float exl = 0.f;
-    const double EVL = pot64_trajectory<NB, false, kXRows>(mdl, ar, sh, w, c, h, lane, wk, xin, vin, xo, g, v, a.L, a.eps, a.chalf, &exl);
+    const double EVL = pot64_trajectory<NB, false, kXRows>(mdl, ar, sh, w, c, h, lane, wk, a.X_in + roff, a.V_in + roff,
+                                                          a.X_out + roff, g, v, a.L, a.eps, a.chalf, &exl);
     const double EXL = (double)exl;
     const double HL = EXL + EVL;
+    const double* xin = a.X_in + roff;
+    const double* vin = a.V_in + roff;
+    const double* gin = a.G_in + roff;
+    double* xo = a.X_out + roff;
+    double* vo = a.V_out + roff;
+    double* go = a.G_out + roff;
 
     // rates / acceptance, waiting times, first minimum: lanes 0..31 of wave 0, one particle each, with the device
     // functions of the elementwise kernels in their one-lane-per-particle forms (as hk_decide of the multi-pass path)
     if (w == 0 && h == 0) {
       const int64_t pp = alive ? p : 0;
       const uint32_t pid = (uint32_t)(a.first_pid + pp);
+      const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const double H0 = EX0 + EV0;
+      // H of the inverse-L proposal: cached, or integrated by pot64_flf_kernel for the cold particles
+      double Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.0;
+      if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
       JumpArgs<double> ja;
       ja.p_r = a.p_r;
       ja.p_flip = a.p_flip;

@@ -51,11 +51,7 @@
 #include <cstdlib>
 
 #include "dense_sic.hpp"
-
-// timing experiments (tools/sic_variants.sh): parts of a round switched off -- results are then garbage.  0 = the product.
-#ifndef SICV
-#define SICV 0
-#endif
+#include "timing_variants.hpp"   // SIC_STAMP: cycle stamps of the timing build (tools/sic_variants.sh); nothing otherwise
 
 namespace mjhmc {
 
@@ -140,30 +136,11 @@ struct SicShared {
   float colsum[kP];           // per-column energies, summed over a particle's columns when n_patches > 1
   int move[kP];
   unsigned tally[4];
-#if SICV == 30
+#ifdef SIC_STAMPS
   unsigned stamp[4][8][8];    // timing build only
 #endif
 };
 static_assert(sizeof(SicShared) <= 160 * 1024, "LDS budget of a CU");
-
-// Timing build only (tools/sic_variants.sh 30t<k>): cycle stamps (s_memtime = core clock) of four of workgroup 0's waves at
-// position k of every round of a leapfrog step's pass; tools/sic_leap_time.py reads them, tools/sic_stamps_merge.py joins
-// the builds.  ONE position per build: a stamp costs ~150 cycles (s_memtime, its wait, the LDS write), seven per round
-// distort what they measure -- plus the entry into round 0, on which the builds are aligned.  Kept in LDS during the pass:
-// a global store would queue behind the dictionary requests it is supposed to time.
-#if SICV == 30
-#ifndef SICT
-#define SICT 1
-#endif
-__device__ unsigned g_sic_stamp[4][8][8];
-#define SIC_STAMP(RD, I)                                                                                     \
-  do {                                                                                                       \
-    if (((I) == SICT || ((I) == 0 && (RD) == 0)) && blockIdx.x == 0 && lane == 0 && (w & 2) == 0)            \
-      sh.stamp[(w & 1) | ((w >> 2) << 1)][RD][I] = (unsigned)__builtin_readcyclecounter();                   \
-  } while (0)
-#else
-#define SIC_STAMP(RD, I) do { } while (0)
-#endif
 
 // ---- the dictionary stream -----------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -208,7 +185,6 @@ struct AStream {
 // k-steps [K0, K1) of block T (compile time) of this wave into its image buffer
 template <int NB, int T, int K0 = 0, int K1 = 16>
 __device__ __forceinline__ void issue_block(const AStream& s) {
-  if (SICV == 4 || SICV == 9) return;
   const char* src = s.a2w + (T % NB) * 512;
 #pragma unroll
   for (int ks = K0; ks < K1; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
@@ -216,7 +192,6 @@ __device__ __forceinline__ void issue_block(const AStream& s) {
 // the same for the wave's SIMD partner (wave w ^ 4, the other group): DIR = +1 from group 0, -1 from group 1
 template <int NB, int T, int K0, int K1, int DIR>
 __device__ __forceinline__ void issue_partner(const AStream& s) {
-  if (SICV == 4 || SICV == 9) return;
   const char* src = s.a2w + (long)DIR * (long)(4 * 32 * NB * 16) + (T % NB) * 512;
   const unsigned img = s.img_own + (unsigned)(DIR * 4 * 16384);
 #pragma unroll
@@ -226,10 +201,7 @@ __device__ __forceinline__ void issue_partner(const AStream& s) {
 // The waves that request stand at the vector-memory port (64 B/clk per CU: ~58 cycles per request with four waves
 // asking) and then run the prior's force: ~1300 cycles to barrier A where this round's owners need ~1000 (G2, drift,
 // publish) and wait.  The owners take over the tail of the burst after their publish.
-#ifndef SIC_OWN_PIECES
-#define SIC_OWN_PIECES ((SICV >= 70 && SICV <= 86) ? (SICV - 70) : 12)   // (timing builds 70..86: 0..16)
-#endif
-constexpr int kOwnPieces = SIC_OWN_PIECES;
+constexpr int kOwnPieces = 12;   // (measured 0..16: DESIGN.md section 3.5)
 
 template <int NB>
 __device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& sh, int w, int lane) {
@@ -365,7 +337,7 @@ __device__ __forceinline__ void round_g2(SicShared& sh, const AStream& as, int l
   const unsigned rb0 = lds_addr(&sh.pubR[0][0]) + 16u * (unsigned)lane;
   // kAhead k-steps of operands in flight: during an owner's G2 its SIMD partner has no matrix work, so nothing but the
   // wave's own earlier reads covers the LDS round trip
-  constexpr int kAhead = (SICV == 11) ? 2 : ((SICV == 12) ? 5 : 3);
+  constexpr int kAhead = 3;   // (2 and 5 measured: within 2 %)
   f32x4 fa[kAhead], fb[kAhead];
 #pragma unroll
   for (int k = 0; k < kAhead; ++k) {
@@ -412,14 +384,14 @@ __device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int l
   ops_of(0, lo, hi, xf);
 #pragma unroll
   for (int n = 0; n < 2 * kG; ++n) {
-    if (SICV != 10) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     nlo = lo;
     nhi = hi;
     nxf = xf;
     if (n + 1 < 2 * kG) ops_of(n + 1, nlo, nhi, nxf);
     const auto a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     R.b[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, xf), R.b[0], 0, 0, 0);
-    if (SICV != 10) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     lo = nlo;
     hi = nhi;
     xf = nxf;
@@ -435,19 +407,17 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
   const bool own = (w >> 2) == (RD & 1);   // wave-uniform
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 0);
   if (own) {
-    if (SICV != 7) wait_vm<0>();                // this wave's block image has landed (issued a round ago)
+    wait_vm<0>();                // this wave's block image has landed (issued a round ago)
     if constexpr (KIND != kPassG1) {
-      if (SICV != 2 && SICV != 9) round_g2(sh, as, lane, acc.b[T]);
+      round_g2(sh, as, lane, acc.b[T]);
     }
     if constexpr (KIND == kPassFused) SIC_STAMP(RD, 1);
     if constexpr (KIND == kPassG2) {
       issue_block<NB, T + 1>(as);   // nobody else reads this image in a kick-only pass
     } else {
       if constexpr (KIND == kPassFused) x.b[T] = x.b[T] + eps * acc.b[T];   // drift (acc is V)
-      if (SICV != 6) {
-        sh.pubX[w & 3][0][lane] = frag_scaled(x.b[T], 0, 1.0f);
-        sh.pubX[w & 3][1][lane] = frag_scaled(x.b[T], 1, 1.0f);
-      }
+      sh.pubX[w & 3][0][lane] = frag_scaled(x.b[T], 0, 1.0f);
+      sh.pubX[w & 3][1][lane] = frag_scaled(x.b[T], 1, 1.0f);
       // the tail of the partner's request burst (it owned round RD - 1 and asked for block (RD - 1) / 2 + 1 after that
       // round's barrier B); landed before barrier B of this round, after which the partner's G2 reads the image
       if constexpr (KIND == kPassFused && RD >= 1 && kOwnPieces < 16)
@@ -455,25 +425,23 @@ __device__ __forceinline__ void pass_round(const SicModel& mdl, SicShared& sh, c
     }
   } else if constexpr (KIND != kPassG1 && RD + 1 < 2 * NB) {
     // beside the owners' matrix work: the prior's force of the block this wave owns in the NEXT round
-    if (SICV != 5 && SICV != 9) prior_kick<CAUCHY>(mdl, x.b[(RD + 1) >> 1], scale, acc.b[(RD + 1) >> 1]);
+    prior_kick<CAUCHY>(mdl, x.b[(RD + 1) >> 1], scale, acc.b[(RD + 1) >> 1]);
   } else if constexpr (KIND != kPassG2 && RD + 1 == 2 * NB) {
     // the pass's last round: group 0 has no next block in this pass -- the prior's force of its block 0 for the NEXT kick
     // (x's block 0 is final since round 0, and so is this pass's kick of it); at the head of that pass it would stand
     // alone, 400 cycles with the other group waiting at the barrier.  next_scale == 0: no kick follows
-    if (next_scale != 0.f) {
-      if (SICV != 5 && SICV != 9) prior_kick<CAUCHY>(mdl, x.b[0], next_scale, acc.b[0]);
-    }
+    if (next_scale != 0.f) prior_kick<CAUCHY>(mdl, x.b[0], next_scale, acc.b[0]);
   }
   if constexpr (KIND == kPassG2) return;
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 2);
-  if (SICV != 3) __syncthreads();               // barrier A: the round's four images have landed, their X blocks are published
+  __syncthreads();               // barrier A: the round's four images have landed, their X blocks are published
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 3);
-  if (SICV != 1 && SICV != 9) round_g1<RD>(sh, as, lane, R);
+  round_g1<RD>(sh, as, lane, R);
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 4);
   if constexpr (KIND == kPassFused && RD >= 1 && kOwnPieces < 16) {
     if (own) wait_vm<0>();                      // (the partner's pieces: requested at least a whole G1 ago)
   }
-  if (SICV != 3) __syncthreads();               // barrier B: the round's images and X fragments have been read by every wave
+  __syncthreads();               // barrier B: the round's images and X fragments have been read by every wave
   if constexpr (KIND == kPassFused) SIC_STAMP(RD, 5);
   if (own) {   // the owner's next block (of the next pass after the last one): lands during the other group's round
     if constexpr (KIND == kPassFused && RD + 1 < 2 * NB) issue_block<NB, T + 1, 0, kOwnPieces>(as);
@@ -512,7 +480,7 @@ __device__ __forceinline__ void sic_pass(const SicModel& mdl, SicShared& sh, con
   }
   if constexpr (KIND != kPassG2) resid_init(mdl, sh, w, h, c, patch, R);
   Rounds<KIND, CAUCHY, NB, 0>::run(mdl, sh, as, w, lane, x, acc, R, scale, eps, next_scale);
-#if SICV == 30
+#ifdef SIC_STAMPS
   if constexpr (KIND == kPassFused) {   // (the last pass run wins)
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < 256) (&g_sic_stamp[0][0][0])[threadIdx.x] = (&sh.stamp[0][0][0])[threadIdx.x];
@@ -894,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, c
   astream_close();
 }
 
-#if SICV == 30
+#ifdef SIC_STAMPS
 }  // namespace mjhmc
 extern "C" int mjhmc_sic_stamps(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mjhmc::g_sic_stamp), sizeof(mjhmc::g_sic_stamp));

@@ -16,3 +16,23 @@ static __device__ unsigned long long g_pot_stamp[4][8][8];
 #else
 #define POT_STAMP(I) do { } while (0)
 #endif
+
+// -DSIC_STAMPS=<k> (tools/sic_variants.sh <k>): cycle stamps (s_memtime = core clock) of four of workgroup 0's waves at
+// position k of every round of a SparseImageCode leapfrog step's pass; tools/sic_leap_time.py reads them,
+// tools/sic_stamps_merge.py joins the builds.  ONE position per build: a stamp costs ~150 cycles (s_memtime, its wait,
+// the LDS write), seven per round distort what they measure -- plus the entry into round 0, on which the builds are
+// aligned.  Kept in LDS (SicShared::stamp) during the pass: a global store would queue behind the dictionary requests it
+// is supposed to time.  (The builds that switched PARTS of a round off -- round 3's SICV 1..12, 70..86 -- are gone from
+// the source: what they measured is recorded in DESIGN.md section 3.5.)
+#ifdef SIC_STAMPS
+namespace mjhmc {
+static __device__ unsigned g_sic_stamp[4][8][8];
+}
+#define SIC_STAMP(RD, I)                                                                                          \
+  do {                                                                                                            \
+    if (((I) == (SIC_STAMPS) || ((I) == 0 && (RD) == 0)) && blockIdx.x == 0 && lane == 0 && (w & 2) == 0)         \
+      sh.stamp[(w & 1) | ((w >> 2) << 1)][RD][I] = (unsigned)__builtin_readcyclecounter();                        \
+  } while (0)
+#else
+#define SIC_STAMP(RD, I) do { } while (0)
+#endif

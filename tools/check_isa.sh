@@ -10,13 +10,21 @@
 #                               and is not counted)
 # in the kernels the benchmark runs (n_coeffs 1024: sic_jump_kernel<*,*,*,4>, sic_flf_kernel<*,4>),
 # and reports the register / spill figures of every SparseImageCode kernel.
+# and, for the ProductOfT tile kernels (dense_pot.hip: float32 state; dense_pot64.hip: the reference's arithmetic), that the
+# two GEMM loop bodies of every kernel (the basic blocks that hold the 128 MFMAs of two chunks) contain no scratch_
+# instruction -- a spill reload inside the loop is a counted load whose wait drains the A-row prefetch; the epilogues may
+# spill -- and, in dense_pot64.hip, that the per-step kick / drift pass (the block that streams the position through
+# registers: >= 16 buffer loads and >= 16 buffer stores of the working copy) contains none either; with the VGPR / spill
+# figures of every instance.
+# Compile flags: the Makefile's own (make print-flags).
 # usage: tools/check_isa.sh [out.s]        exit status 1 on a violation
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/mjhmc_dense_sic.s}
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 cd "$ROOT/mjhmc_amd/csrc" || exit 2
-[ -n "${SKIP_COMPILE:-}" ] || $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -disable-machine-licm -DMJHMC_JUMP_WAVES=1 \
+FLAGS=$(make -s print-flags)
+[ -n "${SKIP_COMPILE:-}" ] || $HIPCC $FLAGS \
   --cuda-device-only -S dense_sic.hip -o "$OUT" 2> /dev/null || { echo "compile failed"; exit 2; }
 python3 - "$OUT" <<'PY'
 import re, sys
@@ -63,3 +71,54 @@ for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel'
 print('check_isa: %s' % ('FAILED: %d kernel(s)' % bad if bad else 'ok'))
 sys.exit(1 if bad else 0)
 PY
+RC=$?
+for TU in dense_pot dense_pot64; do
+  [ -n "${SKIP_COMPILE:-}" ] || $HIPCC $FLAGS --cuda-device-only -S $TU.hip -o /tmp/mjhmc_$TU.s 2> /dev/null || { echo "compile of $TU failed"; exit 2; }
+  python3 - /tmp/mjhmc_$TU.s $TU <<'PY' || RC=1
+import re, sys
+txt = open(sys.argv[1]).read()
+bad = 0
+meta = {}
+for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)', txt, flags=re.S):
+    body = m.group(2)
+    g = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, body).group(1)) if re.search(r'\.%s:\s+(\d+)' % k, body) else None
+    meta[m.group(1)] = dict(vgpr=g('vgpr_count'), agpr=g('agpr_count'), sgpr_spill=g('sgpr_spill_count'), scratch=g('private_segment_fixed_size'),
+                            vgpr_spill=int(m.group(3)))
+for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel', txt, flags=re.S | re.M):
+    if 'pot' not in name:
+        continue
+    blocks, cur = [], []
+    for l in body.split('\n'):
+        if re.match(r'^\.LBB\w+:', l):
+            blocks.append(cur)
+            cur = []
+        else:
+            cur.append(l)
+            if re.match(r'\s*s_c?branch', l):      # a loop body ends at its back edge: what follows falls through
+                blocks.append(cur)
+                cur = []
+    blocks.append(cur)
+    gemm = [b for b in blocks if sum('v_mfma' in x for x in b) >= 64]
+    n_scr = sum(sum(re.match(r'\s*scratch_', x) is not None for x in b) for b in gemm)
+    n_acc = sum(sum('v_accvgpr' in x for x in b) for b in gemm)
+    # the float64-state kernel's per-step kick / drift passes: the blocks that stream the position through registers
+    # (>= 16 buffer loads of the working copy and as many stores)
+    # (the pass that stores the end point's position to the particle rows instead runs once per trajectory: not gated)
+    passes = [b for b in blocks if sum('buffer_load' in x for x in b) >= 16 and sum('buffer_store' in x for x in b) >= 16
+              and not any('v_mfma' in x for x in b)]
+    p_scr = sum(sum(re.match(r'\s*scratch_', x) is not None for x in b) for b in passes)
+    m = meta.get(name, {})
+    hot = 'Li4E' in name and ('jump_kernel' in name or 'flf_kernel' in name)
+    tag = ''
+    if hot and (n_scr or p_scr or len(gemm) < 2 or ('pot64' in name and not passes)):
+        bad += 1
+        tag = '   <-- VIOLATION'
+    if gemm:
+        print('%-84s vgpr %3s spilled %3s scratch %4s B sgpr spills %3s | GEMM loop bodies %d: scratch_ %d (v_accvgpr %d)%s%s'
+              % (name[9:93], m.get('vgpr'), m.get('vgpr_spill'), m.get('scratch'), m.get('sgpr_spill'), len(gemm), n_scr, n_acc,
+                 (' | streamed passes %d: scratch_ %d' % (len(passes), p_scr)) if 'pot64' in name else '', tag))
+print('check_isa %s: %s' % (sys.argv[2], 'FAILED: %d kernel(s)' % bad if bad else 'ok'))
+sys.exit(1 if bad else 0)
+PY
+done
+exit $RC
