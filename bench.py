@@ -496,6 +496,17 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
                         'achieved': dense_bytes * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s',
                         'what': 'state rows read and written per iteration (ProductOfT: X, V and the stored dE/dX; '
                                 'SparseImageCode: X, V) + per-particle scalars; nowhere near the HBM roofline'}}
+        if w['kind'] == 'pot' and w['dtype'] == 'float64':
+            # the float64-state kernel streams the position through a working copy once per leapfrog step:
+            # 8 B read + 8 B written per element and gradient evaluation, by design -- part of what this kernel has to move
+            wc = 16.0 * w['D'] * agg[3] / iters
+            roof['hbm']['working_copy_bytes_per_launch'] = wc
+            roof['hbm']['algorithmic_bytes_per_launch'] += wc
+            roof['hbm']['achieved'] = roof['hbm']['algorithmic_bytes_per_launch'] / (kern_it_ms * 1e-3) / 1e9
+            roof['hbm']['what'] = ('state rows (X, V, dE/dX in float64 + scalars) read and written per iteration + the position\'s '
+                                   'working copy, 16 B per element and gradient evaluation (it is streamed through the tile '
+                                   'kernel\'s epilogue: by design; L2 misses, served by the 256 MB MALL or HBM) -- 1.2 TB/s, nowhere '
+                                   'near a memory roofline')
         if w['kind'] == 'sic':
             # one pass over the 512 KB dictionary per leapfrog step of a 32-particle tile, plus two per trajectory (the
             # residual at its head, the closing half kick): L + 2 passes per L gradient evaluations, out of L2 (the
@@ -505,6 +516,17 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
             roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS,
                           'what': 'dictionary bytes streamed from L2 per launch (512 KiB per tile and dictionary pass, '
                                   'L + 2 passes per trajectory) / time'}
+            # The bound this kernel actually runs into: BOTH operands of every MFMA come out of LDS,
+            # 2 KiB per v_mfma_f32_32x32x16_bf16 -- 2 MiB of LDS reads per tile and leapfrog step (1024 MFMAs) -- plus the
+            # dictionary landing in LDS (512 KiB per step) and the published fragments (80 KiB).  At the LDS array's 256 B/clk
+            # per CU the reads alone take the 8 192 cycles the MFMAs take: the matrix peak is out of reach by construction,
+            # whatever the order of a round's phases.
+            lds_bytes = tile_grads * (2.0 + 0.578) * 1024 * 1024
+            lds_peak = 256.0 * 256 * 2.4                                  # B/clk/CU x CUs x GHz = GB/s
+            roof['lds'] = {'achieved': lds_bytes / (kern_it_ms * 1e-3) / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
+                           'frac': lds_bytes / (kern_it_ms * 1e-3) / 1e9 / lds_peak,
+                           'what': 'LDS bytes moved per launch (per tile and gradient: 2 MiB of MFMA operand reads, 512 KiB of '
+                                   'LDS-DMA landing, 80 KiB of published fragments) / time, against 256 B/clk/CU at 2.4 GHz'}
     else:
         abytes = algorithmic_bytes_per_particle(w['D'], esize) * n_rank          # per sampling iteration
         hbm = {'achieved': abytes / (kern_it_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -565,6 +587,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
     if device.get('sclk_mhz'):
         # the fraction again, against the peak at the clock the chip actually held (the guide's peaks assume 2.4 GHz)
         roof['frac_at_held_clock'] = roof['frac'] * 2400.0 / max(device['sclk_mhz'][1], 1.0)
+        if 'lds' in roof:
+            roof['lds']['frac_at_held_clock'] = roof['lds']['frac'] * 2400.0 / max(device['sclk_mhz'][1], 1.0)
     if boundary is not None:
         out['boundary'] = boundary
     if world == 1 and cpu_seconds > 0:
