@@ -519,8 +519,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
             # The bound this kernel actually runs into: BOTH operands of every MFMA come out of LDS,
             # 2 KiB per v_mfma_f32_32x32x16_bf16 -- 2 MiB of LDS reads per tile and leapfrog step (1024 MFMAs) -- plus the
             # dictionary landing in LDS (512 KiB per step) and the published fragments (80 KiB).  At the LDS array's 256 B/clk
-            # per CU the reads alone take the 8 192 cycles the MFMAs take: the matrix peak is out of reach by construction,
-            # whatever the order of a round's phases.
+            # per CU the reads alone take the 8 192 cycles the MFMAs take: the matrix peak would need the LDS array at 100 %.
+            # (Measured: array 44 % busy, matrix pipe 40 %, profiles/r04/c5_lds_counters.txt -- the phases of a round alternate.)
             lds_bytes = tile_grads * (2.0 + 0.578) * 1024 * 1024
             lds_peak = 256.0 * 256 * 2.4                                  # B/clk/CU x CUs x GHz = GB/s
             roof['lds'] = {'achieved': lds_bytes / (kern_it_ms * 1e-3) / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
