@@ -530,14 +530,14 @@ def test_sic_512_atoms_control_arm_and_leapfrog():
 # ---------------------------------------------------------------------------------------------
 # big dense batches are launched as two halves on two streams (api.hip: half_args): invisible in the results
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('what', ['pot36', 'sic_p1', 'sic_p9', 'pot36_control', 'sic_p1_ct'])
+@pytest.mark.parametrize('what', ['pot36', 'pot36f64', 'sic_p1', 'sic_p9', 'pot36_control', 'pot36f64_control', 'sic_p1_ct'])
 def test_split_launches_equal_single_launches(what, monkeypatch):
     from mjhmc_amd import engine, _lib
     ctxs = (engine.context(0), hooks_context(0))       # [0] the product library, [1] the test build with MJHMC_NO_SPLIT
     mode = {'pot36_control': _lib.MODE_CONTROL, 'sic_p1_ct': _lib.MODE_CTHMC}.get(what, _lib.MODE_MJHMC)   # the other sampler families
     what = what.split('_c')[0]
-    if what == 'pot36':
-        D, N, dtype = 36, 20000, 'float32'
+    if what in ('pot36', 'pot36f64'):
+        D, N, dtype = 36, 20000, 'float64' if what == 'pot36f64' else 'float32'
         W, lognu = ref_init_weights(D, D)
         params = np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)])
         ens = [engine.DeviceEnergy(c, _lib.E_PRODUCT_OF_T, D, params) for c in ctxs]
@@ -573,7 +573,8 @@ def test_split_launches_equal_single_launches(what, monkeypatch):
         s.close()
 
 
-@pytest.mark.parametrize('what,poison', [('sic_p1', '4:300'), ('sic_p1', '6:16000'), ('pot36', '3:19000'), ('pot36', '0:5')])
+@pytest.mark.parametrize('what,poison', [('sic_p1', '4:300'), ('sic_p1', '6:16000'), ('pot36', '3:19000'), ('pot36', '0:5'),
+                                         ('pot36f64', '5:19000'), ('pot36f64', '2:7')])
 def test_split_launches_failure_in_the_middle_of_a_call(what, poison, monkeypatch):
     """A non-finite rate while the two halves of a big dense batch run freely: the call must end exactly like a call
     that was never split -- same `done`, same state, same tallies of the good iterations -- (api.hip: the state copy
@@ -581,8 +582,8 @@ def test_split_launches_failure_in_the_middle_of_a_call(what, poison, monkeypatc
     library's test hook MJHMC_DEBUG_POISON=iteration:particle (that particle's kinetic energy reads NaN there)."""
     from mjhmc_amd import engine, _lib
     ctx = hooks_context(0)                 # both samplers from the test build: only it can place a failure
-    if what == 'pot36':
-        D, N, dtype = 36, 20000, 'float32'
+    if what in ('pot36', 'pot36f64'):
+        D, N, dtype = 36, 20000, 'float64' if what == 'pot36f64' else 'float32'
         W, lognu = ref_init_weights(D, D)
         en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)]))
         X0 = np.random.RandomState(3).randn(D, N)

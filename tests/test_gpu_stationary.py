@@ -57,8 +57,11 @@ def _run(cls_name, dist, n_iter, **kw):
     return s
 
 
-@pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC'])
-def test_product_of_t_stationary_law(cls_name):
+@pytest.mark.parametrize('cls_name,state', [('MarkovJumpHMC', 'float32'), ('ControlHMC', 'float32'),
+                                            ('MarkovJumpHMC', 'float64'), ('ControlHMC', 'float64')])
+def test_product_of_t_stationary_law(cls_name, state):
+    """`state`: float32 state and force (dense_pot.hip) / the reference's arithmetic, float64 state around the float32 force
+    (dense_pot64.hip: the tile kernel with the state streamed through its epilogue)."""
     from mjhmc_amd.misc.distributions import ProductOfT
     D, N = 36, 8192
     W, lognu, nu = _pot_model(D)
@@ -70,7 +73,7 @@ def test_product_of_t_stationary_law(cls_name):
         class Fixed(ProductOfT):
             def gen_init_X(self):
                 self.Xinit = X0
-        return Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W)
+        return Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W, state_dtype=state)
 
     kw = dict(epsilon=0.25, beta=0.3, num_leapfrog_steps=6, seed=11)
     # (1) started from the law: still the law after 80 iterations, and the chain has moved
@@ -159,6 +162,12 @@ def test_leapfrog_conserves_energy_second_order_and_a_wrong_gradient_does_not():
     e1 = np.median(_energy_error(en, X, V, 0.1, 8, 'float32'))
     e2 = np.median(_energy_error(en, X, V, 0.05, 16, 'float32'))
     assert e1 < 0.05 and 3.0 < e1 / e2 < 5.0, (e1, e2)
+    # ... and in the reference's arithmetic (float64 state around the float32 force), down to where the float32 force's
+    # own error (~1e-6 of |g|) starts to show
+    e1 = np.median(_energy_error(en, X, V, 0.1, 8, 'float64'))
+    e2 = np.median(_energy_error(en, X, V, 0.05, 16, 'float64'))
+    e3 = np.median(_energy_error(en, X, V, 0.025, 32, 'float64'))
+    assert e1 < 0.05 and 3.5 < e1 / e2 < 4.5 and 3.5 < e2 / e3 < 4.5, (e1, e2, e3)
     # Funnel: built-in functor and the coupled-expression form, right and (negative control) wrong
     D, N, scale = 10, 4096, 1.5
     X, V = _funnel_exact_draw(D, N, scale, rs), rs.randn(D, N)
