@@ -37,7 +37,9 @@ typedef enum {
   MJHMC_OK = 0,
   MJHMC_ERR_INVALID = -1,      /* bad argument                                                   */
   MJHMC_ERR_HIP = -2,          /* a HIP runtime call failed                                      */
-  MJHMC_ERR_UNSUPPORTED = -3,  /* e.g. ndims too large for the fused register kernel             */
+  MJHMC_ERR_UNSUPPORTED = -3,  /* a dtype that names no arithmetic of the energy (bf16 outside   */
+                               /* SPARSE_CODE), a SPARSE_CODE dictionary shape the reference     */
+                               /* rejects too; every ndims of the other energies runs            */
   MJHMC_ERR_NO_DEVICE = -4,
   MJHMC_ERR_NONFINITE = -5,    /* informational: see mjhmc_iterate                               */
   MJHMC_ERR_COMM = -6          /* librccl could not be loaded, or an RCCL call failed            */
@@ -52,6 +54,9 @@ typedef enum {
  *   FUNNEL_REF  {scale}                         Funnel as coded,      mjhmc/misc/tf_distributions.py:157-165
  *   PRODUCT_OF_T {nbasis, W[D*nbasis] row-major (D,nbasis), nu[nbasis], b[nbasis]}
  *                                               ProductOfT    mjhmc/misc/distributions.py:373-433
+ *                                               (nbasis == ndims, any size: the tile kernels up to 512, 512 x 512
+ *                                               blocks on the multi-pass path beyond; dtype F64 = the reference's
+ *                                               arithmetic, float64 state around the float32 force; F32 = float32 state)
  *   SPARSE_CODE {n_patches, img, n_coeffs, lambda, cauchy, B[img*n_coeffs], Y[n_patches*img]}
  *                                               SparseImageCode mjhmc/misc/tf_distributions.py:204-272
  *                                               (img = 256; n_coeffs = 1024 or 512, :219; 1 <= n_patches <= 32)
@@ -218,8 +223,10 @@ int mjhmc_traj_finish(mjhmc_sampler* s, const double* E, const double* replay_no
  * checkpoint: device copy of X, V, EX, EV, H_flf, dwell + the RNG tick.  restore: put it back. */
 int mjhmc_checkpoint(mjhmc_sampler* s);
 int mjhmc_restore(mjhmc_sampler* s);
-/* Undo the last call when it was mjhmc_iterate(1) and committed: the iteration's inputs are the untouched other
- * halves of the ping-pong buffers, so no copy is taken or restored (the RNG tick stays consumed). */
+/* Undo the last call when it was mjhmc_iterate(1) (or one mjhmc_traj_finish) and committed: the iteration's inputs are
+ * the untouched other halves of the ping-pong buffers -- or, for the samplers that commit in place (rows wider than the
+ * register kernels, host-evaluated energies), the pre-move state the commit left in its workspace -- so no copy is taken
+ * beforehand (the RNG tick stays consumed). */
 int mjhmc_rollback(mjhmc_sampler* s);
 /* The position of the counter RNG (one tick per sampling_iteration attempt): together with X, V and H_flf
  * (mjhmc_read / mjhmc_write) it is the whole resumable state of a sampler -- mjhmc_amd's save_state / load_state write it
