@@ -85,7 +85,10 @@ def oracle_proposal_energies(o):
     HL = o.state.clone().L().H()[0].copy()
     Hflf = o.state.clone().FLF().H()[0].copy()
     en.E_count, en.dEdX_count = counts
-    exps = np.asarray(o.rng.stream.unit_exponentials(o.rng.tick), dtype=np.float64)
+    if hasattr(o.rng, 'stream'):          # counter RNG: the draws of the coming tick
+        exps = np.asarray(o.rng.stream.unit_exponentials(o.rng.tick), dtype=np.float64)
+    else:                                 # recorded numbers (orc.ReplayRNG): the coming attempt's block
+        exps = np.asarray(o.rng._exps[o.rng.attempt], dtype=np.float64)
     return H0, HL, Hflf, exps
 
 

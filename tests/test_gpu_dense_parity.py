@@ -629,3 +629,100 @@ def test_split_launches_failure_in_the_middle_of_a_call(what, poison, monkeypatc
         assert np.array_equal(pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f)), equal_nan=True), f
     for s in pair:
         s.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the REPLAY instances of the tile kernels (recorded random numbers fed from the host, the mode the golden replays of
+# the elementwise energies run in): every draw is the caller's, so device and oracle can be compared decision by decision
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('what,cls_name', [('pot32', 'MarkovJumpHMC'), ('pot64', 'MarkovJumpHMC'), ('sic', 'MarkovJumpHMC'),
+                                           ('pot32', 'ControlHMC'), ('pot64', 'ControlHMC'), ('sic', 'ControlHMC'),
+                                           ('pot64', 'ContinuousTimeHMC'), ('pot32', 'ContinuousTimeHMC'),
+                                           ('sic', 'ContinuousTimeHMC')])
+def test_dense_kernels_in_replay_mode(what, cls_name):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    rs = np.random.RandomState(123)
+    T = 4
+    if what == 'sic':
+        N, D = 40, 1024
+        B, imgs, a0 = sic_problem(0)
+        X0 = to_bf16(a0[:, None] + 0.2 * rs.randn(D, N))
+        d, B, imgs = _sic(1, N, True, X0)
+        en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
+        rounding, tol = to_bf16, dict(delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4)
+        kw = dict(epsilon=0.0625, beta=0.3, num_leapfrog_steps=5)
+        V0 = to_bf16(rs.randn(D, N))
+        normals = [to_bf16(rs.randn(D, N)) for _ in range(T)]          # (what the device stores of them)
+    else:
+        N, D = 70, 36
+        X0 = rs.randn(D, N)
+        state = 'float64' if what == 'pot64' else 'float32'
+        W, lognu = ref_init_weights(D, D)
+        W = W + np.eye(D)
+        from mjhmc_amd.misc.distributions import ProductOfT
+
+        class Fixed(ProductOfT):
+            def init_X(self):
+                self.Xinit = X0
+        d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W, state_dtype=state)
+        f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)       # noqa: E731
+        if what == 'pot64':
+            en, rounding, tol = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float32), None, dict(delta_rel=4e-6, x_tol=1e-6, e_rtol=4e-6)
+        else:
+            en, rounding, tol = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64), f32, dict(delta_rel=2e-5, x_tol=2e-5, e_rtol=2e-5)
+        kw = dict(epsilon=0.1, beta=0.3, num_leapfrog_steps=5)
+        V0 = rs.randn(D, N) if rounding is None else rounding(rs.randn(D, N))
+        normals = [rs.randn(D, N) if rounding is None else rounding(rs.randn(D, N)) for _ in range(T)]
+    okw = {} if rounding is None else dict(state_rounding=rounding)
+    if cls_name == 'ControlHMC':
+        u_acc, u_flip, u_r = [rs.rand(N) for _ in range(T)], [rs.rand(N) for _ in range(T)], [rs.rand() for _ in range(T)]
+        s = M.ControlHMC(distribution=d, Vinit=V0, seed=1, **kw)
+        fired = [u < s.p_r for u in u_r]
+        o = orc.ControlHMC(en, X0, V0=V0, rng=orc.ReplayRNG(normals=[normals[t] for t in range(T) if fired[t]],
+                                                            uniforms=[v for t in range(T) for v in (u_acc[t], u_flip[t], u_r[t])]),
+                           **dict(kw, **okw))
+        _resync(s, o)
+        for t in range(T):
+            # the device side of check_control_iteration, with the recorded numbers
+            H0, HL = o.state.H()[0].copy(), None
+            s.sampling_iteration(replay=[(normals[t] if fired[t] else np.zeros((D, N)), np.concatenate([u_acc[t], u_flip[t], [u_r[t]]]))])
+            o.sampling_iteration()
+            tr = s._dev.read(8)
+            acc_o, flip_o = np.isin(np.arange(N), o.last_fl_idx), np.isin(np.arange(N), o.last_flip_idx)
+            assert np.array_equal(((tr >> 1) & 1).astype(bool), flip_o), t
+            same = (tr & 1).astype(bool) == acc_o
+            assert (~same).sum() <= 1, t                          # (an accept decision within the kernel's energy error of a tie)
+            xs = max(1.0, float(np.abs(o.state.X).max()))
+            assert np.abs(s.state.X[:, same] - o.state.X[:, same]).max() <= tol['x_tol'] * xs, t
+            assert np.abs(s.state.V[:, same] - o.state.V[:, same]).max() <= tol['x_tol'] * max(1.0, float(np.abs(o.state.V).max())), t
+            _resync(s, o)
+        assert sum(fired) == 0 or s.r_count > 0
+        return
+    exps = [rs.standard_exponential((3, N)) for _ in range(T)]
+    if cls_name == 'MarkovJumpHMC':
+        s = M.MarkovJumpHMC(distribution=d, Vinit=V0, seed=1, resample=False, **kw)
+        o = orc.MarkovJumpHMC(en, X0, V0=V0, resample=False, rng=orc.ReplayRNG(normals=normals, exps=exps), **dict(kw, **okw))
+        _resync(s, o)
+        ties = 0
+        for t in range(T):
+            # check_iteration drives both sides itself: hand the recorded numbers to the device through a one-shot patch
+            step = s.sampling_iteration
+            s.sampling_iteration = lambda step=step, t=t: step(replay=[(normals[min(o.rng.n_normals_used, T - 1)], exps[t])])
+            try:
+                ties += check_iteration(s, o, tag='%s replay it %d' % (what, t), **tol)
+            finally:
+                del s.sampling_iteration
+            _resync(s, o)
+        assert ties <= 1
+    else:
+        s = M.ContinuousTimeHMC(distribution=d, Vinit=V0, seed=1, resample=False, **kw)
+        o = orc.ContinuousTimeHMC(en, X0, V0=V0, resample=False, rng=orc.ReplayRNG(normals=normals, exps=exps), **dict(kw, **okw))
+        _resync(s, o)
+        for t in range(T):
+            s.sampling_iteration(replay=[(normals[min(o.rng.n_normals_used, T - 1)], exps[t])])
+            o.sampling_iteration()
+            same = s._dev.read(8) == np.array([1, 0, 2], dtype=np.uint8)[o.last_transition] if hasattr(o, 'last_transition') else None
+            assert (s.fl_count, s.f_count, s.r_count) == (o.fl_count, o.f_count, o.r_count), t
+            assert np.abs(s.state.X - o.state.X).max() <= tol['x_tol'] * max(1.0, np.abs(o.state.X).max()), t
+            assert np.abs(s.state.V - o.state.V).max() <= tol['x_tol'] * max(1.0, np.abs(o.state.V).max()), t
+            _resync(s, o)
