@@ -355,11 +355,12 @@ class ProductOfT(Distribution):
     cores (exact-f32 MFMA).  ndims == nbasis, as the reference's initialiser requires (:391-392); any size (up to 512 dims
     on the register-resident tile kernels, beyond that block by block on the engine's multi-pass path).
 
-    ``state_dtype`` (extension): 'float32' (default) keeps the particle state in float32 too -- the fused tile kernel,
-    BASELINE configs[2]; 'float64' is the reference's own arithmetic, float64 ``HMCState`` arrays around the float32
-    force (:408-415 with hmc_state.py:29-38): the tile kernel with the state streamed through its epilogue."""
+    ``state_dtype``: 'float64' (default) is the reference's own arithmetic -- float64 ``HMCState`` arrays around the
+    float32 force (:408-415 with hmc_state.py:29-38) -- on the tile kernel with the state streamed through its epilogue
+    (csrc/dense_pot64.hip); 'float32' (extension, BASELINE configs[2]'s wording) keeps the particle state in float32
+    too: the fused float32 tile kernel, ~7 % faster."""
 
-    def __init__(self, ndims=36, nbasis=36, nbatch=100, lognu=None, W=None, b=None, state_dtype='float32'):
+    def __init__(self, ndims=36, nbasis=36, nbatch=100, lognu=None, W=None, b=None, state_dtype='float64'):
         if ndims != nbasis:
             raise NotImplementedError("Initializer only works for ndims == nbasis")
         if state_dtype not in ('float32', 'float64'):

@@ -125,7 +125,7 @@ def test_float32_state_ring():
     class Fixed(ProductOfT):
         def init_X(self):
             self.Xinit = X0
-    d = Fixed(ndims=36, nbasis=36, nbatch=45, W=W, lognu=np.log(rs.rand(36) * 2 + 2.1), b=np.zeros(36))
+    d = Fixed(ndims=36, nbasis=36, nbatch=45, W=W, lognu=np.log(rs.rand(36) * 2 + 2.1), b=np.zeros(36), state_dtype='float32')
     smp = MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.2, num_leapfrog_steps=4, seed=5, resample=False)
     T = 32
     smp._record(T)

@@ -78,7 +78,7 @@ def _pot(D, n, b=None, X0=None):
         def init_X(self):
             self.Xinit = X0 if X0 is not None else np.zeros((D, n))
 
-    return Fixed(ndims=D, nbasis=D, nbatch=n, lognu=lognu, W=W, b=b), W, lognu
+    return Fixed(ndims=D, nbasis=D, nbatch=n, lognu=lognu, W=W, b=b, state_dtype='float32'), W, lognu
 
 
 @pytest.mark.parametrize('tag,D,n,src', [('pot_36x25', 36, 25, 'g2_dense'), ('pot_512x64', 512, 64, 'g2_dense'),

@@ -69,7 +69,7 @@ def test_full_size_c3_product_of_t():
     class Fixed(ProductOfT):
         def init_X(self):
             self.Xinit = X0
-    d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W)
+    d = Fixed(ndims=D, nbasis=D, nbatch=N, lognu=lognu, W=W, state_dtype='float32')
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=21, resample=False)
     cols = np.sort(np.random.RandomState(5).choice(N, size=48, replace=False))
     o = orc.MarkovJumpHMC(orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64), X0[:, cols], epsilon=eps, beta=beta,

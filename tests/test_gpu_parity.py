@@ -702,7 +702,7 @@ def test_pot_energy_and_gradient(ndims, n):
     from mjhmc_amd.misc.distributions import ProductOfT
     W, lognu = pot_weights(ndims)
     b = 0.1 * np.random.RandomState(1).randn(ndims)
-    d = ProductOfT(ndims=ndims, nbasis=ndims, nbatch=n, lognu=lognu, W=W, b=b)
+    d = ProductOfT(ndims=ndims, nbasis=ndims, nbatch=n, lognu=lognu, W=W, b=b, state_dtype='float32')
     o = orc.ProductOfT(W, lognu=lognu, b=b, force_dtype=np.float64)
     X = np.random.RandomState(2).randn(ndims, n) * 1.5
     E, G = d.E(X), d.dEdX(X)
@@ -726,7 +726,7 @@ def test_pot_iterations_vs_oracle(ndims, N, eps, L, beta):
         def init_X(self):
             self.Xinit = X0
 
-    d = Fixed(ndims=ndims, nbasis=ndims, nbatch=N, lognu=lognu, W=W)
+    d = Fixed(ndims=ndims, nbasis=ndims, nbatch=N, lognu=lognu, W=W, state_dtype='float32')
     en = orc.ProductOfT(W, lognu=lognu, force_dtype=np.float64)
     seed = 99
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=seed, resample=False)

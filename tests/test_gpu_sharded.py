@@ -80,7 +80,7 @@ def run_pot(comm):
     class FixedT(ProductOfT):
         def init_X(self):
             self.Xinit = Xp
-    d = FixedT(ndims=Dp, nbasis=Dp, nbatch=Np, lognu=lognu, W=Wp)
+    d = FixedT(ndims=Dp, nbasis=Dp, nbatch=Np, lognu=lognu, W=Wp, state_dtype='float32')
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         s = MarkovJumpHMC(distribution=d, epsilon=0.1, beta=0.3, num_leapfrog_steps=6, seed=99, comm=comm,

@@ -134,7 +134,7 @@ def test_dense_energies_integrate_snapshots_too():
     class Fixed(ProductOfT):
         def init_X(self):
             self.Xinit = X0
-    d = Fixed(ndims=36, nbasis=36, nbatch=40)
+    d = Fixed(ndims=36, nbasis=36, nbatch=40, state_dtype='float32')
     s = MarkovJumpHMC(distribution=d, epsilon=0.1, seed=1, resample=False, num_leapfrog_steps=4)
     before = (d.E_count, d.dEdX_count)
     Z = s.state.copy().L()
