@@ -213,12 +213,34 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
       refresh = (k == 2);
     }
     const bool tile_refreshes = __ballot(refresh) != 0ull;
-    if (refresh) {  // HMCState.R (hmc_state.py:121-129)
-      Tile<NB> z;
-      if constexpr (REPLAY) tile_load<NB>(a.noise, alive ? p : 0, w, h, z);
-      else pot_normals<NB>(a.key, (uint32_t)(a.first_pid + (alive ? p : 0)), w, h, a.D, z);
+    if constexpr (REPLAY) {
+      if (refresh) {  // HMCState.R (hmc_state.py:121-129) with the recorded normals
+        Tile<NB> z;
+        tile_load<NB>(a.noise, alive ? p : 0, w, h, z);
 #pragma unroll
-      for (int r = 0; r < NB; ++r) v.b[r] = v.b[r] * a.r_keep + z.b[r] * a.r_mix;
+        for (int r = 0; r < NB; ++r) v.b[r] = v.b[r] * a.r_keep + z.b[r] * a.r_mix;
+      }
+    } else {
+      // column by column (the set is the same in every wave: it comes from sh.move), the whole workgroup drawing
+      unsigned cols = (unsigned)(__ballot(refresh) & 0xFFFFFFFFull);
+      while (cols) {
+        const int c0 = __ffs((int)cols) - 1;
+        cols &= cols - 1;
+        const int64_t p0 = tile * kP + c0;
+        column_normals<NB, float>(a.key, (uint32_t)(a.first_pid + (p0 < a.N ? p0 : 0)), a.D, sh.zn);
+        __syncthreads();
+        if (c == c0) {
+          using V = typename VecN<NB>::type;
+          const float* zrow = sh.zn + 32 * NB * w;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const V z = *reinterpret_cast<const V*>(zrow + NB * acc_row(q, h));
+#pragma unroll
+            for (int r = 0; r < NB; ++r) v.b[r][q] = v.b[r][q] * a.r_keep + vget<NB>(z, r) * a.r_mix;
+          }
+        }
+        __syncthreads();
+      }
     }
     if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result
       const float evr = pot_kinetic<NB>(sh, w, c, h, v);

@@ -95,6 +95,7 @@ template <int NB>
 struct Shared64 {
   Shared<NB> s;
   double red64[4][kP];
+  double zn[128 * NB];   // the float64 standard normals of one refreshing column (column_normals)
 };
 
 // The wave's working copy of its X and V elements between the passes of a trajectory, in the workgroup's scratch
@@ -308,24 +309,6 @@ __device__ __forceinline__ double pot64_trajectory(const PotModel& mdl, AReg<NB>
   return column_sum<NB>(sh, w, c, h, part) / 2.0;
 }
 
-// float64 standard normals of this lane's elements of register index q (Box-Muller pairs (2k, 2k+1) of the counter
-// RNG, zero beyond D) -- the values mjhmc_eval_kernel / hk_commit draw for the same (particle, dim)
-template <int NB>
-__device__ __forceinline__ typename DVecN<NB>::type normals_q(const RngKey& key, uint32_t pid, int w, int h, int q, int D) {
-  const int d = 32 * NB * w + NB * acc_row(q, h);
-  double zz[4] = {0, 0, 0, 0};
-  normal_pair(key, pid, (uint32_t)(d >> 1), zz[0], zz[1]);
-  if constexpr (NB == 4) normal_pair(key, pid, (uint32_t)((d >> 1) + 1), zz[2], zz[3]);
-  typename DVecN<NB>::type z;
-  if constexpr (NB == 1) {
-    z = d < D ? ((d & 1) ? zz[1] : zz[0]) : 0.0;
-  } else {
-#pragma unroll
-    for (int r = 0; r < NB; ++r) z[r] = d + r < D ? zz[r] : 0.0;
-  }
-  return z;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // inverse-L pass of the cold-cache particles, compacted into dense tiles (dense_pot.hip: pot_cold_list_kernel's twin)
 // ---------------------------------------------------------------------------------------------------
@@ -512,27 +495,54 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
       dv_store<NB>(go, q, gg);
     }
     double s2 = 0.0;
-    if (!take || refresh) {
+    if (!take || (REPLAY && refresh)) {
       const double* vsrc = take ? (const double*)vo : vin;   // (a kept end point's momentum is flipped already)
       const bool fl2 = flip && !take;
       const double* nrow = REPLAY ? lane_row<NB>(a.noise, alive ? p : 0, w, h) : nullptr;
-      const uint32_t npid = (uint32_t)(a.first_pid + (alive ? p : 0));
 #pragma unroll 1
       for (int q = 0; q < 16; ++q) {
         DV vv = dv_load<NB>(vsrc, q);
         if (fl2) vv = -vv;
-        if (refresh) {  // HMCState.R (hmc_state.py:121-129)
-          DV z;
-          if constexpr (REPLAY) z = dv_load<NB>(nrow, q);
-          else z = normals_q<NB>(a.key, npid, w, h, q, a.D);
+        if constexpr (REPLAY) {
+          if (refresh) {  // HMCState.R (hmc_state.py:121-129) with the recorded normals
+            const DV z = dv_load<NB>(nrow, q);
 #pragma unroll
-          for (int r = 0; r < NB; ++r) {
-            const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
-            dset<NB>(vv, r, t);
-            s2 = s2 + t * t;
+            for (int r = 0; r < NB; ++r) {
+              const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
+              dset<NB>(vv, r, t);
+              s2 = s2 + t * t;
+            }
           }
         }
         dv_store<NB>(vo, q, vv);
+      }
+    }
+    if constexpr (!REPLAY) {
+      // HMCState.R, column by column (the set is the same in every wave: it comes from sh.move), the whole workgroup
+      // drawing the column's normals (column_normals); the column's momentum is in the output rows by now
+      unsigned cols = (unsigned)(__ballot(refresh) & 0xFFFFFFFFull);
+      while (cols) {
+        const int c0 = __ffs((int)cols) - 1;
+        cols &= cols - 1;
+        const int64_t p0 = tile * kP + c0;
+        column_normals<NB, double>(a.key, (uint32_t)(a.first_pid + (p0 < a.N ? p0 : 0)), a.D, sh.zn);
+        __syncthreads();
+        if (c == c0) {
+          const double* zrow = sh.zn + 32 * NB * w + 4 * NB * h;
+#pragma unroll 1
+          for (int q = 0; q < 16; ++q) {
+            DV vv = dv_load<NB>(vo, q);
+            const DV z = *reinterpret_cast<const DV*>(zrow + q_off<NB>(q));
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+              const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
+              dset<NB>(vv, r, t);
+              s2 = s2 + t * t;
+            }
+            dv_store<NB>(vo, q, vv);
+          }
+        }
+        __syncthreads();
       }
     }
     if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result

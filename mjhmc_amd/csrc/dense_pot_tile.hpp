@@ -297,7 +297,24 @@ struct Shared {
   float red[2][4][kP];    // per-wave partial sums (energy, kinetic)
   int move[kP];           // transition chosen per particle
   float cb[128 * NB];     // b_j / nu_j: the value every u accumulator starts from (stage_bias)
+  float zn[128 * NB];     // the standard normals of ONE refreshing column (column_normals)
 };
+
+// HMCState.R (hmc_state.py:121-129) needs ndims standard normals for a column whose momentum is redrawn.  Drawn by the
+// column's own lanes that is 32 float64 Box-Muller pairs per lane, one after the other, with the rest of the workgroup
+// waiting (~20 us per tile with a refreshing column: a third of an iteration of the reference's own 36 x 1000 batches,
+// 1.5 % of C3).  Instead ALL 256 threads draw one pair each for the column -- the same pairs (2 k, 2 k + 1) of the same
+// counters, so the same values -- into LDS; the column's lanes read their elements after the barrier the caller places.
+template <int NB, typename F>
+__device__ __forceinline__ void column_normals(const RngKey& key, uint32_t pid, int D, F* zn) {
+  const int pair = threadIdx.x;
+  if (pair < 64 * NB) {
+    double z0, z1;
+    normal_pair(key, pid, (uint32_t)pair, z0, z1);
+    zn[2 * pair] = 2 * pair < D ? (F)z0 : (F)0;
+    zn[2 * pair + 1] = 2 * pair + 1 < D ? (F)z1 : (F)0;
+  }
+}
 
 // b / nu into LDS, once per kernel.  Every gradient starts by initialising its 16 NB accumulator registers from it; as
 // global loads these stood right behind the barrier in front of the first MFMA (and, in the float64-state kernel,
