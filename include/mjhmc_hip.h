@@ -271,6 +271,19 @@ int mjhmc_ring_moments(mjhmc_sampler* s, int slot0, int n, double shift, double*
 int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V, int64_t n, double eps, int n_steps,
                    double* X_out, double* V_out, double* EX_out, double* EV_out, double* dEdX_out);
 
+/* The two helpers of the jump process as operators on caller arrays (mjhmc/misc/utils.py; the samplers' kernels use
+ * the same device functions, `wait_time` and `first_min3` of csrc/elementwise.hpp):
+ *   draw_from (utils.py:31-50): waiting times of exponential clocks.  out[i] = inf where rates[i] == 0, otherwise
+ *     (1 / rates[i]) * unit_exp[i] -- numpy's exponential(scale = 1/rate) is scale * standard_exponential(), so with the
+ *     standard exponentials the caller drew the result is bit-identical.  A non-finite rate is the reference's
+ *     ValueError: out[i] = NaN there, *first_bad = the lowest such index, return MJHMC_ERR_NONFINITE (no bad rate:
+ *     *first_bad = -1, return 0).
+ *   min_idx (utils.py:15-28): which[j] = argmin over the k rows of draws[k][n] (row-major) in column j, the FIRST
+ *     minimum on ties and a NaN counting as the minimum, as np.argmin does; the caller lists the columns per row. */
+int mjhmc_draw_from(mjhmc_ctx* ctx, const double* rates, const double* unit_exp, int64_t n, double* out,
+                    int64_t* first_bad);
+int mjhmc_min_idx(mjhmc_ctx* ctx, const double* draws, int k, int64_t n, int32_t* which);
+
 /* Autocorrelation along the time axis of ring slots [slot0, slot0 + n):
  *   out[k] = sum_{d < ndims, particle < N} sum_t x_t * x_{t+k},   k = 0 .. n-1   (n float64 to the host)
  * linear == 0: t + k wraps modulo n.  out / out[0] is fft_autocor(samples) of mjhmc/misc/autocor.py:37-49

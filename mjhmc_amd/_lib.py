@@ -19,6 +19,7 @@ F64, F32, BF16 = 0, 1, 2
 MODE_MJHMC, MODE_CONTROL, MODE_CTHMC = 0, 1, 2
 F_X, F_V, F_EX, F_EV, F_DEDX, F_HFLF, F_CACHE, F_DWELL, F_TRANS = range(9)
 ERR_NO_DEVICE = -4
+ERR_NONFINITE = -5
 OP_SUM, OP_MIN, OP_MAX = 0, 1, 2
 COMM_ID_BYTES = 128
 
@@ -83,6 +84,8 @@ PROTOTYPES = {
     'mjhmc_leapfrog': (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int64, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P]),
     'mjhmc_ring_autocor': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     'mjhmc_autocor': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P]),
+    'mjhmc_draw_from': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, _P, ctypes.POINTER(ctypes.c_int64)]),
+    'mjhmc_min_idx': (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int64, _P]),
     'mjhmc_comm_unique_id': (ctypes.c_int, [_P]),
     'mjhmc_comm_create': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.POINTER(_P)]),
     'mjhmc_comm_destroy': (ctypes.c_int, [_P]),

@@ -137,6 +137,30 @@ int round_rows32(mjhmc_sampler* s, void* rows) {
 // the particle-major device layout; integer bookkeeping
 // ---------------------------------------------------------------------------------------------
 
+// mjhmc_draw_from / mjhmc_min_idx: the jump process's helpers on caller arrays (mjhmc/misc/utils.py:15-50)
+__global__ void draw_from_kernel(const double* __restrict__ rates, const double* __restrict__ e, int64_t n,
+                                 double* __restrict__ out, long long* first_bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool bad = false;
+  out[i] = wait_time(rates[i], e[i], bad);
+  if (bad) atomicMin(first_bad, (long long)i);
+}
+__global__ void min_idx_kernel(const double* __restrict__ draws, int k, int64_t n, int32_t* __restrict__ which) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int w = 0;
+  double best = draws[j];
+  for (int r = 1; r < k; ++r) {   // np.argmin: the first minimum; the first NaN wins outright
+    const double d = draws[(size_t)r * n + j];
+    if (!(best != best) && (d < best || d != d)) {
+      w = r;
+      best = d;
+    }
+  }
+  which[j] = w;
+}
+
 // src (D, N) float64 row-major  ->  dst [N][pitch] T ; only d < D is written
 template <typename T>
 __global__ void to_particle_major(const double* __restrict__ src, T* __restrict__ dst, int D, int64_t N, int pitch) {
@@ -2127,6 +2151,60 @@ int mjhmc_ring_autocor(mjhmc_sampler* s, int slot0, int n, int linear, double* h
   std::string err;
   const int rc = autocor_from_ring(s->stream, view, n, linear, host_out, err);
   return rc ? fail(rc, err) : 0;
+}
+
+int mjhmc_draw_from(mjhmc_ctx* ctx, const double* rates, const double* unit_exp, int64_t n, double* out,
+                    int64_t* first_bad) {
+  if (!ctx || !rates || !unit_exp || !out || n < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
+  if (first_bad) *first_bad = -1;
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  double *d_r = nullptr, *d_e = nullptr, *d_o = nullptr;
+  long long* d_bad = nullptr;
+  const size_t bytes = (size_t)n * sizeof(double);
+  const long long none = 0x7fffffffffffffffLL;
+  long long bad = none;
+  hipError_t rc = hipMalloc(&d_r, 3 * bytes + sizeof(long long));
+  if (rc != hipSuccess) return fail(MJHMC_ERR_HIP, hipGetErrorString(rc));
+  d_e = d_r + n;
+  d_o = d_e + n;
+  d_bad = reinterpret_cast<long long*>(d_o + n);
+  rc = hipMemcpy(d_r, rates, bytes, hipMemcpyHostToDevice);
+  if (rc == hipSuccess) rc = hipMemcpy(d_e, unit_exp, bytes, hipMemcpyHostToDevice);
+  if (rc == hipSuccess) rc = hipMemcpy(d_bad, &none, sizeof(long long), hipMemcpyHostToDevice);
+  if (rc == hipSuccess) {
+    hipLaunchKernelGGL(draw_from_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_r, d_e, n, d_o, d_bad);
+    rc = hipGetLastError();
+  }
+  if (rc == hipSuccess) rc = hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost);
+  if (rc == hipSuccess) rc = hipMemcpy(&bad, d_bad, sizeof(long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d_r);
+  if (rc != hipSuccess) return fail(MJHMC_ERR_HIP, hipGetErrorString(rc));
+  if (bad != none) {
+    if (first_bad) *first_bad = (int64_t)bad;
+    return fail(MJHMC_ERR_NONFINITE, "Infinite rate (mjhmc/misc/utils.py:43-48)");
+  }
+  return 0;
+}
+
+int mjhmc_min_idx(mjhmc_ctx* ctx, const double* draws, int k, int64_t n, int32_t* which) {
+  if (!ctx || !draws || !which || k < 1 || n < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  double* d_d = nullptr;
+  const size_t bytes = (size_t)k * (size_t)n * sizeof(double);
+  hipError_t rc = hipMalloc(&d_d, bytes + (size_t)n * sizeof(int32_t));
+  if (rc != hipSuccess) return fail(MJHMC_ERR_HIP, hipGetErrorString(rc));
+  int32_t* d_w = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(d_d) + bytes);
+  rc = hipMemcpy(d_d, draws, bytes, hipMemcpyHostToDevice);
+  if (rc == hipSuccess) {
+    hipLaunchKernelGGL(min_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_d, k, n, d_w);
+    rc = hipGetLastError();
+  }
+  if (rc == hipSuccess) rc = hipMemcpy(which, d_w, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_d);
+  if (rc != hipSuccess) return fail(MJHMC_ERR_HIP, hipGetErrorString(rc));
+  return 0;
 }
 
 int mjhmc_autocor(mjhmc_ctx* ctx, const double* samples, int64_t n_series, int n_samples, int linear,

@@ -49,6 +49,28 @@ class Context(object):
         return out
 
 
+    def draw_from(self, rates, unit_exp):
+        """Waiting times ``(1 / rate) * e`` (inf where the rate is 0); returns (draws, first_bad) with first_bad = -1
+        or the index of the first non-finite rate (mjhmc_draw_from in include/mjhmc_hip.h)."""
+        rates = np.ascontiguousarray(rates, dtype=np.float64)
+        unit_exp = np.ascontiguousarray(unit_exp, dtype=np.float64)
+        assert rates.ndim == 1 and unit_exp.shape == rates.shape
+        out = np.empty_like(rates)
+        bad = ctypes.c_int64(-1)
+        rc = self.lib.mjhmc_draw_from(self.handle, ptr(rates), ptr(unit_exp), int(rates.size), ptr(out), ctypes.byref(bad))
+        if rc != _lib.ERR_NONFINITE:
+            check(rc, self.lib)
+        return out, int(bad.value)
+
+    def min_idx(self, draws):
+        """argmin over the rows of a (k, n) float64 array per column, first minimum on ties (mjhmc_min_idx)."""
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        assert draws.ndim == 2 and draws.shape[0] >= 1
+        which = np.empty(draws.shape[1], dtype=np.int32)
+        check(self.lib.mjhmc_min_idx(self.handle, ptr(draws), int(draws.shape[0]), int(draws.shape[1]), ptr(which)), self.lib)
+        return which
+
+
 def context(device=0):
     """Process-wide context per device index."""
     if device not in _contexts:
