@@ -11,11 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mjhmc_amd import engine, _lib          # noqa: E402
 from bench import sic_model                 # noqa: E402
 
-tiles_per_cu = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+tiles_per_cu = float(sys.argv[1]) if len(sys.argv) > 1 else 4
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 ctx = engine.context(0)
 ncu = ctx.info()['n_cu']
-N = 32 * ncu * tiles_per_cu
+N = int(32 * ncu * tiles_per_cu)
 B, y, a0 = sic_model()
 en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, 1024, np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), y]))
 rs = np.random.RandomState(0)
