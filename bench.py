@@ -359,12 +359,14 @@ class Rig(object):
         return [float(v) for v in self.comm.allreduce_f64(np.asarray(list(values), dtype=np.float64), 'max')]
 
 
-def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
+def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=1):
+    """shard_of = G > 1: the workload at N/G particles on this one GPU -- what each rank of a G-GPU strong-scaled run
+    executes (no timed region holds a collective, so t(G GPUs, N) = t(1 GPU, N/G)); same kernels, same flags."""
     from mjhmc_amd import engine, _lib
     rank, world = rig.rank, rig.world
     w = dict(WORKLOADS[key])
     n_total = w['N'] if scaling == 'strong' else w['N'] * world
-    n_rank = n_total // world
+    n_rank = n_total // world // shard_of
     first = rank * n_rank
     kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T,
             'sic': _lib.E_SPARSE_CODE}[w['kind']]
@@ -397,7 +399,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
     reps = int(min(max(1, np.ceil(MIN_TIMED_S / per_call)), 4096))
 
     call_s, kern_ms, launches = [], 0.0, 0
-    agg = np.zeros(4)                               # l moves, cold caches, E evaluations, dEdX evaluations
+    agg = np.zeros(6)                               # l moves, cold caches, E evaluations, dEdX evaluations, f moves, r moves
     rig.monitor.start()
     for _ in range(reps):
         rig.barrier(smp)
@@ -412,7 +414,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         kern_ms += tim['jump_kernel_ms']
         launches += tim['n_jump_launches']
         agg += [sum(s.l for s in stats), sum(s.n_cold for s in stats), sum(s.E_evals for s in stats),
-                sum(s.dEdX_evals for s in stats)]
+                sum(s.dEdX_evals for s in stats), sum(s.f for s in stats), sum(s.r for s in stats)]
     device = rig.monitor.stop()
     call_s = rig.max_over_ranks(call_s)
     elapsed = float(np.sum(call_s))
@@ -422,7 +424,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
     # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel: what every
     # sampling_iteration() caller gets -- a call of ONE iteration is never fused), after the timed region
     unfused_ms = None
-    if fused:
+    if fused and shard_of == 1:
         for _ in range(8):
             smp.iterate(1)
         t_sum = 0.0
@@ -434,7 +436,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
     # per particle.  What that costs (re-tile kernel + PCIe, pageable host memory), outside `value`: a state read,
     # and a batch of 10 stacked samples = 10 iterations into the device ring + one download of the ring.
     boundary = None
-    if world == 1 and key == rig.head and scaling == 'weak':
+    if world == 1 and key == rig.head and scaling == 'weak' and shard_of == 1:
         esz = {'float64': 8, 'float32': 4, 'bfloat16': 2}[w['dtype']]
         t_b = time.perf_counter()
         Xh = smp.read(_lib.F_X)
@@ -477,6 +479,9 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
     n_launch_call = -(-steps // 64) if fused else steps
     it_per_launch = steps / float(n_launch_call)
     cold_frac = agg[1] / float(n_rank * iters)
+    full_shape = shard_of == 1 and not (scaling == 'strong' and world > 1)   # the PMC passes were taken on the single-GPU shapes
+    # What every field below means (kernels, byte and flop models, why each bound) is DESIGN.md section 7 ("the line's
+    # fields"); the line itself carries numbers only, so that it stays under the 8 kB the driver keeps.
     if w['kind'] in ('pot', 'sic'):
         # dense energy: the bound is the matrix pipe (fp32 for ProductOfT, bf16 for SparseImageCode).
         # Algorithmic flops from the exact counters: dEdX_evals * 4*D*K + E_evals * 2*D*K
@@ -487,15 +492,12 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         flops = (agg[3] * 4 * DK + agg[2] * 2 * DK) / iters
         tf = flops / (kern_it_ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
-                'traffic': measured_traffic(key, 1),
-                'kernel': (('pot64_jump_kernel + pot64_flf_kernel' if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
-                            'pot_jump_kernel + pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel + sic_flf_kernel')
-                           + ' (one sampling iteration = both kernels, launched as two half-batches on two streams)'),
+                'traffic': measured_traffic(key, 1) if full_shape else None,
+                'kernel': ('pot64_jump_kernel+pot64_flf_kernel' if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
+                           'pot_jump_kernel+pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel+sic_flf_kernel'),
                 'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'algorithmic_flops_per_launch': flops,
                 'hbm': {'algorithmic_bytes_per_launch': dense_bytes * n_rank,
-                        'achieved': dense_bytes * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s',
-                        'what': 'state rows read and written per iteration (ProductOfT: X, V and the stored dE/dX; '
-                                'SparseImageCode: X, V) + per-particle scalars; nowhere near the HBM roofline'}}
+                        'achieved': dense_bytes * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s'}}
         if w['kind'] == 'pot' and w['dtype'] == 'float64':
             # the float64-state kernel streams the position through a working copy once per leapfrog step:
             # 8 B read + 8 B written per element and gradient evaluation, by design -- part of what this kernel has to move
@@ -503,30 +505,26 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
             roof['hbm']['working_copy_bytes_per_launch'] = wc
             roof['hbm']['algorithmic_bytes_per_launch'] += wc
             roof['hbm']['achieved'] = roof['hbm']['algorithmic_bytes_per_launch'] / (kern_it_ms * 1e-3) / 1e9
-            roof['hbm']['what'] = ('state rows (X, V, dE/dX in float64 + scalars) read and written per iteration + the position\'s '
-                                   'working copy, 16 B per element and gradient evaluation (it is streamed through the tile '
-                                   'kernel\'s epilogue: by design; L2 misses, served by the 256 MB MALL or HBM) -- 1.2 TB/s, nowhere '
-                                   'near a memory roofline')
         if w['kind'] == 'sic':
             # one pass over the 512 KB dictionary per leapfrog step of a 32-particle tile, plus two per trajectory (the
             # residual at its head, the closing half kick): L + 2 passes per L gradient evaluations, out of L2 (the
-            # dictionary cannot stay in a CU).  Rounds 1-2 streamed it twice per step.
+            # dictionary cannot stay in a CU).
             tile_grads = agg[3] / 32.0 / iters
             l2 = tile_grads * (w['L'] + 2.0) / w['L'] * 512 * 1024 / (kern_it_ms * 1e-3) / 1e9
-            roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS,
-                          'what': 'dictionary bytes streamed from L2 per launch (512 KiB per tile and dictionary pass, '
-                                  'L + 2 passes per trajectory) / time'}
-            # The bound this kernel actually runs into: BOTH operands of every MFMA come out of LDS,
-            # 2 KiB per v_mfma_f32_32x32x16_bf16 -- 2 MiB of LDS reads per tile and leapfrog step (1024 MFMAs) -- plus the
-            # dictionary landing in LDS (512 KiB per step) and the published fragments (80 KiB).  At the LDS array's 256 B/clk
-            # per CU the reads alone take the 8 192 cycles the MFMAs take: the matrix peak would need the LDS array at 100 %.
-            # (Measured: array 44 % busy, matrix pipe 40 %, profiles/r04/c5_lds_counters.txt -- the phases of a round alternate.)
+            roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS}
+            # The bound the 32-column tile sets: every leapfrog step streams the whole dictionary out of L2 for
+            # 4*D*K*32 flop = 64 flop per dictionary byte; ceiling = min(MFMA peak, L2 peak x 64 flop/B)
+            fl_per_b = 4.0 * DK * 32 / (512 * 1024)
+            ceil_tf = min(peak, L2_PEAK_GBS * fl_per_b / 1e3)
+            roof['l2_stream'] = {'bound': 'l2-stream', 'flop_per_l2_byte': fl_per_b, 'achieved': tf, 'peak': ceil_tf,
+                                 'unit': 'TFLOP/s', 'frac': tf / ceil_tf}
+            # LDS: BOTH operands of every MFMA come out of LDS, 2 KiB per v_mfma_f32_32x32x16_bf16 -- 2 MiB of LDS reads per
+            # tile and leapfrog step (1024 MFMAs) -- plus the dictionary landing (512 KiB per step) and the published
+            # fragments (80 KiB), against 256 B/clk/CU at 2.4 GHz
             lds_bytes = tile_grads * (2.0 + 0.578) * 1024 * 1024
             lds_peak = 256.0 * 256 * 2.4                                  # B/clk/CU x CUs x GHz = GB/s
             roof['lds'] = {'achieved': lds_bytes / (kern_it_ms * 1e-3) / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
-                           'frac': lds_bytes / (kern_it_ms * 1e-3) / 1e9 / lds_peak,
-                           'what': 'LDS bytes moved per launch (per tile and gradient: 2 MiB of MFMA operand reads, 512 KiB of '
-                                   'LDS-DMA landing, 80 KiB of published fragments) / time, against 256 B/clk/CU at 2.4 GHz'}
+                           'frac': lds_bytes / (kern_it_ms * 1e-3) / 1e9 / lds_peak}
     else:
         abytes = algorithmic_bytes_per_particle(w['D'], esize) * n_rank          # per sampling iteration
         hbm = {'achieved': abytes / (kern_it_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -534,44 +532,39 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         hbm['frac_of_algorithmic'] = hbm['achieved'] / HBM_PEAK_GBS
         # Vector work executed per iteration: one fused multiply-add per element for the opening half kick, two per
         # element and leapfrog step (drift, merged kick), on the forward trajectory of every particle and the
-        # inverse one of the cold-cache particles, plus 4 flop per element for the two energy sums.
+        # inverse one of the cold-cache particles, plus 4 flop per element for the two energy sums (rates, draws,
+        # reductions and bookkeeping are vector instructions too, not flops).
         vflops = (1.0 + cold_frac) * (4.0 * w['L'] + 6.0) * w['D'] * n_rank
         valu_tf = vflops / (kern_it_ms * 1e-3) / 1e12
         valu_peak = 78.6 if w['dtype'] == 'float64' else 157.3
-        valu = {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak,
-                'what': 'trajectory + energy-sum flops only (rates, draws, reductions and bookkeeping are vector '
-                        'instructions too, not flops)'}
-        traffic = measured_traffic(key, it_per_launch)
+        valu = {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak}
+        traffic = measured_traffic(key, it_per_launch) if full_shape else None
         if fused:
             # the state crosses HBM once per LAUNCH, not once per iteration: HBM does not bound the launch (the
             # algorithmic byte rate of SURVEY 8d exceeds the HBM peak); the fp64 vector pipe does
             roof = dict(valu, bound='fp64_valu', traffic=traffic, kernel='mjhmc_jump_kernel<FUSED>',
                         avg_launch_ms=kern_it_ms * it_per_launch, launches_timed=launches / it_per_launch,
                         iterations_per_launch=it_per_launch, algorithmic_flops_per_launch=vflops * it_per_launch)
-            hbm['note'] = ('SURVEY 8d byte model / time: not a bound for a fused launch (HBM actually moved: '
-                           'roofline.traffic per launch)')
             roof['hbm_algorithmic'] = hbm
             if unfused_ms:
                 roof['one_iteration_per_launch'] = {
                     'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': abytes / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    'traffic': measured_traffic(key + '_one_iteration_per_launch', 1),
-                    'what': 'the same kernel with the state crossing HBM every iteration (calls of ONE iteration): HBM-bound'}
+                    'traffic': measured_traffic(key + '_one_iteration_per_launch', 1)}
         else:
             roof = {'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': hbm['achieved'] / HBM_PEAK_GBS, 'traffic': traffic,
                     'kernel': 'mjhmc_jump_kernel' if n_rank < 16384 or w['D'] * esize >= 2048 else
-                              'mjhmc_jump_kernel + the compacted passes of one iteration (inverse-L pass with the pending refresh, cold list)',
+                              'mjhmc_jump_kernel+compacted passes',
                     'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'iterations_per_launch': 1.0,
                     'algorithmic_bytes_per_launch': abytes, 'valu': valu}
     alg_bytes = (roof.get('hbm', {}).get('algorithmic_bytes_per_launch') or roof.get('algorithmic_bytes_per_launch')
                  or roof.get('hbm_algorithmic', {}).get('algorithmic_bytes_per_launch'))
     if fused:
         alg_bytes = abytes                     # a fused launch has to move the state across HBM once, whatever it fuses
-    if scaling == 'strong' and world > 1:
-        roof['traffic'] = None                 # the PMC passes were taken on the single-GPU shapes
     roof['traffic_over_algorithmic'] = (roof['traffic'] / alg_bytes) if roof.get('traffic') and alg_bytes else None
     per_step = np.array(call_s) * 1e3 / steps
+    moves = float(n_rank * iters)
     out = {
         'value': units / elapsed, 'unit': 'particle-steps/s', 'ms_per_step': elapsed * 1e3 / iters,
         'ms_per_step_median': float(np.median(per_step)), 'ms_per_step_min': float(per_step.min()),
@@ -580,12 +573,16 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         'config': {'workload': w['name'], 'ndims': w['D'], 'nparticles_per_gpu': n_rank, 'nparticles_total': n_rank * world,
                    'L': w['L'], 'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
                    'particles_x_L_per_s': n_rank * world * w['L'] * iters / elapsed,
-                   'L_move_fraction': agg[0] / float(n_rank * iters), 'cold_fraction': cold_frac},
+                   'L_move_fraction': agg[0] / moves, 'F_move_fraction': agg[4] / moves, 'R_move_fraction': agg[5] / moves,
+                   'cold_fraction': cold_frac},
         'roofline': roof,
         'device': device,
     }
-    if device.get('sclk_mhz'):
-        # the fraction again, against the peak at the clock the chip actually held (the guide's peaks assume 2.4 GHz)
+    if shard_of > 1:
+        out['config']['shard_of'] = shard_of
+    if device.get('sclk_mhz') and roof['bound'] == 'mfma':
+        # the fraction again, against the peak at the clock the chip actually held (the guide's matrix / LDS peaks assume
+        # 2.4 GHz; an HBM or vector-pipe figure does not scale that way and gets none)
         roof['frac_at_held_clock'] = roof['frac'] * 2400.0 / max(device['sclk_mhz'][1], 1.0)
         if 'lds' in roof:
             roof['lds']['frac_at_held_clock'] = roof['lds']['frac'] * 2400.0 / max(device['sclk_mhz'][1], 1.0)
@@ -595,9 +592,44 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak'):
         out['cpu_baseline'] = cpu_baseline(w, cpu_seconds)
         out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
     if w['kind'] == 'pot':
-        out['config']['arithmetic'] = ('float32 state and float32 MFMA force (fused tile kernel)' if w['dtype'] == 'float32' else
-                                       'float64 state around the float32 MFMA force: the reference\'s arithmetic (tile kernel, '
-                                       'state streamed through its epilogue)')
+        out['config']['arithmetic'] = 'f32 state + f32 MFMA force' if w['dtype'] == 'float32' else 'f64 state around the f32 MFMA force (the reference\'s arithmetic)'
+    return out
+
+
+def rnd(x, sig=5):
+    """numbers of the printed line: 5 significant digits (the detail file keeps everything)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (str, int)):
+        return x
+    if isinstance(x, float):
+        return float('%.*g' % (sig, x)) if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: rnd(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [rnd(v, sig) for v in x]
+    return rnd(float(x), sig)
+
+
+def compact(rec):
+    """One workload's record as the printed line carries it (numbers only; the full record goes to --detail)."""
+    r = rec['roofline']
+    roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms') if k in r}
+    for sub in ('l2_stream', 'l2', 'lds', 'one_iteration_per_launch'):
+        if sub in r:
+            roof[sub + '_frac'] = r[sub]['frac']
+    if 'frac_at_held_clock' in r:
+        roof['frac_at_held_clock'] = r['frac_at_held_clock']
+    c = rec['config']
+    out = {'value': rec['value'], 'ms_per_step': rec['ms_per_step'], 'steps': rec.get('steps'), 'roofline': roof,
+           'lfr': [c['L_move_fraction'], c['F_move_fraction'], c['R_move_fraction']], 'cold': c['cold_fraction'],
+           'n': c['nparticles_per_gpu']}
+    d = rec.get('device') or {}
+    if d.get('sclk_mhz'):
+        out['sclk_w'] = [d['sclk_mhz'][1], d['power_w'][1] if d.get('power_w') else None]
+    if 'cpu_baseline' in rec:
+        b = rec['cpu_baseline']
+        out['cpu_baseline'] = {'value': b['value'], 'cores': b['cores'], 'kind': b['kind'], 'n': b['nparticles'],
+                               'iters': b['iterations'], 's': b['seconds']}
+        out['gpu_over_cpu'] = c.get('gpu_over_cpu')
     return out
 
 
@@ -700,10 +732,19 @@ def _watchdog(rdv_dir, n, t_start, limits):
     for r in range(n):
         try:
             with open(os.path.join(rdv_dir, 'progress.%d' % r)) as f:
-                marks.append([ln.split(None, 1) for ln in f.read().splitlines() if ln.strip()])
+                rows = []
+                for ln in f.read().splitlines():        # the ranks append while we read: a half-written line is skipped
+                    parts = ln.split(None, 1)
+                    if len(parts) != 2:
+                        continue
+                    try:
+                        rows.append((float(parts[0]), parts[1]))
+                    except ValueError:
+                        continue
+                marks.append(rows)
         except OSError:
             marks.append([])
-    ready = [next((float(t) for t, m in mk if m == 'ctx_ready'), None) for mk in marks]
+    ready = [next((t for t, m in mk if m == 'ctx_ready'), None) for mk in marks]
     if any(t is None for t in ready):
         return ('a rank did not bring its device context up within %.0f s' % limits['start']) if now - t_start > limits['start'] else None
     done = [any(m == 'gather_done' for _, m in mk) for mk in marks]
@@ -712,7 +753,7 @@ def _watchdog(rdv_dir, n, t_start, limits):
             return 'the communicator / sample all-gather check did not finish within %.0f s (ranks %s)' % (
                 limits['gather'], [r for r in range(n) if not done[r]])
         return None
-    last = max(float(mk[-1][0]) for mk in marks)
+    last = max(mk[-1][0] for mk in marks)
     if now - last > limits['stall']:
         return 'no rank reported a milestone for %.0f s' % limits['stall']
     return None
@@ -780,6 +821,13 @@ def _run_ranks(args, argv, extra_env, limits):
         for t in relays:
             t.join(timeout=10)
     finally:
+        for p in procs:                               # whatever ended the attempt (an exception here included): no rank is left behind
+            if p.poll() is None:
+                p.kill()
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pass
         shutil.rmtree(rdv_dir, ignore_errors=True)
     return rc, timed_out, collected
 
@@ -863,6 +911,12 @@ def main(argv=None):
                          'the float32 force --, the workload of BASELINE.json\'s numeric target; c3: its float32-state form)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard-of', default='8',
+                    help='comma list of G: after every workload, the same workload at N/G particles on this ONE GPU (what a rank '
+                         'of a G-GPU strong-scaled run executes); shard_efficiency = t(N) / (G t(N/G)).  Default 8; "1" = none; '
+                         '"2,4,8" = the whole curve.  Ignored at --gpus > 1')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='file that receives the complete per-workload records (the printed line carries numbers only)')
     ap.add_argument('--spawn-check', action='store_true',
                     help='ranks report their environment and the rendezvous channel, then exit before touching a GPU')
     args = ap.parse_args(argv)
@@ -882,7 +936,8 @@ def main(argv=None):
     head = args.head if args.head in keys else keys[0]
     keys = [head] + [k for k in keys if k != head]
     rig.head = head
-    results, strong = {}, {}
+    results, strong, shards = {}, {}, {}
+    shard_gs = sorted({int(g) for g in args.shard_of.split(',') if g.strip() and int(g) > 1}) if rig.world == 1 else []
 
     def budget(key):
         # the head workload runs exactly --steps / --warmup; the other dense workloads (10-20 ms per iteration: a batch
@@ -904,6 +959,17 @@ def main(argv=None):
         if results[key] is not None:
             results[key]['steps'] = steps
             results[key]['warmup'] = warm
+        # what a rank of a G-GPU strong-scaled run executes: the same workload at N/G particles on this one GPU, right
+        # after the full-size run (same box, same clocks): shard_efficiency = t(N) / (G * t(N/G))
+        for g in shard_gs:
+            if key == 'c1':
+                continue
+            rec = run_workload(rig, key, steps, warm, 0, args.scaling, shard_of=g)
+            progress('shard_done %s/%d' % (key, g))
+            if rec is not None:
+                rec.update(steps=steps, warmup=warm)
+                rec['shard_efficiency'] = results[key]['ms_per_step'] / (g * rec['ms_per_step'])
+                shards.setdefault(key, {})[g] = rec
     if rig.world > 1 and args.scaling == 'weak':
         # BASELINE.json words C4 and C5 as totals sharded over the GPUs: the same line carries them strong-scaled
         for key in [k for k in ('c4', 'c5') if k in keys]:
@@ -916,54 +982,92 @@ def main(argv=None):
         # the two forms of C3 share the CPU baseline (which IS the float64-state arithmetic)
         pair = [results.get('c3'), results.get('c3f64')]
         src = next((r for r in pair if r and 'cpu_baseline' in r), None)
-        for r, same in zip(pair, (False, True)):
+        for r in pair:
             if r and src and 'cpu_baseline' not in r:
-                r['cpu_baseline'] = dict(src['cpu_baseline'], shared='timed once, with the other form of C3: the NumPy port '
-                                         'integrates float64 state around a float32 force' + ('' if same else
-                                         ' (this GPU form keeps float32 state: not like for like)'))
+                r['cpu_baseline'] = dict(src['cpu_baseline'], shared=True)
                 r['config']['gpu_over_cpu'] = r['value'] / src['cpu_baseline']['value']
         h = results[head]
+        hr = h['roofline']
+        # The printed line: the contract's keys, numbers only, <= 8 kB (the driver keeps the line's tail and the scalar keys
+        # of `config`): every workload's ms / fraction / bound as FLAT scalars in `config`, compact per-workload records
+        # under `workloads`, and the summary once more as the LAST key.  The complete records go to --detail.
+        cfg = dict(h['config'])
+        flat = {}
+        for k, v in results.items():
+            if not v:
+                continue
+            r, c = v['roofline'], v['config']
+            flat['%s_ms' % k] = v['ms_per_step']
+            flat['%s_frac' % k] = r['frac']
+            flat['%s_bound' % k] = r['bound']
+            if 'l2_stream' in r:
+                flat['%s_l2stream_frac' % k] = r['l2_stream']['frac']
+                flat['%s_l2_frac' % k] = r['l2']['frac']
+            flat['%s_lfr' % k] = '%.3f/%.3f/%.3f' % (c['L_move_fraction'], c['F_move_fraction'], c['R_move_fraction'])
+            if c.get('gpu_over_cpu'):
+                flat['%s_gpu_over_cpu' % k] = c['gpu_over_cpu']
+            for g, rec in sorted(shards.get(k, {}).items()):
+                flat['%s_shard%d_ms' % (k, g)] = rec['ms_per_step']
+                flat['%s_shard%d_frac' % (k, g)] = rec['roofline']['frac']
+                flat['%s_shard%d_eff' % (k, g)] = rec['shard_efficiency']
+        cfg.update(flat)
+        if gather_info is not None:
+            cfg['sample_gather_ok'] = bool(gather_info.get('ok'))
+            cfg['sample_gather_backend'] = gather_info.get('backend')
+        if rig.comm_note:
+            cfg['comm_note'] = rig.comm_note[:200]
         out = {
             'metric': 'particle-steps/sec (ndims x nparticles x L)',
             'value': h['value'], 'unit': h['unit'], 'n_gpus': rig.world, 'steps': h['steps'], 'warmup': h['warmup'],
             'ms_per_step': h['ms_per_step'], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': h['dtype'], 'data': 'synthetic', 'config': h['config'], 'roofline': h['roofline'],
+            'dtype': h['dtype'], 'data': 'synthetic', 'config': cfg,
+            'roofline': {k: hr[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_ms',
+                                            'launches_timed', 'algorithmic_flops_per_launch', 'algorithmic_bytes_per_launch',
+                                            'traffic_over_algorithmic', 'frac_at_held_clock') if k in hr},
             'timing': {k: h[k] for k in ('ms_per_step_median', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'timed_s')},
-            'device': h.get('device'),
         }
-        # every workload in one compact entry of `config` (which survives a truncated line): [ms per step, fraction of the
-        # bound's peak, bound, median sclk MHz, median socket W]
-        out['config'] = dict(out['config'], summary={
-            k: [round(v['ms_per_step'], 5), round(v['roofline']['frac'], 4), v['roofline']['bound'],
-                (v.get('device') or {}).get('sclk_mhz', [None, None])[1] if (v.get('device') or {}).get('sclk_mhz') else None,
-                (v.get('device') or {}).get('power_w', [None, None])[1] if (v.get('device') or {}).get('power_w') else None]
-            for k, v in results.items() if v})
         if 'cpu_baseline' in h:
-            out['cpu_baseline'] = h['cpu_baseline']
+            b = h['cpu_baseline']
+            out['cpu_baseline'] = {'value': b['value'], 'unit': b['unit'], 'cores': b['cores'], 'kind': b['kind'],
+                                   'sample': 'NumPy port of the reference path, %d of %d columns, %d sampling_iterations after 1 '
+                                             'warm-up, %.1f s, os.cpu_count=%d' % (b['nparticles'], WORKLOADS[head]['N'], b['iterations'],
+                                                                                  b['seconds'], os.cpu_count())}
         tgt = results.get('c3f64') or results.get('c3')
         if tgt is not None and 'cpu_baseline' in tgt:
             # BASELINE.json: ">= 50x the NumPy reference in particle-steps/sec on ProductOfT (ndims=512, 100k particles) at 1 GPU"
             # -- quoted like for like: the GPU run in the reference's arithmetic against the NumPy port (the same arithmetic)
             ratio = tgt['value'] / tgt['cpu_baseline']['value']
             out['target'] = {'workload': 'c3f64' if results.get('c3f64') else 'c3', 'min_gpu_over_cpu': 50, 'gpu_over_cpu': ratio,
-                             'met': bool(ratio >= 50),
-                             'cpu_sample': 'N = %d columns, %d timed iterations' % (tgt['cpu_baseline']['nparticles'],
-                                                                                    tgt['cpu_baseline']['iterations'])}
-            if results.get('c3') and results.get('c3f64'):
-                out['target']['gpu_over_cpu_float32_state'] = results['c3']['value'] / tgt['cpu_baseline']['value']
+                             'met': bool(ratio >= 50)}
         if 'boundary' in h:
-            out['boundary'] = h['boundary']
+            bd = h['boundary']
+            out['boundary'] = {'state_read_GBps': bd['state_read_GBps'], 'state_read_warm_GBps': bd['state_read_warm_GBps'],
+                               'sample10': bd['sample10']}
         if gather_info is not None:
-            out['config'] = dict(out['config'], sample_gather=gather_info)
-        if rig.comm_note:
-            out['config'] = dict(out['config'], comm_note=rig.comm_note)
+            out['sample_gather'] = {k: v for k, v in gather_info.items() if k not in ('compared_with',)}
         if len(keys) > 1:
-            out['workloads'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world, scaling=args.scaling)
-                                for k, v in results.items()}
+            out['workloads'] = {k: compact(v) for k, v in results.items() if v}
+        if shards:
+            out['shards'] = {k: {str(g): {'n': rec['config']['nparticles_per_gpu'], 'ms': rec['ms_per_step'],
+                                          'frac': rec['roofline']['frac'], 'eff': rec['shard_efficiency']}
+                                 for g, rec in sorted(v.items())} for k, v in shards.items()}
         if strong:
-            out['strong'] = {k: dict(v, metric=out['metric'], n_gpus=rig.world) for k, v in strong.items()}
-        print(json.dumps(out))
+            out['strong'] = {k: compact(v) for k, v in strong.items() if v}
+        # LAST key (the tail of the line is what a truncating reader keeps): [ms, frac, bound, shard-8 efficiency] per workload
+        out['summary'] = {k: [v['ms_per_step'], v['roofline']['frac'], v['roofline']['bound'],
+                              (shards.get(k, {}).get(8) or {}).get('shard_efficiency')] for k, v in results.items() if v}
+        line = json.dumps(rnd(out))
+        print(line)
         sys.stdout.flush()
+        if args.detail:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+                with open(args.detail, 'w') as f:
+                    json.dump({'line_bytes': len(line), 'workloads': results,
+                               'shards': {k: {str(g): r for g, r in v.items()} for k, v in shards.items()},
+                               'strong': strong, 'sample_gather': gather_info}, f, indent=1, default=float)
+            except OSError as exc:
+                sys.stderr.write('bench.py: --detail %s not written (%s)\n' % (args.detail, exc))
     if rig.comm is not None:
         rig.comm.barrier()
         if hasattr(rig.comm, 'close'):
