@@ -106,13 +106,19 @@ typedef enum {
  * Distribution.E_count / dEdX_count (mjhmc/misc/distributions.py:62-75). */
 typedef struct {
   int64_t l, f, r, fl;
-  int64_t n_cold;      /* particles whose inverse-L proposal had to be integrated (cold FLF cache) */
+  int64_t n_cold;      /* particles with a cold FLF cache: the reference integrates F L F for each of them
+                          (hmc_state.py:109-119) and counts the evaluations below                      */
   int64_t E_evals;
   int64_t dEdX_evals;
   int32_t nonfinite;   /* 1: some particle produced a non-finite rate (utils.py:41-48); the attempt
                           was NOT committed, state is as before the attempt                        */
   int32_t L_used;
   double eps_used;
+  int64_t n_flf_run;   /* inverse-L trajectories the device actually integrated (<= n_cold): a particle that has
+                          just moved by F has F L F (X, -V) = F L (X, V), the L proposal of the iteration in which
+                          it flipped -- the same operations on the same numbers (the reference's authors left the
+                          shortcut commented out, markov_jump_hmc.py:401); the dense kernels hand its H() on instead
+                          of integrating it again.  Results and the reference's counters are unaffected           */
 } mjhmc_iter_stats;
 
 const char* mjhmc_last_error(void);

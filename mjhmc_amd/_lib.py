@@ -27,7 +27,8 @@ COMM_ID_BYTES = 128
 class IterStats(ctypes.Structure):
     _fields_ = [('l', ctypes.c_int64), ('f', ctypes.c_int64), ('r', ctypes.c_int64), ('fl', ctypes.c_int64),
                 ('n_cold', ctypes.c_int64), ('E_evals', ctypes.c_int64), ('dEdX_evals', ctypes.c_int64),
-                ('nonfinite', ctypes.c_int32), ('L_used', ctypes.c_int32), ('eps_used', ctypes.c_double)]
+                ('nonfinite', ctypes.c_int32), ('L_used', ctypes.c_int32), ('eps_used', ctypes.c_double),
+                ('n_flf_run', ctypes.c_int64)]
 
 
 class EngineError(RuntimeError):

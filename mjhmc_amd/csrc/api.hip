@@ -33,7 +33,7 @@ static int pow2ceil(int v) {
 }
 
 // The A/B switches of the measurement tools and of the launch-strategy tests (MJHMC_NO_FUSE, MJHMC_NO_COMPACT,
-// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
+// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
 // MJHMC_SIC_COPIES) and the failure-placing hook MJHMC_DEBUG_POISON exist only in libmjhmc_hip_test.so (built with
 // -DMJHMC_TEST_HOOKS, `make test_hooks`).  The shipped library consults no environment variable on the sampling path:
 // the only ones it reads at all name libraries to dlopen (MJHMC_RCCL_LIB; hipRTC / hipFFT by their sonames).
@@ -877,7 +877,7 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void* ptrs[] = {s->flf_list, s->flf_counts, s->Hpre, s->Hwork, s->cold_list, s->pot64_scratch, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
+  void* ptrs[] = {s->flf_list, s->flf_counts, s->Hpre, s->Hwork, s->cold_list, s->pot64_scratch, s->Hspec[0], s->Hspec[1], s->Hspec_dump, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
                   s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
@@ -899,7 +899,6 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
     if (s->pipe_ev[i]) (void)hipEventDestroy(s->pipe_ev[i]);
   }
   host_traj_free(s);
-  if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return 0;
@@ -951,10 +950,12 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
         if (!s->Hwork) {
           HIPCHK(hipMalloc((void**)&s->Hwork, s->Npad * ssize(s)));  // float32, or float64 for ProductOfT's float64 state
           HIPCHK(hipMemsetAsync(s->Hwork, 0, s->Npad * ssize(s), s->stream));   // (padding rows read it and ignore it)
-          HIPCHK(hipMalloc((void**)&s->cold_list, (2 * s->Npad + 4) * sizeof(int)));  // two lists (iterations alternate) + [half][parity] counters
-          if (e->is_pot() && dtype == MJHMC_F64 && !e->pot_big())   // working rows of the inverse-L pass, for two concurrent launches
-            HIPCHK(hipMalloc((void**)&s->pot64_scratch, (size_t)2 * pot64_scratch_workgroups() * 2 * 32 * row_bytes(s)));
+          HIPCHK(hipMalloc((void**)&s->cold_list, (2 * s->Npad + 3 * kMaxDenseParts) * sizeof(int)));  // two lists (iterations alternate) + [part][3] counters
+          if (e->is_pot() && dtype == MJHMC_F64 && !e->pot_big())   // working rows of the tile kernel, one set per concurrent launch
+            HIPCHK(hipMalloc((void**)&s->pot64_scratch, (size_t)kMaxDenseParts * pot64_scratch_workgroups() * 2 * 32 * row_bytes(s)));
         }
+        HIPCHK(hipMalloc(&s->Hspec[i], s->Npad * ssize(s)));
+        HIPCHK(hipMemsetAsync(s->Hspec[i], 0xFF, s->Npad * ssize(s), s->stream));   // NaN: nothing handed on
       }
       HIPCHK(hipMalloc(&s->EX[i], s->Npad * ssize(s)));
       HIPCHK(hipMalloc(&s->EV[i], s->Npad * ssize(s)));
@@ -1005,10 +1006,21 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   return 0;
 }
 
+// An F-mover's H(L proposal) stands in for the H of its inverse-L proposal in the next iteration (dense_pot.hip).  That
+// holds for the state and the trajectory it was computed with: anything that changes either -- the step size or count,
+// a state or cache write from the host, reset_flf_cache, a restore -- drops it (all NaN: every cold particle integrates).
+static int drop_spec(mjhmc_sampler* s) {
+  if (!s->Hspec[0]) return 0;
+  HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipMemsetAsync(s->Hspec[s->scur], 0xFF, (size_t)s->Npad * ssize(s), s->stream));
+  return 0;
+}
+
 int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, double p_r, double beta,
                       double p_flip) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   if (num_leapfrog_steps < 0) return fail(MJHMC_ERR_INVALID, "num_leapfrog_steps must be >= 0");
+  if (epsilon != s->eps || num_leapfrog_steps != s->L) TRY(drop_spec(s));
   s->eps = epsilon;
   s->L = num_leapfrog_steps;
   s->p_r = p_r;
@@ -1047,6 +1059,7 @@ int mjhmc_restore(mjhmc_sampler* s) {
   void* dst[7] = {s->Xcur, s->Vbuf[s->vcur], s->EX[s->scur], s->EV[s->scur], s->Hflf[s->scur], s->dwell,
                   s->Gbuf[s->vcur]};
   for (int i = 0; i < nck; ++i) HIPCHK(hipMemcpyAsync(dst[i], s->ck[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
+  TRY(drop_spec(s));
   s->tick = s->ck_tick;
   s->undo_valid = false;
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1090,7 +1103,7 @@ int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
   HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
-  return 0;
+  return drop_spec(s);
 }
 
 }  // extern "C"
@@ -1106,7 +1119,7 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
       st.l = hs[4 * i + 0];
       st.f = hs[4 * i + 1];
       st.r = hs[4 * i + 2];
-      st.n_cold = hs[4 * i + 3];
+      st.n_cold = hs[4 * i + 3] & 0xFFFFFFFFLL;   // (the dense kernels: integrated inverse-L trajectories in the high half)
     } else if (s->mode == MJHMC_MODE_CTHMC) {  // clocks FL, F, R (markov_jump_hmc.py:288-290)
       st.fl = hs[4 * i + 0];
       st.f = hs[4 * i + 1];
@@ -1122,6 +1135,8 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
     st.nonfinite = (failed && i == done) ? 1 : 0;
     st.L_used = s->L;
     st.eps_used = s->eps;
+    // inverse-L trajectories integrated: all of the cold ones -- the dense kernels skip the F-movers' (dense_pot.hip)
+    st.n_flf_run = (s->mode == MJHMC_MODE_MJHMC && s->en->is_dense()) ? (hs[4 * i + 3] >> 32) : st.n_cold;
   }
 }
 
@@ -1145,8 +1160,10 @@ static void fill_iter_stats(const mjhmc_sampler* s, const std::vector<long long>
 // every iteration boundary (the first form of this) kept 1.5 % / 4 %: the dispatcher hands free CUs to the pending
 // workgroups of the OLDEST dispatch first, a persistent grid of one workgroup per CU shuts out even a one-block memset
 // until a workgroup exits, and a boundary at which both halves wait for each other is a drain again.
+// part `which` of a dense batch: particles [start, start + n), their rows of every per-particle array, their stretch of the
+// lists, their own three rotating counters (iteration i reads slot i % 3, appends to (i + 1) % 3, clears (i + 2) % 3)
 template <class A, typename S>
-static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pitch, int which) {
+static A part_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pitch, int which, int iter, int* counters) {
   A h = a;
   h.X_in = a.X_in + (size_t)start * pitch;
   h.V_in = a.V_in + (size_t)start * pitch;
@@ -1155,18 +1172,25 @@ static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pi
   h.EX_in = a.EX_in + start;
   h.EV_in = a.EV_in + start;
   h.Hflf_in = a.Hflf_in + start;
+  h.Hspec_in = a.Hspec_in + start;
   h.Hwork = a.Hwork + start;
   h.EX_out = a.EX_out + start;
   h.EV_out = a.EV_out + start;
   h.Hflf_out = a.Hflf_out + start;
+  h.Hspec_out = a.Hspec_out + start;
   h.dwell = a.dwell + start;
   h.dwell_ring = a.dwell_ring + start;
   h.trans = a.trans + start;
   h.cold_list = a.cold_list + start;
   h.next_list = a.next_list + start;
-  h.cold_count = a.cold_count + 2 * which;   // counters: [half][parity]
-  h.next_count = a.next_count + 2 * which;
-  if constexpr (std::is_same<A, Pot64JumpArgs>::value)   // the inverse-L pass's working rows: one set per concurrent launch
+  h.cold_count = counters + 3 * which + iter % 3;
+  h.next_count = counters + 3 * which + (iter + 1) % 3;
+  h.zero_count = counters + 3 * which + (iter + 2) % 3;
+  if constexpr (std::is_same<A, Pot64JumpArgs>::value || std::is_same<A, PotJumpArgs>::value) {
+    h.G_in = a.G_in + (size_t)start * pitch;
+    h.G_out = a.G_out + (size_t)start * pitch;
+  }
+  if constexpr (std::is_same<A, Pot64JumpArgs>::value)   // the tile kernel's working rows: one set per concurrent launch
     h.scratch = a.scratch + (size_t)which * pot64_scratch_workgroups() * 2 * 32 * (size_t)pitch;
   h.N = n;
   h.Npad = npad;
@@ -1174,11 +1198,20 @@ static A half_args(const A& a, int64_t start, int64_t n, int64_t npad, size_t pi
   return h;
 }
 
-static int ensure_second_stream(mjhmc_sampler* s) {
-  if (s->stream2) return 0;
-  HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+// The parts of a dense batch on their streams (part 0: the sampler's own)
+static int ensure_part_streams(mjhmc_sampler* s, int n_parts) {
+  if (!s->ev_fork) {
+    HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  }
+  while ((int)s->part_streams.size() < n_parts - 1) {
+    hipStream_t q;
+    hipEvent_t e;
+    HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    s->part_streams.push_back(q);
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->part_events.push_back(e);
+  }
   return 0;
 }
 
@@ -1193,6 +1226,9 @@ static int split_state_copy(mjhmc_sampler* s, bool restore) {
     if (restore) HIPCHK(hipMemcpyAsync(live[i], s->ick[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
     else HIPCHK(hipMemcpyAsync(s->ick[i], live[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
   }
+  // (Hspec follows scur and an attempt only writes the other parity, so the call's starting values survive a failed
+  // attempt like H_flf's do -- but the halves may have run several iterations: both parities are overwritten)
+  if (restore) TRY(drop_spec(s));
   return 0;
 }
 
@@ -1251,17 +1287,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     const int64_t nslots = s->Npad >> (6 - s->sh.logG);
     if (nslots >= 8 * 4096) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part
     if (split_at <= 0 || split_at * (n_parts - 1) >= s->N) split_at = 0;
-    if (split_at) {
-      TRY(ensure_second_stream(s));
-      while ((int)s->part_streams.size() < n_parts - 1) {
-        hipStream_t q;
-        hipEvent_t e;
-        HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        s->part_streams.push_back(q);
-        s->part_events.push_back(e);
-      }
-    }
+    if (split_at) TRY(ensure_part_streams(s, n_parts));
   }
   auto launch = [&](const Launch& l, long long* stats) -> int {
     JumpArgs<T> a;
@@ -1479,22 +1505,46 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)2 * n_iter * sizeof(int), s->stream));
   }
 
-  // big dense batches: two halves on two streams (half_args)
-  int64_t split_at = 0;
+  // dense batches: free-running parts on their own streams (part_args; the story is above iterate_fused_t)
+  int n_parts = 1;
+  int64_t part_len = 0;   // particles per part (the last part takes the rest)
   // (The elementwise compacted passes -- C4 -- were tried as 2 / 3 / 4 free-running parts the same way: 0.2727 ms per
   // iteration unsplit, 0.2729 / 0.2744 / 0.310 split: their kernels leave room for each other already.)
-  if (allow_split && s->en->is_dense() && !replay_normal && !replay_exp && !replay_unif &&
-      ring_slot0 < 0 && !test_env("MJHMC_NO_SPLIT")) {
+  if (s->en->is_dense()) {
     const int cus = std::max(1, s->ctx->prop.multiProcessorCount);  // of THIS sampler's device
     const int ppt = s->en->is_sic() ? sic_particles_per_tile(s->en->sic_P) : 32;
-    const int64_t unit = 64 * (int64_t)ppt;  // whole tiles and whole 64-particle row groups on both sides
-    if ((s->N + ppt - 1) / ppt >= 2 * (int64_t)cus) split_at = (s->Npad / 2) / unit * unit;
-    if (split_at <= 0 || split_at >= s->N) split_at = 0;
-    if (split_at) {
-      TRY(ensure_second_stream(s));
+    const int64_t unit = 64 * (int64_t)ppt;  // whole tiles and whole 64-particle row groups in every part
+    const int64_t ntiles = (s->N + ppt - 1) / ppt;
+    // A launch is a persistent grid of one workgroup per CU whose items (forward tiles + the inverse-L tiles of the R-movers)
+    // take one trajectory time each: alone it ends in a partial round, and at a few hundred tiles that round is most of
+    // the launch (C3 at 12 500 particles: 410 items = 1.6 rounds run as 2).  Two parts that never wait for each other fill
+    // each other's partial rounds; below ~3/4 of a round of tiles there is nothing to fill.
+    int want = (allow_split && !replay_normal && !replay_exp && !replay_unif && ring_slot0 < 0 && !test_env("MJHMC_NO_SPLIT") &&
+                4 * ntiles >= 3 * (int64_t)cus) ? 2 : 1;
+    if (want > 1)
+      if (const char* np = test_env("MJHMC_SPLIT_PARTS")) want = std::max(1, std::min(kMaxDenseParts, std::atoi(np)));
+    if (want > 1) {
+      part_len = (s->Npad / want) / unit * unit;
+      if (part_len > 0 && part_len * (want - 1) < s->N) n_parts = want;
+    }
+    if (n_parts > 1) {
+      TRY(ensure_part_streams(s, n_parts));
       if (n_iter > 1) TRY(split_state_copy(s, false));
     }
   }
+  // test build, MJHMC_NO_FSPEC=1: nothing is handed on from an F move to the next iteration -- every cold particle's
+  // inverse-L proposal is integrated, as the reference does (the A side of test_f_mover_shortcut_is_bit_identical)
+  void* spec_out_override = nullptr;
+  if (s->en->is_dense() && s->mode == MJHMC_MODE_MJHMC && test_env("MJHMC_NO_FSPEC")) {
+    if (!s->Hspec_dump) HIPCHK(hipMalloc(&s->Hspec_dump, (size_t)s->Npad * ssize(s)));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMemsetAsync(s->Hspec[i], 0xFF, (size_t)s->Npad * ssize(s), s->stream));
+    spec_out_override = s->Hspec_dump;
+  }
+  auto part_stream = [&](int k) { return k == 0 ? s->stream : s->part_streams[(size_t)k - 1]; };
+  auto part_start = [&](int k) { return (int64_t)k * part_len; };
+  auto part_count = [&](int k) { return k + 1 == n_parts ? s->N - part_start(k) : part_len; };
+  auto part_npad = [&](int k) { return k + 1 == n_parts ? s->Npad - part_start(k) : part_len; };
+  int* const dense_counters = s->cold_list ? s->cold_list + 2 * s->Npad : nullptr;
 
   std::vector<void*> xout(n_iter);
   void* xin = s->Xcur;
@@ -1532,16 +1582,17 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       if (std::sscanf(poison, "%d:%lld", &pit, &pp) == 2 && pit == i && pp >= 0 && pp < s->N) {
         static const double nan64 = __builtin_nan("");
         static const float nan32 = __builtin_nanf("");
-        hipStream_t pst = (split_at && pp >= split_at) ? s->stream2 : s->stream;
-        if (split_at && i == 0 && pst == s->stream2) HIPCHK(hipStreamSynchronize(s->stream));  // (the fork below comes later)
+        const int pk = n_parts > 1 ? (int)std::min<int64_t>(pp / part_len, n_parts - 1) : 0;
+        hipStream_t pst = part_stream(pk);
+        if (pk > 0 && i == 0) HIPCHK(hipStreamSynchronize(s->stream));  // (the fork below comes later)
         HIPCHK(hipMemcpyAsync((char*)s->EV[si] + (size_t)pp * ssize(s), sizeof(T) == 8 ? (const void*)&nan64 : (const void*)&nan32,
                               ssize(s), hipMemcpyHostToDevice, pst));
       }
     }
 #endif  // MJHMC_TEST_HOOKS
-    if (split_at && i == 0) {  // the second stream starts from everything the first has been given so far
+    if (n_parts > 1 && i == 0) {  // the other parts' streams start from everything the first has been given so far
       HIPCHK(hipEventRecord(s->ev_fork, s->stream));
-      HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+      for (int k = 1; k < n_parts; ++k) HIPCHK(hipStreamWaitEvent(part_stream(k), s->ev_fork, 0));
     }
     JumpArgs<T> a;
     a.X_in = (const T*)xin;
@@ -1601,8 +1652,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.Hwork = s->Hwork;
         pa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;          // iteration i reads list i & 1 ...
         pa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;    // ... and writes the next iteration's
-        pa.cold_count = s->cold_list + 2 * s->Npad + (i & 1);
-        pa.next_count = s->cold_list + 2 * s->Npad + ((i + 1) & 1);
+        pa.Hspec_in = (const float*)s->Hspec[si];
+        pa.Hspec_out = (float*)(spec_out_override ? spec_out_override : s->Hspec[si ^ 1]);
+        pa.rescan = spec_out_override ? 1 : 0;
         pa.EX_out = a.EX_out;
         pa.EV_out = a.EV_out;
         pa.Hflf_out = a.Hflf_out;
@@ -1629,20 +1681,11 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.r_mix = a.r_mix;
         pa.p_r = a.p_r;
         pa.key = a.key;
-        if (split_at > 0) {
-          PotJumpArgs h[2];
-          h[0] = half_args<PotJumpArgs, float>(pa, 0, split_at, split_at, (size_t)s->sh.pitch, 0);
-          h[0].G_in = pa.G_in;
-          h[0].G_out = pa.G_out;
-          h[0].ntiles = split_at / 32;
-          h[1] = half_args<PotJumpArgs, float>(pa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
-          h[1].G_in = pa.G_in + (size_t)split_at * s->sh.pitch;
-          h[1].G_out = pa.G_out + (size_t)split_at * s->sh.pitch;
-          h[1].ntiles = (s->Npad - split_at) / 32;
-          pot_launch_jump(h[0], s->en->pot_model(), s->stream);
-          pot_launch_jump(h[1], s->en->pot_model(), s->stream2);
-        } else {
-          pot_launch_jump(pa, s->en->pot_model(), s->stream);
+        for (int k = 0; k < n_parts; ++k) {
+          PotJumpArgs h = part_args<PotJumpArgs, float>(pa, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
+                                                        n_parts > 1 ? part_npad(k) : s->Npad, (size_t)s->sh.pitch, k, i, dense_counters);
+          h.ntiles = h.Npad / 32;
+          pot_launch_jump(h, s->en->pot_model(), part_stream(k));
         }
       } else {
         // the reference's arithmetic: float64 state rows streamed through the tile kernel's epilogue (dense_pot64.hip)
@@ -1659,8 +1702,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.Hwork = (double*)s->Hwork;
         pa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;          // iteration i reads list i & 1 ...
         pa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;    // ... and writes the next iteration's
-        pa.cold_count = s->cold_list + 2 * s->Npad + (i & 1);
-        pa.next_count = s->cold_list + 2 * s->Npad + ((i + 1) & 1);
+        pa.Hspec_in = (const double*)s->Hspec[si];
+        pa.Hspec_out = (double*)(spec_out_override ? spec_out_override : s->Hspec[si ^ 1]);
+        pa.rescan = spec_out_override ? 1 : 0;
         pa.EX_out = (double*)a.EX_out;
         pa.EV_out = (double*)a.EV_out;
         pa.Hflf_out = (double*)a.Hflf_out;
@@ -1688,20 +1732,11 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         pa.r_mix = std::sqrt(s->beta);
         pa.p_r = a.p_r;
         pa.key = a.key;
-        if (split_at > 0) {
-          Pot64JumpArgs h[2];
-          h[0] = half_args<Pot64JumpArgs, double>(pa, 0, split_at, split_at, (size_t)s->sh.pitch, 0);
-          h[0].G_in = pa.G_in;
-          h[0].G_out = pa.G_out;
-          h[0].ntiles = split_at / 32;
-          h[1] = half_args<Pot64JumpArgs, double>(pa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
-          h[1].G_in = pa.G_in + (size_t)split_at * s->sh.pitch;
-          h[1].G_out = pa.G_out + (size_t)split_at * s->sh.pitch;
-          h[1].ntiles = (s->Npad - split_at) / 32;
-          pot64_launch_jump(h[0], s->en->pot_model(), s->stream);
-          pot64_launch_jump(h[1], s->en->pot_model(), s->stream2);
-        } else {
-          pot64_launch_jump(pa, s->en->pot_model(), s->stream);
+        for (int k = 0; k < n_parts; ++k) {
+          Pot64JumpArgs h = part_args<Pot64JumpArgs, double>(pa, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
+                                                             n_parts > 1 ? part_npad(k) : s->Npad, (size_t)s->sh.pitch, k, i, dense_counters);
+          h.ntiles = h.Npad / 32;
+          pot64_launch_jump(h, s->en->pot_model(), part_stream(k));
         }
       }
     } else if (s->en->is_sic()) {
@@ -1717,8 +1752,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         sa.Hwork = s->Hwork;
         sa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;
         sa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;
-        sa.cold_count = s->cold_list + 2 * s->Npad + (i & 1);
-        sa.next_count = s->cold_list + 2 * s->Npad + ((i + 1) & 1);
+        sa.Hspec_in = (const float*)s->Hspec[si];
+        sa.Hspec_out = (float*)(spec_out_override ? spec_out_override : s->Hspec[si ^ 1]);
+        sa.rescan = spec_out_override ? 1 : 0;
         sa.EX_out = a.EX_out;
         sa.EV_out = a.EV_out;
         sa.Hflf_out = a.Hflf_out;
@@ -1745,16 +1781,11 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         sa.r_mix = a.r_mix;
         sa.p_r = a.p_r;
         sa.key = a.key;
-        if (split_at > 0) {
-          SicJumpArgs h[2];
-          h[0] = half_args<SicJumpArgs, __bf16>(sa, 0, split_at, split_at, (size_t)s->sh.pitch, 0);
-          h[0].ntiles = split_at / ppt;
-          h[1] = half_args<SicJumpArgs, __bf16>(sa, split_at, s->N - split_at, s->Npad - split_at, (size_t)s->sh.pitch, 1);
-          h[1].ntiles = (s->N - split_at + ppt - 1) / ppt;
-          sic_launch_jump(h[0], s->en->sic_model(), s->stream);
-          sic_launch_jump(h[1], s->en->sic_model(), s->stream2);
-        } else {
-          sic_launch_jump(sa, s->en->sic_model(), s->stream);
+        for (int k = 0; k < n_parts; ++k) {
+          SicJumpArgs h = part_args<SicJumpArgs, __bf16>(sa, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
+                                                         n_parts > 1 ? part_npad(k) : s->Npad, (size_t)s->sh.pitch, k, i, dense_counters);
+          h.ntiles = (h.N + ppt - 1) / ppt;
+          sic_launch_jump(h, s->en->sic_model(), part_stream(k));
         }
       }
     } else {
@@ -1827,9 +1858,11 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         launch_refresh<T>(ra, s->sh.E, s->N, s->stream);
       }
     }
-    if (split_at && i + 1 == n_iter) {  // the read-back follows both halves
-      HIPCHK(hipEventRecord(s->ev_join, s->stream2));
-      HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    if (n_parts > 1 && i + 1 == n_iter) {  // the read-back follows every part
+      for (int k = 1; k < n_parts; ++k) {
+        HIPCHK(hipEventRecord(s->part_events[(size_t)k - 1], part_stream(k)));
+        HIPCHK(hipStreamWaitEvent(s->stream, s->part_events[(size_t)k - 1], 0));
+      }
     }
     HIPCHK(hipGetLastError());
     xin = xo;
@@ -1839,8 +1872,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   std::vector<long long> hs((size_t)n_iter * 4);
   TRY(read_back_call(s, s->stats, hs.size() * sizeof(long long), &hc, hs.data()));
 
-  if (hc.failed && split_at && n_iter > 1) {
-    // a non-finite rate somewhere in the free-running halves: back to the state the call started from, and once more
+  if (hc.failed && n_parts > 1 && n_iter > 1) {
+    // a non-finite rate somewhere in the free-running parts: back to the state the call started from, and once more
     // on one stream -- that run stops at the failing iteration with the state, tallies and RNG position of a call that
     // was never split (nothing of this attempt has been committed: parities, Xcur and the tick are still the call's)
     TRY(split_state_copy(s, true));
@@ -1922,8 +1955,11 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   // multi-pass form (the same arithmetic, bit for bit) serves L = 0 and, in the test build, the A/B switch
   const bool pot64_fused = s->sh.wide && s->en->is_pot() && !s->en->pot_big() && !s->sh.round32 && s->L >= 1 &&
                            !test_env("MJHMC_POT64_MULTIPASS");
-  if (s->sh.wide && !pot64_fused)
-    return multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
+  if (s->sh.wide && !pot64_fused) {
+    const int rc = multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
+    if (rc == 0) TRY(drop_spec(s));   // (that path neither reads nor writes the F-movers' hand-over: nothing of it is valid afterwards)
+    return rc;
+  }
   return s->dtype == MJHMC_F64
              ? iterate_t<double>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done)
              : iterate_t<float>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
@@ -2018,11 +2054,13 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       if (s->sh.round32) TRY(round_rows32(s, dst));
       TRY(run_eval(s, s->Xcur, s->Gbuf[s->vcur], s->EX[s->scur], s->Vbuf[s->vcur], nullptr, s->EV[s->scur]));
       HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
+      TRY(drop_spec(s));
       HIPCHK(hipStreamSynchronize(s->stream));
       return 0;
     }
     case MJHMC_F_HFLF: {  // float64 (N); NaN marks a cold cache entry
       if (nbytes != (size_t)s->N * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected N float64");
+      TRY(drop_spec(s));
       if (s->dtype == MJHMC_F64) {
         HIPCHK(hipMemcpyAsync(s->Hflf[s->scur], host_src, nbytes, hipMemcpyHostToDevice, s->stream));
       } else {

@@ -66,47 +66,120 @@ __global__ __launch_bounds__(256, 1) void pot_eval_kernel(const PotEvalArgs a, c
 }
 
 // ---------------------------------------------------------------------------------------------------
-// cold-cache compaction.  A tile of 32 particles costs the same whether 1 or 32 of them need the
-// inverse-L trajectory, so the cold particles (5-60 % of the batch) are gathered into dense tiles
-// first: the F L F work stays proportional to the cold fraction, as in the reference (hmc_state.py:109-119).
+// The inverse-L proposal F L F of MarkovJumpHMC (markov_jump_hmc.py:360-367, hmc_state.py:109-119) on the matrix cores.
+//
+// WHICH particles integrate it.  The reference integrates F L F for every particle whose cache is cold -- the F- and
+// R-movers of the iteration before (markov_jump_hmc.py:409-411) -- and reads the result only through H().  For an
+// F-MOVER that trajectory is one this kernel has just run: the state after F is (X, -V), so F L F (X, -V) = F L (X, V),
+// and L (X, V) is the L proposal of the iteration in which the particle flipped -- the same start point, the same
+// stored dE/dX, the same operations in the same order: the same bits, and H() does not see the final F.  (The
+// reference's authors knew: `# self.state.cache_flf_state(f_idx, l_state.F())` stands commented out at
+// markov_jump_hmc.py:401.)  So the jump kernel hands an F-mover's H(L proposal) on in `Hspec` and the next iteration
+// uses it instead of integrating: only R-movers (a fresh momentum) are integrated.  The cache stays COLD as far as anyone
+// can see -- H_flf is NaN, cache_active False, the evaluation counters count the particle as the reference does
+// (stats[3]: all cold particles in its low half, what was actually integrated in its high half) -- and `Hspec` is dropped (NaN) by anything
+// that could make it stale: new hyper-parameters, a state write, reset_flf_cache, restore (api.hip: drop_spec).
+// tests/test_gpu_dense_parity.py::test_f_mover_shortcut_is_bit_identical runs both ways.
+//
+// WHEN.  A tile of 32 particles costs the same whether 1 or 32 of them need the trajectory, so the listed particles are
+// gathered into dense tiles; and those tiles are items of the SAME launch as the iteration's forward tiles (items
+// [0, nft) = inverse-L tiles of the list, [nft, nft + ntiles) = forward tiles): they run beside each other instead of
+// one kernel after the other -- a list of 20 tiles used to hold the chip for a whole trajectory time on 20 CUs, which
+// at N / 8 particles was a third of the iteration.  A listed particle's decision needs both of its trajectories, so the
+// jump kernel leaves it PENDING (its L proposal written as if taken, no bookkeeping) and pot_fix_kernel, a tile kernel
+// over the same list without any trajectory, decides it afterwards and puts the pre-move state back where the move
+// is not L.  Same device functions, same per-column reductions: a particle's results do not depend on which kernel
+// finished it.
+//
+// The list of the FIRST iteration of a mjhmc_iterate call comes from a scan (this kernel, once per call); every later
+// one is appended by the jump and fix kernels of the iteration before it (append_cold): no per-iteration memset, no
+// per-iteration list kernel -- a 4-byte memset behind a persistent grid waited for a workgroup to exit.  Counters
+// rotate over three slots: iteration i reads slot i % 3, appends to (i + 1) % 3 and clears (i + 2) % 3.
 // ---------------------------------------------------------------------------------------------------
-// The list of the FIRST iteration of a mjhmc_iterate call comes from a scan of the cache (this kernel, once per call);
-// every later one is written by the jump kernel of the iteration before it (append_cold): no per-iteration memset, no
-// per-iteration list kernel -- a 4-byte memset behind a persistent grid waited for a workgroup to exit (20 % of the
-// summed kernel time of a C3 profile was such queue waits).
-__global__ void pot_cold_list_kernel(const float* __restrict__ Hflf_in, int64_t N, int* __restrict__ list,
-                                     int* __restrict__ count, const Control* ctl) {
+__global__ void pot_cold_list_kernel(const float* __restrict__ Hflf_in, const float* __restrict__ Hspec_in, int64_t N,
+                                     int* __restrict__ list, int* __restrict__ count, const Control* ctl) {
   if (ctl->failed) return;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float hc = p < N ? Hflf_in[p] : 0.f;
-  append_cold(list, count, (p < N) && !(hc == hc), p);
+  const float hc = p < N ? Hflf_in[p] : 0.f, hs = p < N ? Hspec_in[p] : 0.f;
+  append_cold(list, count, (p < N) && !(hc == hc) && !(hs == hs), p);
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, 1) void pot_flf_kernel(const PotJumpArgs a, const PotModel mdl) {
-  __shared__ Shared<NB> sh;
-  if (a.ctl->failed) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  const int ncold = *a.cold_count;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold);  // the cold tally
-  if ((int64_t)blockIdx.x * kP >= ncold) return;  // nothing for this workgroup
-  AReg<NB> ar;
-  areg_load<NB>(mdl, w, c, h, ar);
-  stage_bias<NB>(mdl, sh);
-  for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
-    const int slot = tile * kP + c;
-    const int64_t p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
-    Tile<NB> x, v, g;
-    tile_load<NB>(a.X_in, p, w, h, x);
-    tile_load<NB>(a.V_in, p, w, h, v);
-    tile_load<NB>(a.G_in, p, w, h, g);
+// The successor's rows once the moves of a tile's columns stand in sh.move.  FIX = false (jump kernel): x, v, g hold the
+// end point of L.  FIX = true (pot_fix_kernel): columns that keep the end point are finished already (their rows hold
+// it); only the others are touched.
+template <int NB, bool REPLAY, int MODE, bool FIX, class SH>
+__device__ __forceinline__ void pot_finish(const PotJumpArgs& a, SH& sh, int64_t p, bool alive, int w, int c, int h,
+                                           Tile<NB>& x, Tile<NB>& v, Tile<NB>& g) {
+  const int mv = sh.move[c];
+  const int k = mv & 3;
+  bool refresh;  // this column's momentum is redrawn (HMCState.R)
+  bool touch = true;
+  if constexpr (MODE == kModeControl) {
+    if (!(k & 1)) {  // rejected: back to the pre-move state
+      tile_load<NB>(a.X_in, p, w, h, x);
+      tile_load<NB>(a.G_in, p, w, h, g);
+      tile_load<NB>(a.V_in, p, w, h, v);
+    } else {  // accepted L F: flip
 #pragma unroll
-    for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
-    float ex = 0.f;
-    pot_trajectory<NB>(mdl, ar, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &ex);
-    const float ev = pot_kinetic<NB>(sh, w, c, h, v);
-    if (w == 0 && h == 0) a.Hwork[p] = ex + ev;
-    __syncthreads();
+      for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
+    }
+    if (k & 2) {
+#pragma unroll
+      for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
+    }
+    refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
+  } else {
+    const bool keep_L = (k == 0);
+    if constexpr (FIX) touch = !keep_L;
+    if (!keep_L) {  // F / R keep the position (and its gradient)
+      tile_load<NB>(a.X_in, p, w, h, x);
+      tile_load<NB>(a.G_in, p, w, h, g);
+      tile_load<NB>(a.V_in, p, w, h, v);
+    }
+    if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
+#pragma unroll
+      for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
+    }
+    refresh = (k == 2);
+  }
+  const bool tile_refreshes = __ballot(refresh) != 0ull;
+  if constexpr (REPLAY) {
+    if (refresh) {  // HMCState.R (hmc_state.py:121-129) with the recorded normals
+      Tile<NB> z;
+      tile_load<NB>(a.noise, alive ? p : 0, w, h, z);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) v.b[r] = v.b[r] * a.r_keep + z.b[r] * a.r_mix;
+    }
+  } else {
+    // column by column (the set is the same in every wave: it comes from sh.move), the whole workgroup drawing
+    unsigned cols = (unsigned)(__ballot(refresh) & 0xFFFFFFFFull);
+    while (cols) {
+      const int c0 = __ffs((int)cols) - 1;
+      cols &= cols - 1;
+      const int64_t p0 = __shfl((long long)p, c0);
+      column_normals<NB, float>(a.key, (uint32_t)(a.first_pid + (p0 < a.N ? p0 : 0)), a.D, sh.zn);
+      __syncthreads();
+      if (c == c0) {
+        using V = typename VecN<NB>::type;
+        const float* zrow = sh.zn + 32 * NB * w;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const V z = *reinterpret_cast<const V*>(zrow + NB * acc_row(q, h));
+#pragma unroll
+          for (int r = 0; r < NB; ++r) v.b[r][q] = v.b[r][q] * a.r_keep + vget<NB>(z, r) * a.r_mix;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result
+    const float evr = pot_kinetic<NB>(sh, w, c, h, v);
+    if (refresh && w == 0 && h == 0) a.EV_out[p] = evr;
+  }
+  if (touch) {
+    tile_store<NB>(a.X_out, p, w, h, x);
+    tile_store<NB>(a.V_out, p, w, h, v);
+    tile_store<NB>(a.G_out, p, w, h, g);
   }
 }
 
@@ -121,134 +194,103 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
   __shared__ Shared<NB> sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  // the inverse-L pass of this iteration has consumed its list: its counter is free for the iteration after the next
-  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) *a.cold_count = 0;
+  // MJHMC: the inverse-L tiles of this iteration's list are the first items of the launch
+  const int ncold = MODE == kModeMJHMC ? *a.cold_count : 0;
+  const int64_t nft = (ncold + kP - 1) / kP;
+  if ((int64_t)blockIdx.x >= nft + a.ntiles) return;
+  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.zero_count = 0;   // the list two iterations back is consumed: its counter is free for the next iteration's appends
+    if (ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold << 32);   // integrated here: the high half of the cold tally
+  }
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
   stage_bias<NB>(mdl, sh);
-  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int64_t p = tile * kP + c;
+  for (int64_t item = blockIdx.x; item < nft + a.ntiles; item += gridDim.x) {
+    const bool inverse = item < nft;   // (uniform over the workgroup)
+    int64_t p;
+    if (inverse) {
+      const int64_t slot = item * kP + c;
+      p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
+    } else {
+      p = (item - nft) * kP + c;
+    }
     const bool alive = p < a.N;
-    const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
-    const float H0 = EX0 + EV0;
-    // H of the inverse-L proposal: cached, or integrated by pot_flf_kernel for the cold particles
-    float Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.f;
-    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
     Tile<NB> x, v, g;
     tile_load<NB>(a.X_in, p, w, h, x);
     tile_load<NB>(a.V_in, p, w, h, v);
     tile_load<NB>(a.G_in, p, w, h, g);
+    if (inverse) {
+#pragma unroll
+      for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
+    }
     float EXL = 0.f;
     pot_trajectory<NB>(mdl, ar, sh, w, c, h, lane, x, v, g, a.L, a.eps, a.chalf, &EXL);
     const float EVL = pot_kinetic<NB>(sh, w, c, h, v);
     const float HL = EXL + EVL;
+    if (inverse) {
+      if (w == 0 && h == 0) a.Hwork[p] = HL;
+      __syncthreads();
+      continue;
+    }
 
     // rates / acceptance, waiting times, first minimum: lanes 0..31 of wave 0, one particle each
     if (w == 0 && h == 0) {
       const uint32_t pid = (uint32_t)(a.first_pid + (alive ? p : 0));
+      const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const float H0 = EX0 + EV0;
+      // H of the inverse-L proposal: cached; or the L proposal of the iteration in which the particle flipped; or being
+      // integrated by an inverse-L item of this very launch -- then the particle is left pending for pot_fix_kernel
+      float Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.f;
+      const bool cold = !(Hflf == Hflf);
+      bool pending = false;
+      if (cold) {
+        Hflf = a.Hspec_in[p];
+        pending = !(Hflf == Hflf);
+      }
       double best = 0.0;
       bool bad = false, gate = false;
-      int k;
-      if constexpr (MODE == kModeMJHMC)
-        k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
-      else if constexpr (MODE == kModeCT)
-        k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
-      else
-        k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, alive ? p : 0, a.N, a.runif, a.key, gate);
-      any_bad |= (bad && alive);
-      if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k != 0, p);
+      int k = 0;
+      if (!pending) {
+        if constexpr (MODE == kModeMJHMC)
+          k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
+        else if constexpr (MODE == kModeCT)
+          k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, alive ? p : 0, a.N, a.rexp, a.key, best, bad);
+        else
+          k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, alive ? p : 0, a.N, a.runif, a.key, gate);
+        any_bad |= (bad && alive);
+        // every move but L clears the cache; of those only the R-movers need their inverse-L proposal integrated
+        if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k == 2, p);
+        a.dwell[p] = best;
+        a.dwell_ring[p] = best;
+        a.trans[p] = (uint8_t)k;
+      }
       sh.move[c] = k | (gate ? 4 : 0);
-      a.dwell[p] = best;
-      a.dwell_ring[p] = best;
-      a.trans[p] = (uint8_t)k;
       if (alive) {
         if constexpr (MODE == kModeControl) {  // l_count, f_count, R applied, fl_count (markov_jump_hmc.py:143-148)
           n0 += (k == 3);
           n1 += (k == 2);
           n2 += gate ? 1u : 0u;
           n3 += (k == 1);
-        } else {
+        } else if (!pending) {
           n0 += (k == 0);
           n1 += (k == 1);
           n2 += (k == 2);
         }
+        if constexpr (MODE == kModeMJHMC) n3 += cold;   // the reference integrates F L F for every one of these
       }
       // scalars of the successors that keep or take whole states; a refreshed kinetic energy is filled in below
       const bool took_L = MODE == kModeControl ? (k & 1) : (k == 0);
       a.EX_out[p] = took_L ? EXL : EX0;
       a.EV_out[p] = took_L ? EVL : EV0;
-      a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nanf("");
+      if (!pending) {
+        a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nanf("");
+        if constexpr (MODE == kModeMJHMC) a.Hspec_out[p] = (k == 1) ? HL : __builtin_nanf("");
+      }
     }
     __syncthreads();
-    const int mv = sh.move[c];
-    const int k = mv & 3;
-    bool refresh;  // this column's momentum is redrawn (HMCState.R)
-    if constexpr (MODE == kModeControl) {
-      if (!(k & 1)) {  // rejected: back to the pre-move state
-        tile_load<NB>(a.X_in, p, w, h, x);
-        tile_load<NB>(a.G_in, p, w, h, g);
-        tile_load<NB>(a.V_in, p, w, h, v);
-      } else {  // accepted L F: flip
-#pragma unroll
-        for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
-      }
-      if (k & 2) {
-#pragma unroll
-        for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
-      }
-      refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
-    } else {
-      const bool keep_L = (k == 0);
-      if (!keep_L) {  // F / R keep the position (and its gradient)
-        tile_load<NB>(a.X_in, p, w, h, x);
-        tile_load<NB>(a.G_in, p, w, h, g);
-        tile_load<NB>(a.V_in, p, w, h, v);
-      }
-      if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
-#pragma unroll
-        for (int r = 0; r < NB; ++r) v.b[r] = -v.b[r];
-      }
-      refresh = (k == 2);
-    }
-    const bool tile_refreshes = __ballot(refresh) != 0ull;
-    if constexpr (REPLAY) {
-      if (refresh) {  // HMCState.R (hmc_state.py:121-129) with the recorded normals
-        Tile<NB> z;
-        tile_load<NB>(a.noise, alive ? p : 0, w, h, z);
-#pragma unroll
-        for (int r = 0; r < NB; ++r) v.b[r] = v.b[r] * a.r_keep + z.b[r] * a.r_mix;
-      }
-    } else {
-      // column by column (the set is the same in every wave: it comes from sh.move), the whole workgroup drawing
-      unsigned cols = (unsigned)(__ballot(refresh) & 0xFFFFFFFFull);
-      while (cols) {
-        const int c0 = __ffs((int)cols) - 1;
-        cols &= cols - 1;
-        const int64_t p0 = tile * kP + c0;
-        column_normals<NB, float>(a.key, (uint32_t)(a.first_pid + (p0 < a.N ? p0 : 0)), a.D, sh.zn);
-        __syncthreads();
-        if (c == c0) {
-          using V = typename VecN<NB>::type;
-          const float* zrow = sh.zn + 32 * NB * w;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const V z = *reinterpret_cast<const V*>(zrow + NB * acc_row(q, h));
-#pragma unroll
-            for (int r = 0; r < NB; ++r) v.b[r][q] = v.b[r][q] * a.r_keep + vget<NB>(z, r) * a.r_mix;
-          }
-        }
-        __syncthreads();
-      }
-    }
-    if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result
-      const float evr = pot_kinetic<NB>(sh, w, c, h, v);
-      if (refresh && w == 0 && h == 0) a.EV_out[p] = evr;
-    }
-    tile_store<NB>(a.X_out, p, w, h, x);
-    tile_store<NB>(a.V_out, p, w, h, v);
-    tile_store<NB>(a.G_out, p, w, h, g);
+    pot_finish<NB, REPLAY, MODE, false>(a, sh, p, alive, w, c, h, x, v, g);
     __syncthreads();
   }
   if (any_bad) {
@@ -264,6 +306,71 @@ __global__ __launch_bounds__(256, 1) void pot_jump_kernel(const PotJumpArgs a, c
   if (n3) atomicAdd(&tally[3], n3);
   __syncthreads();
   if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
+// The particles the jump kernel left pending (this iteration's list): both trajectories are done now -- H of the
+// inverse-L proposal in Hwork, the L proposal in the output rows with its energies in EX_out / EV_out -- so decide, and
+// where the move is not L put the pre-move position and dE/dX back and flip / redraw the momentum.
+template <int NB, bool REPLAY>
+__global__ __launch_bounds__(256) void pot_fix_kernel(const PotJumpArgs a) {
+  __shared__ FinishShared<NB> sh;
+  if (a.ctl->failed) return;
+  const int ncold = *a.cold_count;
+  if ((int64_t)blockIdx.x * kP >= ncold) return;
+  const int w = threadIdx.x >> 6, c = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
+  unsigned n0 = 0, n1 = 0, n2 = 0;
+  bool any_bad = false;
+  for (int64_t tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
+    const int64_t slot = tile * kP + c;
+    const bool valid = slot < ncold;    // the last tile repeats an entry: those columns do nothing
+    const int64_t p = a.cold_list[valid ? slot : ncold - 1];
+    if (w == 0 && h == 0) {
+      const uint32_t pid = (uint32_t)(a.first_pid + p);
+      const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const float H0 = EX0 + EV0;
+      const float HL = a.EX_out[p] + a.EV_out[p];
+      double best = 0.0;
+      bool bad = false;
+      const int k = dense_decide<REPLAY>(H0, HL, a.Hwork[p], a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
+      sh.move[c] = valid ? k : 0;
+      if (valid) {
+        any_bad |= bad;
+        append_cold(a.next_list, a.next_count, k == 2, p);
+        a.dwell[p] = best;
+        a.dwell_ring[p] = best;
+        a.trans[p] = (uint8_t)k;
+        n0 += (k == 0);
+        n1 += (k == 1);
+        n2 += (k == 2);
+        if (k != 0) {
+          a.EX_out[p] = EX0;
+          a.EV_out[p] = EV0;   // (an R-mover's: filled in by pot_finish)
+        }
+        a.Hflf_out[p] = k == 0 ? H0 : __builtin_nanf("");
+        a.Hspec_out[p] = k == 1 ? HL : __builtin_nanf("");
+      }
+    }
+    __syncthreads();
+    Tile<NB> x, v, g;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v.b[r][q] = 0.f;
+    pot_finish<NB, REPLAY, kModeMJHMC, true>(a, sh, p, true, w, c, h, x, v, g);
+    __syncthreads();
+  }
+  if (any_bad) {
+    a.ctl->failed = 1;
+    a.ctl->failed_iter = a.iter;
+  }
+  __shared__ unsigned tally[3];
+  if (threadIdx.x < 3) tally[threadIdx.x] = 0;
+  __syncthreads();
+  if (n0) atomicAdd(&tally[0], n0);
+  if (n1) atomicAdd(&tally[1], n1);
+  if (n2) atomicAdd(&tally[2], n2);
+  __syncthreads();
+  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -410,19 +517,23 @@ static void launch_jump_mode(const PotJumpArgs& a, const PotModel& mdl, unsigned
 
 template <int NB>
 static void launch_jump_nb(const PotJumpArgs& a, const PotModel& mdl, hipStream_t st) {
-  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus());
+  const int cus = resident_cus();
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
-    if (a.iter == 0) {  // first iteration of a call: both counters cleared (they are adjacent), the list from a scan
-      (void)hipMemsetAsync(a.cold_count < a.next_count ? a.cold_count : a.next_count, 0, 2 * sizeof(int), st);
-      hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.N,
-                         a.cold_list, a.cold_count, (const Control*)a.ctl);
+    if (a.iter == 0 || a.rescan) {  // first iteration of a call: the three counters cleared (they are adjacent), the list from a scan
+      (void)hipMemsetAsync(std::min(a.cold_count, std::min(a.next_count, a.zero_count)), 0, 3 * sizeof(int), st);
+      hipLaunchKernelGGL(pot_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hspec_in,
+                         a.N, a.cold_list, a.cold_count, (const Control*)a.ctl);
     }
-    hipLaunchKernelGGL(pot_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
+    // forward tiles + at most as many inverse-L tiles (workgroups without an item leave at once)
+    const unsigned grid = (unsigned)std::min<int64_t>(2 * a.ntiles, cus);
     launch_jump_mode<NB, kModeMJHMC>(a, mdl, grid, st);
-  } else if (a.mode == kModeCT) {
-    launch_jump_mode<NB, kModeCT>(a, mdl, grid, st);
+    const unsigned fgrid = (unsigned)std::min<int64_t>(a.ntiles, 4 * cus);
+    if (a.rexp && a.noise) hipLaunchKernelGGL((pot_fix_kernel<NB, true>), dim3(fgrid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pot_fix_kernel<NB, false>), dim3(fgrid), dim3(256), 0, st, a);
   } else {
-    launch_jump_mode<NB, kModeControl>(a, mdl, grid, st);
+    const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, cus);
+    if (a.mode == kModeCT) launch_jump_mode<NB, kModeCT>(a, mdl, grid, st);
+    else launch_jump_mode<NB, kModeControl>(a, mdl, grid, st);
   }
 }
 

@@ -30,11 +30,15 @@ struct PotJumpArgs {
   const float* EX_in;
   const float* EV_in;
   const float* Hflf_in;
-  float* Hwork;        // [Npad] H of the inverse-L proposal for this attempt (cached or freshly integrated)
-  int* cold_list;      // [Npad] compacted indices of the cold particles
+  float* Hwork;        // [Npad] H of the inverse-L proposal, where this iteration integrates it (the listed particles)
+  int* cold_list;      // [Npad] compacted indices of the particles whose inverse-L proposal must be integrated
   int* cold_count;
-  int* next_list;       // the NEXT iteration's cold list and counter, filled by this iteration's jump kernel
+  int* next_list;       // the NEXT iteration's list and counter, filled by this iteration's jump and fix kernels
   int* next_count;
+  int* zero_count;      // the counter of the list two iterations back (consumed): cleared by the jump kernel for its next use
+  int rescan;           // host side: build this iteration's list by a scan even if it is not the call's first (test build, MJHMC_NO_FSPEC)
+  const float* Hspec_in;   // H of the L proposal of a particle that then moved by F, NaN otherwise (see dense_pot.hip: F-movers)
+  float* Hspec_out;
   float* EX_out;
   float* EV_out;
   float* Hflf_out;
@@ -68,8 +72,12 @@ struct Pot64JumpArgs {
   double* Hwork;
   int* cold_list;
   int* cold_count;
-  int* next_list;       // the NEXT iteration's cold list and counter, filled by this iteration's jump kernel
+  int* next_list;       // the NEXT iteration's list and counter, filled by this iteration's jump and fix kernels
   int* next_count;
+  int* zero_count;
+  int rescan;
+  const double* Hspec_in;
+  double* Hspec_out;
   double* EX_out;
   double* EV_out;
   double* Hflf_out;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void wk_store(const Work<NB>& k, unsigned area, int q
   }
 }
 
-constexpr int kXWork = 0, kXRows = 1, kXNone = 2;  // where a drift's X goes: the working copy, the output rows, nowhere
+constexpr int kXWork = 0, kXRows = 1;  // where a drift's X goes: the working copy, the rows xout
 
 // the wave's momentum elements, float64, in registers for the whole trajectory (accumulator layout: 2 x 16 NB registers)
 template <int NB>
@@ -174,16 +174,16 @@ struct VTile {
 // One kick / drift pass over this wave's elements of the tile.  The momentum stays in registers; the position is
 // streamed through registers in four chunks of four register indices (double buffered: chunk n + 1 is in flight while
 // chunk n is worked on).
-//   NKICK = 1: v = [-]V_in + c g                    (the first step of a trajectory; NEG: the F of F L F)
+//   NKICK = 1: v = [-]V_in + c g                    (the first step of a trajectory; neg: the F of F L F)
 //   NKICK = 2: v = (v + c g) + c g                  (closing half kick of a step, opening one of the next)
 //   x = X + eps v ;  store x ;  float32(x) -> the X image of GEMM 1
 // FIRST: X, V come from the particle rows (the trajectory's first pass), else X from the working copy.  X goes to XDST
 // (the last drift's X is the end point: nothing reads it again but the caller).
 // Every product is rounded before its sum (the library is built with -ffp-contract=off): NumPy's V += c * g.
-template <int NB, int NKICK, bool NEG, bool FIRST, int XDST>
+template <int NB, int NKICK, bool FIRST, int XDST>
 __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double* xin, const double* vin, double* xout,
                                                 const Tile<NB>& g, VTile<NB>& v, double c, double eps, PubWave<NB>& pub,
-                                                int lane) {
+                                                int lane, bool neg = false) {
   using DV = typename DVecN<NB>::type;
   DV xa[4], xb[4], va[4], vb[4];   // (va, vb: the first pass only)
   auto load4 = [&](int q4, DV(&x)[4], DV(&vv)[4]) {
@@ -208,7 +208,7 @@ __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double
         double vv;
         if constexpr (FIRST) {
           vv = dget<NB>(vin4[qq], r);
-          if constexpr (NEG) vv = -vv;
+          vv = neg ? -vv : vv;   // (uniform over the workgroup: an inverse-L item of the jump launch)
         } else {
           vv = v.b[r][q];
         }
@@ -274,8 +274,8 @@ __device__ __forceinline__ double closing_kick(const Tile<NB>& g, VTile<NB>& v, 
 
 // sum over the tile's 4 waves x 2 lane halves of a per-lane partial; every lane of column c gets the total.
 // One barrier pair.
-template <int NB>
-__device__ __forceinline__ double column_sum(Shared64<NB>& sh, int w, int c, int h, double part) {
+template <int NB, class SH>
+__device__ __forceinline__ double column_sum(SH& sh, int w, int c, int h, double part) {
   const double both = swap32_sum(part);
   if (h == 0) sh.red64[w][c] = both;
   __syncthreads();
@@ -285,24 +285,24 @@ __device__ __forceinline__ double column_sum(Shared64<NB>& sh, int w, int c, int
 }
 
 // L >= 1 leapfrog steps (hmc_state.py:86-100) from the rows (xin, vin) and the stored dE/dX in g.  On return the end
-// point's position is in the rows xout (XLAST = kXRows; kXNone: not wanted), its momentum in v, g holds its dE/dX (float32), *ex its
+// point's position is in the rows xout (XLAST = kXRows; kXNone: not wanted; neg: start from -V, the F of F L F), its momentum in v, g holds its dE/dX (float32), *ex its
 // energy (float32, from the last gradient's u), and the return value is its kinetic energy sum(V^2) / 2 (all lanes of
 // column c).
-template <int NB, bool NEG, int XLAST>
+template <int NB, int XLAST>
 __device__ __forceinline__ double pot64_trajectory(const PotModel& mdl, AReg<NB>& ar, Shared64<NB>& sh, int w, int c, int h,
                                                    int lane, const Work<NB>& wk, const double* xin, const double* vin,
                                                    double* xout, Tile<NB>& g, VTile<NB>& v, int L, double eps, double chalf,
-                                                   float* ex) {
+                                                   float* ex, bool neg) {
   PubWave<NB>& pub = sh.s.pub[0][w];
-  if (L == 1) kick_drift_pass<NB, 1, NEG, true, XLAST>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane);
-  else kick_drift_pass<NB, 1, NEG, true, kXWork>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane);
+  if (L == 1) kick_drift_pass<NB, 1, true, XLAST>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane, neg);
+  else kick_drift_pass<NB, 1, true, kXWork>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane, neg);
   for (int s = 0; s < L; ++s) {
     [[maybe_unused]] const int stamp_slot = s;
     POT_STAMP(0);
     pot_gradient_published<NB>(mdl, ar, sh.s, w, c, h, lane, g, s == L - 1, ex, s);
     POT_STAMP(6);
-    if (s < L - 2) kick_drift_pass<NB, 2, false, false, kXWork>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
-    else if (s == L - 2) kick_drift_pass<NB, 2, false, false, XLAST>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
+    if (s < L - 2) kick_drift_pass<NB, 2, false, kXWork>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
+    else if (s == L - 2) kick_drift_pass<NB, 2, false, XLAST>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
     POT_STAMP(7);
   }
   const double part = closing_kick<NB>(g, v, chalf);
@@ -310,40 +310,179 @@ __device__ __forceinline__ double pot64_trajectory(const PotModel& mdl, AReg<NB>
 }
 
 // ---------------------------------------------------------------------------------------------------
-// inverse-L pass of the cold-cache particles, compacted into dense tiles (dense_pot.hip: pot_cold_list_kernel's twin)
+// The inverse-L proposal: which particles integrate it (not the F-movers), its tiles as items of the jump launch, the
+// pending particles and the fix kernel -- dense_pot.hip has the story; this is the float64-state twin.
 // ---------------------------------------------------------------------------------------------------
-__global__ void pot64_cold_list_kernel(const double* __restrict__ Hflf_in, int64_t N, int* __restrict__ list,
-                                       int* __restrict__ count, const Control* ctl) {
+__global__ void pot64_cold_list_kernel(const double* __restrict__ Hflf_in, const double* __restrict__ Hspec_in, int64_t N,
+                                       int* __restrict__ list, int* __restrict__ count, const Control* ctl) {
   if (ctl->failed) return;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const double hc = p < N ? Hflf_in[p] : 0.0;
-  append_cold(list, count, (p < N) && !(hc == hc), p);
+  const double hc = p < N ? Hflf_in[p] : 0.0, hs = p < N ? Hspec_in[p] : 0.0;
+  append_cold(list, count, (p < N) && !(hc == hc) && !(hs == hs), p);
 }
 
+// what the kernels that only FINISH a move need of Shared64 (pot64_fix_kernel)
 template <int NB>
-__global__ __launch_bounds__(256, 1) void pot64_flf_kernel(const Pot64JumpArgs a, const PotModel mdl) {
-  __shared__ Shared64<NB> sh;
-  if (a.ctl->failed) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  const int ncold = *a.cold_count;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold);  // the cold tally
-  if ((int64_t)blockIdx.x * kP >= ncold) return;  // nothing for this workgroup
-  AReg<NB> ar;
-  areg_load<NB>(mdl, w, c, h, ar);
-  stage_bias<NB>(mdl, sh.s);
-  const Work<NB> wk = work_of<NB>(a.scratch, blockIdx.x, w, lane);
-  for (int tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
-    const int slot = tile * kP + c;
-    const int64_t p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
-    Tile<NB> g;
-    VTile<NB> v;
-    tile_load_narrow<NB>(lane_row<NB>(a.G_in, p, w, h), g);
-    float ex = 0.f;
-    const double ev = pot64_trajectory<NB, true, kXNone>(mdl, ar, sh, w, c, h, lane, wk, lane_row<NB>(a.X_in, p, w, h),
-                                                 lane_row<NB>(a.V_in, p, w, h), nullptr, g, v, a.L, a.eps, a.chalf, &ex);
-    if (w == 0 && h == 0) a.Hwork[p] = (double)ex + ev;
-    __syncthreads();
+struct Finish64Shared {
+  struct {
+    int move[kP];
+  } s;
+  double red64[4][kP];
+  double zn[128 * NB];
+};
+
+// The successor's rows once the moves of a tile's columns stand in sh.s.move.  FIX = false (jump kernel): the end point's
+// position is in the output rows, its momentum in v, its dE/dX in g.  FIX = true (pot64_fix_kernel): columns that keep the
+// end point are finished already (v, g unused); only the others are touched.  roff: this lane's elements of its column's row.
+template <int NB, bool REPLAY, int MODE, bool FIX, class SH>
+__device__ __forceinline__ void pot64_finish(const Pot64JumpArgs& a, SH& sh, int64_t p, bool alive, size_t roff, int w, int c,
+                                             int h, const VTile<NB>& v, const Tile<NB>& g) {
+  using DV = typename DVecN<NB>::type;
+  const double* xin = a.X_in + roff;
+  const double* vin = a.V_in + roff;
+  const double* gin = a.G_in + roff;
+  double* xo = a.X_out + roff;
+  double* vo = a.V_out + roff;
+  double* go = a.G_out + roff;
+  const int mv = sh.s.move[c];
+  const int k = mv & 3;
+  bool take, flip, refresh;  // keep the end point of L; negate the successor's momentum; redraw it (HMCState.R)
+  if constexpr (MODE == kModeControl) {
+    const bool accept = k & 1, fl = k & 2;
+    take = accept;
+    flip = accept != fl;      // accepted: L F, then possibly F again; rejected: possibly F (markov_jump_hmc.py:116-141)
+    refresh = (mv & 4) != 0;  // batch-wide (:138-141)
+  } else {
+    take = k == 0;
+    flip = (MODE == kModeCT && k == 0) || k == 1;  // CT's FL move ends with a flip (:258,278); F flips
+    refresh = k == 2;
   }
+  // the successor's rows.  A kept end point: position already in the output rows, momentum from the registers
+  // (negated where the move ends with a flip), dE/dX from the accumulator; everything else: the pre-move position and
+  // dE/dX, and in the second loop its momentum, flipped / refreshed
+  const bool tile_refreshes = __ballot(refresh) != 0ull;
+  if (!FIX || !take) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      DV gg;
+      if (take) {
+        if constexpr (!FIX) {
+          DV vv;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+            dset<NB>(vv, r, flip ? -v.b[r][q] : v.b[r][q]);
+            dset<NB>(gg, r, (double)g.b[r][q]);
+          }
+          dv_store<NB>(vo, q, vv);
+        }
+      } else {
+        gg = dv_load<NB>(gin, q);
+        dv_store<NB>(xo, q, dv_load<NB>(xin, q));
+      }
+      dv_store<NB>(go, q, gg);
+    }
+  }
+  double s2 = 0.0;
+  if (!take || (REPLAY && refresh)) {
+    const double* vsrc = take ? (const double*)vo : vin;   // (a kept end point's momentum is flipped already)
+    const bool fl2 = flip && !take;
+    const double* nrow = REPLAY ? lane_row<NB>(a.noise, alive ? p : 0, w, h) : nullptr;
+#pragma unroll 1
+    for (int q = 0; q < 16; ++q) {
+      DV vv = dv_load<NB>(vsrc, q);
+      if (fl2) vv = -vv;
+      if constexpr (REPLAY) {
+        if (refresh) {  // HMCState.R (hmc_state.py:121-129) with the recorded normals
+          const DV z = dv_load<NB>(nrow, q);
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+            const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
+            dset<NB>(vv, r, t);
+            s2 = s2 + t * t;
+          }
+        }
+      }
+      dv_store<NB>(vo, q, vv);
+    }
+  }
+  if constexpr (!REPLAY) {
+    // HMCState.R, column by column (the set is the same in every wave: it comes from sh.move), the whole workgroup
+    // drawing the column's normals (column_normals); the column's momentum is in the output rows by now
+    unsigned cols = (unsigned)(__ballot(refresh) & 0xFFFFFFFFull);
+    while (cols) {
+      const int c0 = __ffs((int)cols) - 1;
+      cols &= cols - 1;
+      const int64_t p0 = __shfl((long long)p, c0);
+      column_normals<NB, double>(a.key, (uint32_t)(a.first_pid + (p0 < a.N ? p0 : 0)), a.D, sh.zn);
+      __syncthreads();
+      if (c == c0) {
+        const double* zrow = sh.zn + 32 * NB * w + 4 * NB * h;
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) {
+          DV vv = dv_load<NB>(vo, q);
+          const DV z = *reinterpret_cast<const DV*>(zrow + q_off<NB>(q));
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+            const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
+            dset<NB>(vv, r, t);
+            s2 = s2 + t * t;
+          }
+          dv_store<NB>(vo, q, vv);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result
+    const double evr = column_sum<NB>(sh, w, c, h, s2) / 2.0;
+    if (refresh && w == 0 && h == 0) a.EV_out[p] = evr;
+  }
+}
+
+// rates / acceptance, waiting times, first minimum of ONE particle by one lane, with the device functions of the
+// elementwise kernels in their one-lane-per-particle forms (as hk_decide of the multi-pass path)
+template <bool REPLAY, int MODE>
+__device__ __forceinline__ int pot64_decide(const Pot64JumpArgs& a, double H0, double HL, double Hflf, int64_t pp, uint32_t pid,
+                                            double& best, bool& bad, bool& gate) {
+  JumpArgs<double> ja;
+  ja.p_r = a.p_r;
+  ja.p_flip = a.p_flip;
+  ja.rexp = a.rexp;
+  ja.runif = a.runif;
+  ja.N = a.N;
+  LaneMap m;
+  m.j = 0;
+  m.G = 1;
+  m.D = 1;
+  m.CH = 1;
+  m.lane0 = 0;
+  m.wpp = 0;
+  int k = 0;
+  if constexpr (MODE == kModeMJHMC) {
+    decide<double, REPLAY>(ja, a.key, m, H0, HL, Hflf, pp, pid, k, best, bad);
+  } else if constexpr (MODE == kModeCT) {
+    decide_ct<double, REPLAY>(ja, a.key, m, H0, HL, pp, pid, k, best, bad);
+  } else {
+    double uacc, uflip, ugate;
+    if constexpr (REPLAY) {
+      uacc = a.runif[pp];
+      uflip = a.runif[a.N + pp];
+      ugate = a.runif[2 * a.N];
+    } else {
+      const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
+      const u32x4 f = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+      const u32x4 gq = philox4x32_10(0xFFFFFFFFu, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
+      uacc = u53(q.w2, q.w3);
+      uflip = u53(f.w0, f.w1);
+      ugate = u53(gq.w2, gq.w3);
+    }
+    const double dH = H0 - HL;
+    const bool accept = !(dH < 0.0) || (uacc < exp(dH));
+    const bool flip = uflip < a.p_flip;
+    gate = ugate < a.p_r;
+    k = (accept ? 1 : 0) | (flip ? 2 : 0);
+  }
+  return k;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -353,202 +492,106 @@ template <int NB, bool REPLAY, int MODE>
 __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs a, const PotModel mdl) {
   __shared__ Shared64<NB> sh;
   if (a.ctl->failed) return;
-  using DV = typename DVecN<NB>::type;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  // the inverse-L pass of this iteration has consumed its list: its counter is free for the iteration after the next
-  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) *a.cold_count = 0;
+  // MJHMC: the inverse-L tiles of this iteration's list are the first items of the launch
+  const int ncold = MODE == kModeMJHMC ? *a.cold_count : 0;
+  const int64_t nft = (ncold + kP - 1) / kP;
+  if ((int64_t)blockIdx.x >= nft + a.ntiles) return;
+  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.zero_count = 0;   // the list two iterations back is consumed: its counter is free for the next iteration's appends
+    if (ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold << 32);   // integrated here: the high half of the cold tally
+  }
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
   stage_bias<NB>(mdl, sh.s);
   const Work<NB> wk = work_of<NB>(a.scratch, blockIdx.x, w, lane);
-  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int64_t p = tile * kP + c;
+  for (int64_t item = blockIdx.x; item < nft + a.ntiles; item += gridDim.x) {
+    const bool inverse = item < nft;   // (uniform over the workgroup)
+    int64_t p;
+    if (inverse) {
+      const int64_t slot = item * kP + c;
+      p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
+    } else {
+      p = (item - nft) * kP + c;
+    }
     const bool alive = p < a.N;
     // (everything that is not needed during the trajectory -- the scalars of the decision, the output rows' addresses --
     // is fetched / formed after it: the kernel sits at its 512-register budget, and what is live across the GEMM loops
     // and the streamed passes decides whether those spill; tools/check_isa.sh gates both)
     const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;   // this lane's elements inside a [*][DIM] matrix
+    // the end point's position: into the output rows -- an inverse-L item's is wanted by nobody: into the second half of
+    // the workgroup's working rows (32 rows, the momentum's would-be working copy: unused)
+    double* xend = inverse ? a.scratch + (size_t)blockIdx.x * (Work<NB>::kArea) + Work<NB>::kArea / 2 +
+                                 (size_t)c * (128 * NB) + 32 * NB * w + 4 * NB * h
+                           : a.X_out + roff;
     Tile<NB> g;
     VTile<NB> v;
     tile_load_narrow<NB>(a.G_in + roff, g);
     float exl = 0.f;
-    const double EVL = pot64_trajectory<NB, false, kXRows>(mdl, ar, sh, w, c, h, lane, wk, a.X_in + roff, a.V_in + roff,
-                                                          a.X_out + roff, g, v, a.L, a.eps, a.chalf, &exl);
+    const double EVL = pot64_trajectory<NB, kXRows>(mdl, ar, sh, w, c, h, lane, wk, a.X_in + roff, a.V_in + roff, xend, g, v,
+                                                    a.L, a.eps, a.chalf, &exl, inverse);
     const double EXL = (double)exl;
     const double HL = EXL + EVL;
-    const double* xin = a.X_in + roff;
-    const double* vin = a.V_in + roff;
-    const double* gin = a.G_in + roff;
-    double* xo = a.X_out + roff;
-    double* vo = a.V_out + roff;
-    double* go = a.G_out + roff;
+    if (inverse) {
+      if (w == 0 && h == 0) a.Hwork[p] = HL;
+      __syncthreads();
+      continue;
+    }
 
-    // rates / acceptance, waiting times, first minimum: lanes 0..31 of wave 0, one particle each, with the device
-    // functions of the elementwise kernels in their one-lane-per-particle forms (as hk_decide of the multi-pass path)
+    // lanes 0..31 of wave 0, one particle each
     if (w == 0 && h == 0) {
       const int64_t pp = alive ? p : 0;
       const uint32_t pid = (uint32_t)(a.first_pid + pp);
       const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
       const double H0 = EX0 + EV0;
-      // H of the inverse-L proposal: cached, or integrated by pot64_flf_kernel for the cold particles
+      // H of the inverse-L proposal: cached; or the L proposal of the iteration in which the particle flipped; or being
+      // integrated by an inverse-L item of this very launch -- then the particle is left pending for pot64_fix_kernel
       double Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.0;
-      if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
-      JumpArgs<double> ja;
-      ja.p_r = a.p_r;
-      ja.p_flip = a.p_flip;
-      ja.rexp = a.rexp;
-      ja.runif = a.runif;
-      ja.N = a.N;
-      LaneMap m;
-      m.j = 0;
-      m.G = 1;
-      m.D = 1;
-      m.CH = 1;
-      m.lane0 = 0;
-      m.wpp = 0;
+      const bool cold = !(Hflf == Hflf);
+      bool pending = false;
+      if (cold) {
+        Hflf = a.Hspec_in[p];
+        pending = !(Hflf == Hflf);
+      }
       double best = 0.0;
       bool bad = false, gate = false;
       int k = 0;
-      if constexpr (MODE == kModeMJHMC) {
-        decide<double, REPLAY>(ja, a.key, m, H0, HL, Hflf, pp, pid, k, best, bad);
-      } else if constexpr (MODE == kModeCT) {
-        decide_ct<double, REPLAY>(ja, a.key, m, H0, HL, pp, pid, k, best, bad);
-      } else {
-        double uacc, uflip, ugate;
-        if constexpr (REPLAY) {
-          uacc = a.runif[pp];
-          uflip = a.runif[a.N + pp];
-          ugate = a.runif[2 * a.N];
-        } else {
-          const u32x4 q = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotExpR, a.key.k0, a.key.k1);
-          const u32x4 f = philox4x32_10(pid, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
-          const u32x4 gq = philox4x32_10(0xFFFFFFFFu, a.key.tick_lo, a.key.tick_hi, kSlotFlip, a.key.k0, a.key.k1);
-          uacc = u53(q.w2, q.w3);
-          uflip = u53(f.w0, f.w1);
-          ugate = u53(gq.w2, gq.w3);
-        }
-        const double dH = H0 - HL;
-        const bool accept = !(dH < 0.0) || (uacc < exp(dH));
-        const bool flip = uflip < a.p_flip;
-        gate = ugate < a.p_r;
-        k = (accept ? 1 : 0) | (flip ? 2 : 0);
+      if (!pending) {
+        k = pot64_decide<REPLAY, MODE>(a, H0, HL, Hflf, pp, pid, best, bad, gate);
+        any_bad |= (bad && alive);
+        // every move but L clears the cache; of those only the R-movers need their inverse-L proposal integrated
+        if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k == 2, p);
+        a.dwell[p] = best;
+        a.dwell_ring[p] = best;
+        a.trans[p] = (uint8_t)k;
       }
-      any_bad |= (bad && alive);
-      if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k != 0, p);
       sh.s.move[c] = k | (gate ? 4 : 0);
-      a.dwell[p] = best;
-      a.dwell_ring[p] = best;
-      a.trans[p] = (uint8_t)k;
       if (alive) {
         if constexpr (MODE == kModeControl) {  // l_count, f_count, R applied, fl_count (markov_jump_hmc.py:143-148)
           n0 += (k == 3);
           n1 += (k == 2);
           n2 += gate ? 1u : 0u;
           n3 += (k == 1);
-        } else {
+        } else if (!pending) {
           n0 += (k == 0);
           n1 += (k == 1);
           n2 += (k == 2);
         }
+        if constexpr (MODE == kModeMJHMC) n3 += cold;   // the reference integrates F L F for every one of these
       }
       // scalars of the successors that keep or take whole states; a refreshed kinetic energy is filled in below
       const bool took_L = MODE == kModeControl ? (k & 1) : (k == 0);
       a.EX_out[p] = took_L ? EXL : EX0;
       a.EV_out[p] = took_L ? EVL : EV0;
-      a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nan("");
+      if (!pending) {
+        a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nan("");
+        if constexpr (MODE == kModeMJHMC) a.Hspec_out[p] = (k == 1) ? HL : __builtin_nan("");
+      }
     }
     __syncthreads();
-    const int mv = sh.s.move[c];
-    const int k = mv & 3;
-    bool take, flip, refresh;  // keep the end point of L; negate the successor's momentum; redraw it (HMCState.R)
-    if constexpr (MODE == kModeControl) {
-      const bool accept = k & 1, fl = k & 2;
-      take = accept;
-      flip = accept != fl;      // accepted: L F, then possibly F again; rejected: possibly F (markov_jump_hmc.py:116-141)
-      refresh = (mv & 4) != 0;  // batch-wide (:138-141)
-    } else {
-      take = k == 0;
-      flip = (MODE == kModeCT && k == 0) || k == 1;  // CT's FL move ends with a flip (:258,278); F flips
-      refresh = k == 2;
-    }
-    // the successor's rows.  A kept end point: position already in the output rows, momentum from the registers
-    // (negated where the move ends with a flip), dE/dX from the accumulator; everything else: the pre-move position and
-    // dE/dX, and in the second loop its momentum, flipped / refreshed
-    const bool tile_refreshes = __ballot(refresh) != 0ull;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      DV gg;
-      if (take) {
-        DV vv;
-#pragma unroll
-        for (int r = 0; r < NB; ++r) {
-          dset<NB>(vv, r, flip ? -v.b[r][q] : v.b[r][q]);
-          dset<NB>(gg, r, (double)g.b[r][q]);
-        }
-        dv_store<NB>(vo, q, vv);
-      } else {
-        gg = dv_load<NB>(gin, q);
-        dv_store<NB>(xo, q, dv_load<NB>(xin, q));
-      }
-      dv_store<NB>(go, q, gg);
-    }
-    double s2 = 0.0;
-    if (!take || (REPLAY && refresh)) {
-      const double* vsrc = take ? (const double*)vo : vin;   // (a kept end point's momentum is flipped already)
-      const bool fl2 = flip && !take;
-      const double* nrow = REPLAY ? lane_row<NB>(a.noise, alive ? p : 0, w, h) : nullptr;
-#pragma unroll 1
-      for (int q = 0; q < 16; ++q) {
-        DV vv = dv_load<NB>(vsrc, q);
-        if (fl2) vv = -vv;
-        if constexpr (REPLAY) {
-          if (refresh) {  // HMCState.R (hmc_state.py:121-129) with the recorded normals
-            const DV z = dv_load<NB>(nrow, q);
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-              const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
-              dset<NB>(vv, r, t);
-              s2 = s2 + t * t;
-            }
-          }
-        }
-        dv_store<NB>(vo, q, vv);
-      }
-    }
-    if constexpr (!REPLAY) {
-      // HMCState.R, column by column (the set is the same in every wave: it comes from sh.move), the whole workgroup
-      // drawing the column's normals (column_normals); the column's momentum is in the output rows by now
-      unsigned cols = (unsigned)(__ballot(refresh) & 0xFFFFFFFFull);
-      while (cols) {
-        const int c0 = __ffs((int)cols) - 1;
-        cols &= cols - 1;
-        const int64_t p0 = tile * kP + c0;
-        column_normals<NB, double>(a.key, (uint32_t)(a.first_pid + (p0 < a.N ? p0 : 0)), a.D, sh.zn);
-        __syncthreads();
-        if (c == c0) {
-          const double* zrow = sh.zn + 32 * NB * w + 4 * NB * h;
-#pragma unroll 1
-          for (int q = 0; q < 16; ++q) {
-            DV vv = dv_load<NB>(vo, q);
-            const DV z = *reinterpret_cast<const DV*>(zrow + q_off<NB>(q));
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-              const double t = dget<NB>(vv, r) * a.r_keep + dget<NB>(z, r) * a.r_mix;
-              dset<NB>(vv, r, t);
-              s2 = s2 + t * t;
-            }
-            dv_store<NB>(vo, q, vv);
-          }
-        }
-        __syncthreads();
-      }
-    }
-    if (tile_refreshes) {  // all waves take part in the reduction; only refreshed columns use the result
-      const double evr = column_sum<NB>(sh, w, c, h, s2) / 2.0;
-      if (refresh && w == 0 && h == 0) a.EV_out[p] = evr;
-    }
+    pot64_finish<NB, REPLAY, MODE, false>(a, sh, p, alive, roff, w, c, h, v, g);
     __syncthreads();
   }
   if (any_bad) {
@@ -564,6 +607,69 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
   if (n3) atomicAdd(&tally[3], n3);
   __syncthreads();
   if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
+// The particles the jump kernel left pending (this iteration's list): decide them now that both of their trajectories
+// are done, and where the move is not L put the pre-move position and dE/dX back and flip / redraw the momentum
+// (pot_fix_kernel's twin)
+template <int NB, bool REPLAY>
+__global__ __launch_bounds__(256) void pot64_fix_kernel(const Pot64JumpArgs a) {
+  __shared__ Finish64Shared<NB> sh;
+  if (a.ctl->failed) return;
+  const int ncold = *a.cold_count;
+  if ((int64_t)blockIdx.x * kP >= ncold) return;
+  const int w = threadIdx.x >> 6, c = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
+  unsigned n0 = 0, n1 = 0, n2 = 0;
+  bool any_bad = false;
+  for (int64_t tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
+    const int64_t slot = tile * kP + c;
+    const bool valid = slot < ncold;    // the last tile repeats an entry: those columns do nothing
+    const int64_t p = a.cold_list[valid ? slot : ncold - 1];
+    if (w == 0 && h == 0) {
+      const uint32_t pid = (uint32_t)(a.first_pid + p);
+      const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const double H0 = EX0 + EV0;
+      const double HL = a.EX_out[p] + a.EV_out[p];
+      double best = 0.0;
+      bool bad = false, gate = false;
+      const int k = pot64_decide<REPLAY, kModeMJHMC>(a, H0, HL, a.Hwork[p], p, pid, best, bad, gate);
+      sh.s.move[c] = valid ? k : 0;
+      if (valid) {
+        any_bad |= bad;
+        append_cold(a.next_list, a.next_count, k == 2, p);
+        a.dwell[p] = best;
+        a.dwell_ring[p] = best;
+        a.trans[p] = (uint8_t)k;
+        n0 += (k == 0);
+        n1 += (k == 1);
+        n2 += (k == 2);
+        if (k != 0) {
+          a.EX_out[p] = EX0;
+          a.EV_out[p] = EV0;   // (an R-mover's: filled in by pot64_finish)
+        }
+        a.Hflf_out[p] = k == 0 ? H0 : __builtin_nan("");
+        a.Hspec_out[p] = k == 1 ? HL : __builtin_nan("");
+      }
+    }
+    __syncthreads();
+    const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;
+    VTile<NB> v;   // (unused: FIX)
+    Tile<NB> g;
+    pot64_finish<NB, REPLAY, kModeMJHMC, true>(a, sh, p, true, roff, w, c, h, v, g);
+    __syncthreads();
+  }
+  if (any_bad) {
+    a.ctl->failed = 1;
+    a.ctl->failed_iter = a.iter;
+  }
+  __shared__ unsigned tally[3];
+  if (threadIdx.x < 3) tally[threadIdx.x] = 0;
+  __syncthreads();
+  if (n0) atomicAdd(&tally[0], n0);
+  if (n1) atomicAdd(&tally[1], n1);
+  if (n2) atomicAdd(&tally[2], n2);
+  __syncthreads();
+  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
 static int resident_cus64() {
@@ -584,19 +690,23 @@ static void launch64_mode(const Pot64JumpArgs& a, const PotModel& mdl, unsigned 
 
 template <int NB>
 static void launch64_nb(const Pot64JumpArgs& a, const PotModel& mdl, hipStream_t st) {
-  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, resident_cus64());
+  const int cus = resident_cus64();
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
-    if (a.iter == 0) {  // first iteration of a call: both counters cleared (they are adjacent), the list from a scan
-      (void)hipMemsetAsync(a.cold_count < a.next_count ? a.cold_count : a.next_count, 0, 2 * sizeof(int), st);
-      hipLaunchKernelGGL(pot64_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.N,
-                         a.cold_list, a.cold_count, (const Control*)a.ctl);
+    if (a.iter == 0 || a.rescan) {  // first iteration of a call: the three counters cleared (they are adjacent), the list from a scan
+      (void)hipMemsetAsync(std::min(a.cold_count, std::min(a.next_count, a.zero_count)), 0, 3 * sizeof(int), st);
+      hipLaunchKernelGGL(pot64_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hspec_in,
+                         a.N, a.cold_list, a.cold_count, (const Control*)a.ctl);
     }
-    hipLaunchKernelGGL(pot64_flf_kernel<NB>, dim3(grid), dim3(256), 0, st, a, mdl);
+    // forward tiles + at most as many inverse-L tiles (workgroups without an item leave at once)
+    const unsigned grid = (unsigned)std::min<int64_t>(2 * a.ntiles, cus);
     launch64_mode<NB, kModeMJHMC>(a, mdl, grid, st);
-  } else if (a.mode == kModeCT) {
-    launch64_mode<NB, kModeCT>(a, mdl, grid, st);
+    const unsigned fgrid = (unsigned)std::min<int64_t>(a.ntiles, 4 * cus);
+    if (a.rexp && a.noise) hipLaunchKernelGGL((pot64_fix_kernel<NB, true>), dim3(fgrid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pot64_fix_kernel<NB, false>), dim3(fgrid), dim3(256), 0, st, a);
   } else {
-    launch64_mode<NB, kModeControl>(a, mdl, grid, st);
+    const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, cus);
+    if (a.mode == kModeCT) launch64_mode<NB, kModeCT>(a, mdl, grid, st);
+    else launch64_mode<NB, kModeControl>(a, mdl, grid, st);
   }
 }
 

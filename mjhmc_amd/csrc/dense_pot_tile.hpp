@@ -300,6 +300,14 @@ struct Shared {
   float zn[128 * NB];     // the standard normals of ONE refreshing column (column_normals)
 };
 
+// What the kernels that only FINISH a move need of the above (pot_fix_kernel: no GEMM operands, no bias)
+template <int NB>
+struct FinishShared {
+  float red[2][4][kP];
+  int move[kP];
+  float zn[128 * NB];
+};
+
 // HMCState.R (hmc_state.py:121-129) needs ndims standard normals for a column whose momentum is redrawn.  Drawn by the
 // column's own lanes that is 32 float64 Box-Muller pairs per lane, one after the other, with the rest of the workgroup
 // waiting (~20 us per tile with a refreshing column: a third of an iteration of the reference's own 36 x 1000 batches,
@@ -387,8 +395,8 @@ __device__ __forceinline__ void pot_gradient(const PotModel& mdl, AReg<NB>& ar, 
 }
 
 // kinetic energy sum(v^2)/2 per particle (all lanes of column c get it).  One barrier pair.
-template <int NB>
-__device__ __forceinline__ float pot_kinetic(Shared<NB>& sh, int w, int c, int h, const Tile<NB>& v) {
+template <int NB, class SH>
+__device__ __forceinline__ float pot_kinetic(SH& sh, int w, int c, int h, const Tile<NB>& v) {
   float s = 0.f;
 #pragma unroll
   for (int r = 0; r < NB; ++r)

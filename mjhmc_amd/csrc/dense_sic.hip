@@ -495,7 +495,8 @@ __device__ __forceinline__ float half_swap_sum(float s) {
 }
 
 // sum of a per-column value over the columns of the caller's particle (n_patches of them, consecutive)
-__device__ __forceinline__ float group_total(SicShared& sh, int w, int c, int h, int P, int g0, float col_tot) {
+template <class SH>
+__device__ __forceinline__ float group_total(SH& sh, int w, int c, int h, int P, int g0, float col_tot) {
   if (P == 1) return col_tot;
   if (w == 0 && h == 0) sh.colsum[c] = col_tot;
   __syncthreads();
@@ -531,8 +532,8 @@ __device__ __forceinline__ float sic_energy(const SicModel& mdl, SicShared& sh, 
 }
 
 // sum(v^2) / 2 per PARTICLE
-template <int NB>
-__device__ __forceinline__ float sic_kinetic(SicShared& sh, int w, int c, int h, int P, const Col& col, const CTile<NB>& v) {
+template <int NB, class SH>
+__device__ __forceinline__ float sic_kinetic(SH& sh, int w, int c, int h, int P, const Col& col, const CTile<NB>& v) {
   float s = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -655,13 +656,15 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
   astream_close();
 }
 
-// the cold list of the FIRST iteration of a call (later ones: append_cold in the jump kernel; dense_pot.hip has the story)
-__global__ void sic_cold_list_kernel(const float* __restrict__ Hflf_in, int64_t N, int* __restrict__ list,
-                                     int* __restrict__ count, const Control* ctl) {
+// The list of the FIRST iteration of a call: the particles whose inverse-L proposal must be integrated (cold cache and
+// no H(L proposal) handed on by an F move; later lists: append_cold in the jump and fix kernels; dense_pot.hip has the
+// story of the F-movers, of the inverse-L tiles as items of the jump launch and of the fix kernel)
+__global__ void sic_cold_list_kernel(const float* __restrict__ Hflf_in, const float* __restrict__ Hspec_in, int64_t N,
+                                     int* __restrict__ list, int* __restrict__ count, const Control* ctl) {
   if (ctl->failed) return;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float hc = p < N ? Hflf_in[p] : 0.f;
-  append_cold(list, count, (p < N) && !(hc == hc), p);
+  const float hc = p < N ? Hflf_in[p] : 0.f, hs = p < N ? Hspec_in[p] : 0.f;
+  append_cold(list, count, (p < N) && !(hc == hc) && !(hs == hs), p);
 }
 
 struct FromList {
@@ -669,32 +672,76 @@ struct FromList {
   __device__ int64_t operator()(int64_t s) const { return list[s]; }
 };
 
-template <bool CAUCHY, int NB>
-__global__ __launch_bounds__(512, 2) void sic_flf_kernel(const SicJumpArgs a, const SicModel mdl) {
-  __shared__ SicShared sh;
-  if (a.ctl->failed) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  const int ncold = *a.cold_count;
-  const int ppt = kP / mdl.P;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold);  // the cold tally
-  if ((int64_t)blockIdx.x * ppt >= ncold) return;  // nothing for this workgroup
-  stage_patches(mdl, sh);
-  const AStream as = astream_open<NB>(mdl, sh, w, lane);
-  for (int64_t tile = blockIdx.x; tile * ppt < ncold; tile += gridDim.x) {
-    const Col col = col_of(tile, c, mdl.P, (int64_t)ncold, FromList{a.cold_list});  // the last tile repeats an entry
-    CTile<NB> x, v;
-    RTile R;
-    ctile_load(a.X_in, col.q, w, h, x);
-    ctile_load(a.V_in, col.q, w, h, v);
+// what the kernels that only FINISH a move need of SicShared (sic_fix_kernel)
+struct SicFinishShared {
+  float red[2][kW][kP];
+  float colsum[kP];
+  int move[kP];
+  unsigned tally[4];
+};
+
+// The successor's rows once the moves of a tile's columns stand in sh.move.  FIX = false (jump kernel): x, v hold the
+// end point of L.  FIX = true (sic_fix_kernel): columns that keep the end point are finished already.
+template <bool REPLAY, int MODE, int NB, bool FIX, class SH>
+__device__ __forceinline__ void sic_finish(const SicJumpArgs& a, SH& sh, int P, const Col& col, int w, int c, int h,
+                                           CTile<NB>& x, CTile<NB>& v) {
+  const int64_t p = col.part;
+  const int mv = sh.move[c];
+  const int k = mv & 3;
+  bool refresh;  // this column's momentum is redrawn (HMCState.R)
+  bool touch = col.alive;
+  if constexpr (MODE == kModeControl) {
+    if (!(k & 1)) {  // rejected: back to the pre-move state
+      ctile_load(a.X_in, col.q, w, h, x);
+      ctile_load(a.V_in, col.q, w, h, v);
+    } else {  // accepted L F: flip
 #pragma unroll
-    for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
-    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
-    round_to_state(v);  // the same rounding the jump kernel applies to the forward proposal
-    const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
-    if (w == 0 && h == 0 && col.leader) a.Hwork[col.part] = ex + ev;
-    __syncthreads();
+      for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
+    }
+    if (k & 2) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
+    }
+    refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
+  } else {
+    if constexpr (FIX) touch = touch && k != 0;
+    if (k != 0) {  // F / R keep the position
+      ctile_load(a.X_in, col.q, w, h, x);
+      ctile_load(a.V_in, col.q, w, h, v);
+    }
+    if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
+    }
+    refresh = (k == 2);
   }
-  astream_close();
+  const bool tile_refreshes = __ballot(refresh) != 0ull;
+  if (refresh) {  // HMCState.R (hmc_state.py:121-129)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v.b[b] = v.b[b] * a.r_keep;
+    if constexpr (REPLAY) {
+      const __bf16* zrow = a.noise + (size_t)col.q * kC + 32 * NB * w + 4 * h;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const bf16x4 z = *reinterpret_cast<const bf16x4*>(zrow + 32 * b + 8 * g4);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) v.b[b][4 * g4 + kk] += (float)z[kk] * a.r_mix;
+        }
+    } else {
+      sic_add_normals(a.key, (uint32_t)(a.first_pid + p), col.patch, w, h, a.r_mix, v);
+    }
+    round_to_state(v);
+  }
+  if (tile_refreshes) {
+    const float evr = sic_kinetic(sh, w, c, h, P, col, v);
+    if (refresh && w == 0 && h == 0 && col.leader) a.EV_out[p] = evr;
+  }
+  if (touch) {
+    ctile_store(a.X_out, col.q, w, h, x);
+    ctile_store(a.V_out, col.q, w, h, v);
+  }
 }
 
 // MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
@@ -704,114 +751,95 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
   __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  // the inverse-L pass of this iteration has consumed its list: its counter is free for the iteration after the next
-  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) *a.cold_count = 0;
+  // MJHMC: the inverse-L tiles of this iteration's list are the first items of the launch
+  const int ncold = MODE == kModeMJHMC ? *a.cold_count : 0;
+  const int ppt = kP / mdl.P;
+  const int64_t nft = (ncold + ppt - 1) / ppt;
+  if ((int64_t)blockIdx.x >= nft + a.ntiles) return;
+  if (MODE == kModeMJHMC && blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.zero_count = 0;   // the list two iterations back is consumed: its counter is free for the next iteration's appends
+    if (ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold << 32);   // integrated here: the high half of the cold tally
+  }
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
   bool any_bad = false;
   if (threadIdx.x < 4) sh.tally[threadIdx.x] = 0;
   stage_patches(mdl, sh);
   const AStream as = astream_open<NB>(mdl, sh, w, lane);
-  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const Col col = col_of(tile, c, mdl.P, a.N, Identity{});
+  for (int64_t item = blockIdx.x; item < nft + a.ntiles; item += gridDim.x) {
+    const bool inverse = item < nft;   // (uniform over the workgroup)
+    const Col col = inverse ? col_of(item, c, mdl.P, (int64_t)ncold, FromList{a.cold_list})   // the last tile repeats an entry
+                            : col_of(item - nft, c, mdl.P, a.N, Identity{});
     const int64_t p = col.part;
-    const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
-    const float H0 = EX0 + EV0;
-    float Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.f;
-    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];
     CTile<NB> x, v;
     RTile R;
     ctile_load(a.X_in, col.q, w, h, x);
     ctile_load(a.V_in, col.q, w, h, v);
+    if (inverse) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
+    }
     const float EXL = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
     round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
     const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
+    if (inverse) {
+      if (w == 0 && h == 0 && col.leader) a.Hwork[p] = HL;
+      __syncthreads();
+      continue;
+    }
     if (w == 0 && h == 0) {  // every column of a particle reaches the same decision; its leader reports it
       const uint32_t pid = (uint32_t)(a.first_pid + p);
+      const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const float H0 = EX0 + EV0;
+      // H of the inverse-L proposal: cached; or the L proposal of the iteration in which the particle flipped; or being
+      // integrated by an inverse-L item of this very launch -- then the particle is left pending for sic_fix_kernel
+      float Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.f;
+      const bool cold = !(Hflf == Hflf);
+      bool pending = false;
+      if (cold) {
+        Hflf = a.Hspec_in[p];
+        pending = !(Hflf == Hflf);
+      }
       double best = 0.0;
       bool bad = false, gate = false;
-      int k;
-      if constexpr (MODE == kModeMJHMC) k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
-      else if constexpr (MODE == kModeCT) k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
-      else k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, p, a.N, a.runif, a.key, gate);
+      int k = 0;
+      if (!pending) {
+        if constexpr (MODE == kModeMJHMC) k = dense_decide<REPLAY>(H0, HL, Hflf, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
+        else if constexpr (MODE == kModeCT) k = dense_decide_ct<REPLAY>(H0, HL, a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
+        else k = dense_control<REPLAY>(H0, HL, a.p_r, a.p_flip, pid, p, a.N, a.runif, a.key, gate);
+        // every move but L clears the cache; of those only the R-movers need their inverse-L proposal integrated
+        if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, col.leader && k == 2, p);
+      }
       sh.move[c] = k | (gate ? 4 : 0);
-      if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, col.leader && k != 0, p);
       if (col.leader) {
-        any_bad |= bad;
-        a.dwell[p] = best;
-        a.dwell_ring[p] = best;
-        a.trans[p] = (uint8_t)k;
+        if (!pending) {
+          any_bad |= bad;
+          a.dwell[p] = best;
+          a.dwell_ring[p] = best;
+          a.trans[p] = (uint8_t)k;
+        }
         if constexpr (MODE == kModeControl) {  // l_count, f_count, R applied, fl_count (markov_jump_hmc.py:143-148)
           n0 += (k == 3);
           n1 += (k == 2);
           n2 += gate ? 1u : 0u;
           n3 += (k == 1);
-        } else {
+        } else if (!pending) {
           n0 += (k == 0);
           n1 += (k == 1);
           n2 += (k == 2);
         }
+        if constexpr (MODE == kModeMJHMC) n3 += cold;   // the reference integrates F L F for every one of these
         const bool took_L = MODE == kModeControl ? (k & 1) : (k == 0);
         a.EX_out[p] = took_L ? EXL : EX0;
         a.EV_out[p] = took_L ? EVL : EV0;
-        a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nanf("");
+        if (!pending) {
+          a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nanf("");
+          if constexpr (MODE == kModeMJHMC) a.Hspec_out[p] = (k == 1) ? HL : __builtin_nanf("");
+        }
       }
     }
     __syncthreads();
-    const int mv = sh.move[c];
-    const int k = mv & 3;
-    bool refresh;  // this column's momentum is redrawn (HMCState.R)
-    if constexpr (MODE == kModeControl) {
-      if (!(k & 1)) {  // rejected: back to the pre-move state
-        ctile_load(a.X_in, col.q, w, h, x);
-        ctile_load(a.V_in, col.q, w, h, v);
-      } else {  // accepted L F: flip
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
-      }
-      if (k & 2) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
-      }
-      refresh = (mv & 4) != 0;  // batch-wide (markov_jump_hmc.py:138-141)
-    } else {
-      if (k != 0) {  // F / R keep the position
-        ctile_load(a.X_in, col.q, w, h, x);
-        ctile_load(a.V_in, col.q, w, h, v);
-      }
-      if ((MODE == kModeCT && k == 0) || k == 1) {  // CT's FL move ends with a flip (:258,278); F flips
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
-      }
-      refresh = (k == 2);
-    }
-    const bool tile_refreshes = __ballot(refresh) != 0ull;
-    if (refresh) {  // HMCState.R (hmc_state.py:121-129)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) v.b[b] = v.b[b] * a.r_keep;
-      if constexpr (REPLAY) {
-        const __bf16* zrow = a.noise + (size_t)col.q * kC + 32 * NB * w + 4 * h;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const bf16x4 z = *reinterpret_cast<const bf16x4*>(zrow + 32 * b + 8 * g4);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) v.b[b][4 * g4 + kk] += (float)z[kk] * a.r_mix;
-          }
-      } else {
-        sic_add_normals(a.key, (uint32_t)(a.first_pid + p), col.patch, w, h, a.r_mix, v);
-      }
-      round_to_state(v);
-    }
-    if (tile_refreshes) {
-      const float evr = sic_kinetic(sh, w, c, h, mdl.P, col, v);
-      if (refresh && w == 0 && h == 0 && col.leader) a.EV_out[p] = evr;
-    }
-    if (col.alive) {
-      ctile_store(a.X_out, col.q, w, h, x);
-      ctile_store(a.V_out, col.q, w, h, v);
-    }
+    sic_finish<REPLAY, MODE, NB, false>(a, sh, mdl.P, col, w, c, h, x, v);
     __syncthreads();
   }
   if (any_bad) {
@@ -825,6 +853,66 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
   if (n3) atomicAdd(&sh.tally[3], n3);
   __syncthreads();
   if (threadIdx.x < 4 && sh.tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)sh.tally[threadIdx.x]);
+}
+
+// The particles the jump kernel left pending (this iteration's list): decide them now that both of their trajectories
+// are done, and where the move is not L put the pre-move position back and flip / redraw the momentum (pot_fix_kernel's twin)
+template <bool REPLAY, int NB>
+__global__ __launch_bounds__(512) void sic_fix_kernel(const SicJumpArgs a, int P) {
+  __shared__ SicFinishShared sh;
+  if (a.ctl->failed) return;
+  const int ncold = *a.cold_count;
+  const int ppt = kP / P;
+  if ((int64_t)blockIdx.x * ppt >= ncold) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  unsigned n0 = 0, n1 = 0, n2 = 0;
+  bool any_bad = false;
+  if (threadIdx.x < 4) sh.tally[threadIdx.x] = 0;
+  for (int64_t tile = blockIdx.x; tile * ppt < ncold; tile += gridDim.x) {
+    const Col col = col_of(tile, c, P, (int64_t)ncold, FromList{a.cold_list});   // idle columns: alive == false
+    const int64_t p = col.part;
+    if (w == 0 && h == 0) {
+      const uint32_t pid = (uint32_t)(a.first_pid + p);
+      const float EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const float H0 = EX0 + EV0;
+      const float HL = a.EX_out[p] + a.EV_out[p];
+      double best = 0.0;
+      bool bad = false;
+      const int k = dense_decide<REPLAY>(H0, HL, a.Hwork[p], a.p_r, pid, p, a.N, a.rexp, a.key, best, bad);
+      sh.move[c] = col.alive ? k : 0;
+      __builtin_amdgcn_wave_barrier();   // (every column has read EX_out / EV_out before a leader overwrites them)
+      append_cold(a.next_list, a.next_count, col.leader && k == 2, p);
+      if (col.leader) {
+        any_bad |= bad;
+        a.dwell[p] = best;
+        a.dwell_ring[p] = best;
+        a.trans[p] = (uint8_t)k;
+        n0 += (k == 0);
+        n1 += (k == 1);
+        n2 += (k == 2);
+        if (k != 0) {
+          a.EX_out[p] = EX0;
+          a.EV_out[p] = EV0;   // (an R-mover's: filled in by sic_finish)
+        }
+        a.Hflf_out[p] = k == 0 ? H0 : __builtin_nanf("");
+        a.Hspec_out[p] = k == 1 ? HL : __builtin_nanf("");
+      }
+    }
+    __syncthreads();
+    CTile<NB> x, v;
+    ctile_zero(v);
+    sic_finish<REPLAY, kModeMJHMC, NB, true>(a, sh, P, col, w, c, h, x, v);
+    __syncthreads();
+  }
+  if (any_bad) {
+    a.ctl->failed = 1;
+    a.ctl->failed_iter = a.iter;
+  }
+  if (n0) atomicAdd(&sh.tally[0], n0);
+  if (n1) atomicAdd(&sh.tally[1], n1);
+  if (n2) atomicAdd(&sh.tally[2], n2);
+  __syncthreads();
+  if (threadIdx.x < 3 && sh.tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)sh.tally[threadIdx.x]);
 }
 
 // HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
@@ -886,19 +974,23 @@ static void sic_launch_mode(const SicJumpArgs& a, const SicModel& mdl, unsigned 
 
 template <bool CAUCHY, int NB>
 static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
+  const int cus = sic_cus();
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
-    if (a.iter == 0) {  // first iteration of a call: both counters cleared (they are adjacent), the list from a scan
-      (void)hipMemsetAsync(a.cold_count < a.next_count ? a.cold_count : a.next_count, 0, 2 * sizeof(int), st);
-      hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.N,
-                         a.cold_list, a.cold_count, (const Control*)a.ctl);
+    if (a.iter == 0 || a.rescan) {  // first iteration of a call: the three counters cleared (they are adjacent), the list from a scan
+      (void)hipMemsetAsync(std::min(a.cold_count, std::min(a.next_count, a.zero_count)), 0, 3 * sizeof(int), st);
+      hipLaunchKernelGGL(sic_cold_list_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a.Hflf_in, a.Hspec_in,
+                         a.N, a.cold_list, a.cold_count, (const Control*)a.ctl);
     }
-    hipLaunchKernelGGL((sic_flf_kernel<CAUCHY, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+    // forward tiles + at most as many inverse-L tiles (workgroups without an item leave at once)
+    const unsigned grid = (unsigned)std::min<int64_t>(2 * a.ntiles, cus);
     sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
-  } else if (a.mode == kModeCT) {
-    sic_launch_mode<CAUCHY, kModeCT, NB>(a, mdl, grid, st);
+    const unsigned fgrid = (unsigned)std::min<int64_t>(a.ntiles, 4 * cus);
+    if (a.rexp && a.noise) hipLaunchKernelGGL((sic_fix_kernel<true, NB>), dim3(fgrid), dim3(512), 0, st, a, mdl.P);
+    else hipLaunchKernelGGL((sic_fix_kernel<false, NB>), dim3(fgrid), dim3(512), 0, st, a, mdl.P);
   } else {
-    sic_launch_mode<CAUCHY, kModeControl, NB>(a, mdl, grid, st);
+    const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, cus);
+    if (a.mode == kModeCT) sic_launch_mode<CAUCHY, kModeCT, NB>(a, mdl, grid, st);
+    else sic_launch_mode<CAUCHY, kModeControl, NB>(a, mdl, grid, st);
   }
 }
 

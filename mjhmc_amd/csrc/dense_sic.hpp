@@ -35,8 +35,12 @@ struct SicJumpArgs {
   float* Hwork;
   int* cold_list;
   int* cold_count;
-  int* next_list;       // the NEXT iteration's cold list and counter, filled by this iteration's jump kernel
+  int* next_list;       // the NEXT iteration's list and counter, filled by this iteration's jump and fix kernels
   int* next_count;
+  int* zero_count;      // (as PotJumpArgs)
+  int rescan;
+  const float* Hspec_in;
+  float* Hspec_out;
   float* EX_out;
   float* EV_out;
   float* Hflf_out;

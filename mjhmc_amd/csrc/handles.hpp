@@ -78,6 +78,8 @@ struct Shape {
 };
 
 
+constexpr int kMaxDenseParts = 4;   // free-running parts of a dense batch (iterate_t)
+
 struct HostTraj;  // proposal workspace of a host-energy sampler (host_energy.hip)
 
 struct mjhmc_sampler {
@@ -87,21 +89,24 @@ struct mjhmc_sampler {
   int D, dtype, mode;
   Shape sh;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // second half of a big dense batch (iterate_t: split launches)
   char* h_pin = nullptr;          // pinned host staging of the per-call read-back (failure flag + tallies)
   size_t h_pin_cap = 0;
-  std::vector<hipStream_t> part_streams;   // further parts of a split fused launch (iterate_fused_t)
+  std::vector<hipStream_t> part_streams;   // further parts of a split launch: fused elementwise launches (iterate_fused_t), dense batches (iterate_t)
   std::vector<hipEvent_t> part_events;
-  hipEvent_t ev_join = nullptr;                // "the second stream's half of this call is done"
+  hipEvent_t ev_join = nullptr;
   void* ick[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the split schedule's own checkpoint (as ck[])
   hipEvent_t ev_fork = nullptr;                // "everything the first stream has been given so far"
   void* Xbuf[2] = {nullptr, nullptr};
   void* Vbuf[2] = {nullptr, nullptr};
   void* Xcur = nullptr;
   void* Gbuf[2] = {nullptr, nullptr};  // dEdX (dense energies keep it, like HMCState.dEdX); follows vcur
-  float* Hwork = nullptr;              // dense energies: per-attempt H_flf work vector
-  int* cold_list = nullptr;            // + compacted cold-particle list (Npad entries, then the counter)
-  double* pot64_scratch = nullptr;     // ProductOfT, float64 state: working rows of the inverse-L pass (two concurrent launches)
+  float* Hwork = nullptr;              // dense energies: H of the inverse-L proposals an iteration integrates
+  int* cold_list = nullptr;            // + the compacted lists of those particles (two of Npad entries, iterations alternate; then
+                                       //   kMaxDenseParts x 3 rotating counters)
+  double* pot64_scratch = nullptr;     // ProductOfT, float64 state: working rows, one set per concurrent launch (kMaxDenseParts)
+  void* Hspec[2] = {nullptr, nullptr}; // dense energies, MJHMC: H(L proposal) of the particles that then moved by F (NaN elsewhere):
+                                       //   next iteration's H of their inverse-L proposal, bit for bit (dense_pot.hip); follows scur
+  void* Hspec_dump = nullptr;          // (test build, MJHMC_NO_FSPEC: where the hand-over goes instead, so that nothing is ever handed on)
   // elementwise energies, several particles per wave: inverse-L pass over the compacted cold particles
   int* flf_list = nullptr;     // [Npad]
   int* flf_counts = nullptr;   // [flf_cap] one counter per attempt of the current mjhmc_iterate call

@@ -867,6 +867,7 @@ int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double
     st->nonfinite = hc.failed ? 1 : 0;
     st->L_used = t->steps;
     st->eps_used = s->eps;
+    st->n_flf_run = st->n_cold;
   }
   return 0;
 }

@@ -528,12 +528,11 @@ def test_sic_512_atoms_control_arm_and_leapfrog():
 
 
 # ---------------------------------------------------------------------------------------------
-# big dense batches are launched as two halves on two streams (api.hip: half_args): invisible in the results
+# dense batches are launched as free-running parts on their own streams (api.hip: part_args): invisible in the results
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('what', ['pot36', 'pot36f64', 'sic_p1', 'sic_p9', 'pot36_control', 'pot36f64_control', 'sic_p1_ct'])
-def test_split_launches_equal_single_launches(what, monkeypatch):
+def _dense_case(what, ctxs, seed=8):
+    """(energies per context, X0, dtype, mode, (eps, L, beta)) of the split / shortcut tests"""
     from mjhmc_amd import engine, _lib
-    ctxs = (engine.context(0), hooks_context(0))       # [0] the product library, [1] the test build with MJHMC_NO_SPLIT
     mode = {'pot36_control': _lib.MODE_CONTROL, 'sic_p1_ct': _lib.MODE_CTHMC}.get(what, _lib.MODE_MJHMC)   # the other sampler families
     what = what.split('_c')[0]
     if what in ('pot36', 'pot36f64'):
@@ -551,24 +550,106 @@ def test_split_launches_equal_single_launches(what, monkeypatch):
         ens = [engine.DeviceEnergy(c, _lib.E_SPARSE_CODE, D, params) for c in ctxs]
         X0 = a0[:, None] + 0.2 * np.random.RandomState(4).randn(D, N)
         hp = (0.0625, 3, 0.1)
+    return ens, X0, dtype, mode, hp
+
+
+_FIELDS = ('X', 'V', 'EX', 'EV', 'HFLF', 'CACHE', 'DWELL', 'TRANS')
+
+
+@pytest.mark.parametrize('what,parts', [('pot36', None), ('pot36f64', None), ('sic_p1', None), ('sic_p9', None), ('pot36_control', None),
+                                        ('pot36f64_control', None), ('sic_p1_ct', None),
+                                        ('pot36', 3), ('pot36f64', 4), ('sic_p1', 4), ('sic_p9', 3), ('pot36f64_control', 3)])
+def test_split_launches_equal_single_launches(what, parts, monkeypatch):
+    """[0] the product library's own schedule (two parts at these sizes) -- or, parts = 3 / 4, the test build told to run
+    that many -- against [1] the test build with MJHMC_NO_SPLIT: one launch sequence on one stream."""
+    from mjhmc_amd import engine, _lib
+    ctxs = (engine.context(0) if parts is None else hooks_context(0), hooks_context(0))
+    ens, X0, dtype, mode, hp = _dense_case(what, ctxs)
     pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype, mode=mode) for en in ens]
-    fields = ('X', 'V', 'EX', 'EV', 'HFLF', 'DWELL', 'TRANS')
     all_stats = [[], []]
     for n_it in (1, 3, 2):
         for k, s in enumerate(pair):
             s.set_hparams(hp[0], hp[1], hp[2], 1.0)
+            monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+            monkeypatch.delenv('MJHMC_SPLIT_PARTS', raising=False)
             if k == 1:
                 monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
-            else:
-                monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+            elif parts:
+                monkeypatch.setenv('MJHMC_SPLIT_PARTS', str(parts))
             st, done = s.iterate(n_it)
             assert done == n_it
-            all_stats[k] += [(t.l, t.f, t.r, t.n_cold, t.E_evals, t.dEdX_evals) for t in st]
+            all_stats[k] += [(t.l, t.f, t.r, t.n_cold, t.E_evals, t.dEdX_evals, t.n_flf_run) for t in st]
         monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
-        for f in fields:
+        monkeypatch.delenv('MJHMC_SPLIT_PARTS', raising=False)
+        for f in _FIELDS:
             fa, fb = pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f))
             assert np.array_equal(fa, fb, equal_nan=True), (what, n_it, f)
     assert all_stats[0] == all_stats[1]
+    for s in pair:
+        s.close()
+
+
+@pytest.mark.parametrize('what', ['pot36', 'pot36f64', 'sic_p1', 'sic_p9'])
+def test_f_mover_shortcut_is_bit_identical(what, monkeypatch):
+    """A particle that has just moved by F needs no inverse-L trajectory: F L F (X, -V) = F L (X, V) is the L proposal of
+    the iteration in which it flipped, and the dense kernels hand its H() on (dense_pot.hip).  [0] the product library
+    against [1] the test build with MJHMC_NO_FSPEC=1, which integrates every cold particle's inverse-L proposal as the
+    reference does (hmc_state.py:109-119): state, cache, dwelling times, transitions and the reference's counters bit
+    for bit -- through single iterations, batches, a change of the step size (which drops the hand-over), a
+    reset_flf_cache and a checkpoint / restore; only n_flf_run differs: it is n_cold on the one side, the R-movers of
+    the iteration before on the other."""
+    from mjhmc_amd import engine, _lib
+    ctxs = (engine.context(0), hooks_context(0))
+    ens, X0, dtype, mode, hp = _dense_case(what, ctxs)
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype, mode=mode) for en in ens]
+    N = X0.shape[1]
+    stats = [[], []]
+    saved = 0.0
+
+    def step(n_it, eps=hp[0], L=hp[1]):
+        for k, s in enumerate(pair):
+            s.set_hparams(eps, L, hp[2], 1.0)
+            if k == 1:
+                monkeypatch.setenv('MJHMC_NO_FSPEC', '1')
+            else:
+                monkeypatch.delenv('MJHMC_NO_FSPEC', raising=False)
+            st, done = s.iterate(n_it)
+            assert done == n_it
+            stats[k] += list(st)
+        monkeypatch.delenv('MJHMC_NO_FSPEC', raising=False)
+        for f in _FIELDS:
+            fa, fb = pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f))
+            assert np.array_equal(fa, fb, equal_nan=True), (what, len(stats[0]), f)
+
+    step(1)
+    step(4)
+    step(1)
+    n_a = len(stats[0])
+    step(2, eps=hp[0] / 2, L=2 * hp[1])        # new step size: the hand-over is dropped, everything cold integrates
+    assert stats[0][n_a].n_flf_run == stats[0][n_a].n_cold
+    step(1)                                     # and back (the retry sequence of markov_jump_hmc.py:376-389)
+    assert stats[0][-1].n_flf_run == stats[0][-1].n_cold
+    for s in pair:
+        s.checkpoint()
+    step(3)
+    for s in pair:
+        s.restore()
+    n_a = len(stats[0])
+    step(2)
+    assert stats[0][n_a].n_flf_run == stats[0][n_a].n_cold
+    for s in pair:
+        s.reset_flf_cache()
+    step(2)
+    assert stats[0][-2].n_cold == N and stats[0][-2].n_flf_run == N
+    for a, b in zip(*stats):
+        assert (a.l, a.f, a.r, a.n_cold, a.E_evals, a.dEdX_evals) == (b.l, b.f, b.r, b.n_cold, b.E_evals, b.dEdX_evals)
+        assert b.n_flf_run == b.n_cold and a.n_flf_run <= a.n_cold
+    # inside a batch and from one single-iteration call to the next: only the R-movers of the iteration before integrate
+    a = stats[0]
+    assert a[1].n_flf_run == a[0].r and a[1].n_cold == a[0].f + a[0].r
+    assert a[2].n_flf_run == a[1].r and a[3].n_flf_run == a[2].r and a[5].n_flf_run == a[4].r
+    saved = sum(t.n_cold - t.n_flf_run for t in a)
+    assert saved > 0, 'no F move in the whole run: the test does not exercise the shortcut'
     for s in pair:
         s.close()
 
