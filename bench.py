@@ -399,7 +399,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
     reps = int(min(max(1, np.ceil(MIN_TIMED_S / per_call)), 4096))
 
     call_s, kern_ms, launches = [], 0.0, 0
-    agg = np.zeros(6)                               # l moves, cold caches, E evaluations, dEdX evaluations, f moves, r moves
+    agg = np.zeros(7)                               # l moves, cold caches, E evaluations, dEdX evaluations, f moves, r moves, inverse-L trajectories run
     rig.monitor.start()
     for _ in range(reps):
         rig.barrier(smp)
@@ -414,7 +414,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         kern_ms += tim['jump_kernel_ms']
         launches += tim['n_jump_launches']
         agg += [sum(s.l for s in stats), sum(s.n_cold for s in stats), sum(s.E_evals for s in stats),
-                sum(s.dEdX_evals for s in stats), sum(s.f for s in stats), sum(s.r for s in stats)]
+                sum(s.dEdX_evals for s in stats), sum(s.f for s in stats), sum(s.r for s in stats),
+                sum(s.n_flf_run for s in stats)]
     device = rig.monitor.stop()
     call_s = rig.max_over_ranks(call_s)
     elapsed = float(np.sum(call_s))
@@ -489,9 +490,17 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         # ProductOfT keeps dE/dX as part of the state (read + written with X, V); SparseImageCode recomputes it
         dense_bytes = (6.0 if w['kind'] == 'pot' else 4.0) * w['D'] * esize + 6 * (8 if w['dtype'] == 'float64' else 4) + 17
         peak = 157.3 if w['kind'] == 'pot' else 2500.0
-        flops = (agg[3] * 4 * DK + agg[2] * 2 * DK) / iters
+        # ... of the trajectories the device RAN.  The reference integrates the inverse-L proposal of every cold particle; the
+        # kernels skip the F-movers' (it is the L proposal of the iteration before, bit for bit: csrc/dense_pot.hip), so the
+        # counters (which follow the reference) count more evaluations than were executed.  `achieved` / `frac` = executed
+        # flops / time -- what the matrix pipe did; `counted` = the reference's evaluation count / time.
+        run = float(n_rank * iters + agg[6])                                  # trajectories integrated (forward + inverse-L)
+        flops = run * (w['L'] * 4 * DK + 2 * DK) / iters
+        flops_counted = (agg[3] * 4 * DK + agg[2] * 2 * DK) / iters
         tf = flops / (kern_it_ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+                'counted': {'achieved': flops_counted / (kern_it_ms * 1e-3) / 1e12, 'frac': flops_counted / (kern_it_ms * 1e-3) / 1e12 / peak,
+                            'flops_per_launch': flops_counted},
                 'traffic': measured_traffic(key, 1) if full_shape else None,
                 'kernel': ('pot64_jump_kernel+pot64_flf_kernel' if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
                            'pot_jump_kernel+pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel+sic_flf_kernel'),
@@ -501,7 +510,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         if w['kind'] == 'pot' and w['dtype'] == 'float64':
             # the float64-state kernel streams the position through a working copy once per leapfrog step:
             # 8 B read + 8 B written per element and gradient evaluation, by design -- part of what this kernel has to move
-            wc = 16.0 * w['D'] * agg[3] / iters
+            wc = 16.0 * w['D'] * run * w['L'] / iters
             roof['hbm']['working_copy_bytes_per_launch'] = wc
             roof['hbm']['algorithmic_bytes_per_launch'] += wc
             roof['hbm']['achieved'] = roof['hbm']['algorithmic_bytes_per_launch'] / (kern_it_ms * 1e-3) / 1e9
@@ -509,7 +518,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
             # one pass over the 512 KB dictionary per leapfrog step of a 32-particle tile, plus two per trajectory (the
             # residual at its head, the closing half kick): L + 2 passes per L gradient evaluations, out of L2 (the
             # dictionary cannot stay in a CU).
-            tile_grads = agg[3] / 32.0 / iters
+            tile_grads = run * w['L'] / 32.0 / iters
             l2 = tile_grads * (w['L'] + 2.0) / w['L'] * 512 * 1024 / (kern_it_ms * 1e-3) / 1e9
             roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS}
             # The bound the 32-column tile sets: every leapfrog step streams the whole dictionary out of L2 for
@@ -574,7 +583,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
                    'L': w['L'], 'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
                    'particles_x_L_per_s': n_rank * world * w['L'] * iters / elapsed,
                    'L_move_fraction': agg[0] / moves, 'F_move_fraction': agg[4] / moves, 'R_move_fraction': agg[5] / moves,
-                   'cold_fraction': cold_frac},
+                   'cold_fraction': cold_frac, 'inverse_L_run_fraction': agg[6] / moves},
         'roofline': roof,
         'device': device,
     }
@@ -613,7 +622,7 @@ def compact(rec):
     """One workload's record as the printed line carries it (numbers only; the full record goes to --detail)."""
     r = rec['roofline']
     roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms') if k in r}
-    for sub in ('l2_stream', 'l2', 'lds', 'one_iteration_per_launch'):
+    for sub in ('l2_stream', 'l2', 'lds', 'one_iteration_per_launch', 'counted'):
         if sub in r:
             roof[sub + '_frac'] = r[sub]['frac']
     if 'frac_at_held_clock' in r:
@@ -621,6 +630,7 @@ def compact(rec):
     c = rec['config']
     out = {'value': rec['value'], 'ms_per_step': rec['ms_per_step'], 'steps': rec.get('steps'), 'roofline': roof,
            'lfr': [c['L_move_fraction'], c['F_move_fraction'], c['R_move_fraction']], 'cold': c['cold_fraction'],
+           'inv_run': c['inverse_L_run_fraction'],
            'n': c['nparticles_per_gpu']}
     d = rec.get('device') or {}
     if d.get('sclk_mhz'):
@@ -1000,6 +1010,8 @@ def main(argv=None):
             flat['%s_ms' % k] = v['ms_per_step']
             flat['%s_frac' % k] = r['frac']
             flat['%s_bound' % k] = r['bound']
+            if 'counted' in r:
+                flat['%s_frac_counted' % k] = r['counted']['frac']
             if 'l2_stream' in r:
                 flat['%s_l2stream_frac' % k] = r['l2_stream']['frac']
                 flat['%s_l2_frac' % k] = r['l2']['frac']
@@ -1026,6 +1038,8 @@ def main(argv=None):
                                             'traffic_over_algorithmic', 'frac_at_held_clock') if k in hr},
             'timing': {k: h[k] for k in ('ms_per_step_median', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'timed_s')},
         }
+        if 'counted' in hr:     # the reference's evaluation count / time (it integrates the F-movers' inverse-L proposals too)
+            out['roofline']['frac_counted'] = hr['counted']['frac']
         if 'cpu_baseline' in h:
             b = h['cpu_baseline']
             out['cpu_baseline'] = {'value': b['value'], 'unit': b['unit'], 'cores': b['cores'], 'kind': b['kind'],

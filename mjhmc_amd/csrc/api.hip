@@ -33,7 +33,7 @@ static int pow2ceil(int v) {
 }
 
 // The A/B switches of the measurement tools and of the launch-strategy tests (MJHMC_NO_FUSE, MJHMC_NO_COMPACT,
-// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
+// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_FUSE_BELOW, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
 // MJHMC_SIC_COPIES) and the failure-placing hook MJHMC_DEBUG_POISON exist only in libmjhmc_hip_test.so (built with
 // -DMJHMC_TEST_HOOKS, `make test_hooks`).  The shipped library consults no environment variable on the sampling path:
 // the only ones it reads at all name libraries to dlopen (MJHMC_RCCL_LIB; hipRTC / hipFFT by their sonames).
@@ -1461,6 +1461,9 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   return 0;
 }
 
+// batches of the non-Gaussian elementwise energies below this many particles run fused (tools/sweep_shard_c4.py)
+constexpr int64_t kFuseBelow = 16384;
+
 template <typename T>
 static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                      const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done,
@@ -1468,7 +1471,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // Fused launches: always for the Gaussian forces (one iteration is HBM-bound), for the other elementwise energies
   // while the batch is small (launch-/latency-bound) -- big batches of those take the compacted passes below instead.
   const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
-  const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || s->N < 16384 || s->D <= 4);
+  int64_t fuse_below = kFuseBelow;
+  if (const char* fb = test_env("MJHMC_FUSE_BELOW")) fuse_below = std::atoll(fb);
+  const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || s->N < fuse_below || s->D <= 4);
   if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !test_env("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);

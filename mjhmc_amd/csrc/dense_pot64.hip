@@ -91,11 +91,13 @@ __device__ __forceinline__ void tile_load_narrow(const double* lrow, Tile<NB>& t
   }
 }
 
+constexpr int kPark = 8;   // momentum elements per lane that sit out the GEMM loops in LDS (see pot64_trajectory)
 template <int NB>
 struct Shared64 {
   Shared<NB> s;
   double red64[4][kP];
   double zn[128 * NB];   // the float64 standard normals of one refreshing column (column_normals)
+  f32x4 park[kPark / 2][256];
 };
 
 // The wave's working copy of its X and V elements between the passes of a trajectory, in the workgroup's scratch
@@ -182,8 +184,8 @@ struct VTile {
 // Every product is rounded before its sum (the library is built with -ffp-contract=off): NumPy's V += c * g.
 template <int NB, int NKICK, bool FIRST, int XDST>
 __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double* xin, const double* vin, double* xout,
-                                                const Tile<NB>& g, VTile<NB>& v, double c, double eps, PubWave<NB>& pub,
-                                                int lane, bool neg = false) {
+                                                const Tile<NB>& g, VTile<NB>& v, double c, double eps, PubWave<NB>* pub0,
+                                                int w, int lane, bool neg = false) {
   using DV = typename DVecN<NB>::type;
   DV xa[4], xb[4], va[4], vb[4];   // (va, vb: the first pass only)
   auto load4 = [&](int q4, DV(&x)[4], DV(&vv)[4]) {
@@ -232,8 +234,20 @@ __device__ __forceinline__ void kick_drift_pass(const Work<NB>& wk, const double
       if constexpr (XDST == kXWork) wk_store<NB>(wk, wk.xb, q, x[qq]);
       else if constexpr (XDST == kXRows) dv_store<NB>(xout, q, x[qq]);
     }
+    if constexpr (NB == 4) {
+      // this lane's slot of the X image, formed from the working copy's lane offset (which every load and store of the
+      // pass holds in a register anyway): voff = w * 32 KB + lane * 16 -> w * 16 KB + lane * 16.  As a loop-invariant
+      // address it was one more value held -- in scratch -- across the GEMM loops, and its reload in front of the first
+      // publish of a pass stood behind an s_waitcnt vmcnt(0) that drained the pass's loads.
+      unsigned off = ((wk.voff >> 1) & 0xFFFFC000u) | (wk.voff & 0x3FFu);
+      asm volatile("" : "+v"(off));
+      char* img = reinterpret_cast<char*>(pub0) + off;
 #pragma unroll
-    for (int r = 0; r < NB; ++r) pub.v[r][q4][lane] = px[r];
+      for (int r = 0; r < NB; ++r) *reinterpret_cast<f32x4*>(img + (size_t)(r * 4 + q4) * 1024) = px[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < NB; ++r) pub0[w].v[r][q4][lane] = px[r];
+    }
   };
   // (Measured: all four kick4 first, in the shadow of the first X loads, then the drifts -- more registers live across
   // the pass, 119 -> 283 spilled, C3 in this arithmetic 17.6 -> 18.7 ms.)
@@ -288,21 +302,50 @@ __device__ __forceinline__ double column_sum(SH& sh, int w, int c, int h, double
 // point's position is in the rows xout (XLAST = kXRows; kXNone: not wanted; neg: start from -V, the F of F L F), its momentum in v, g holds its dE/dX (float32), *ex its
 // energy (float32, from the last gradient's u), and the return value is its kinetic energy sum(V^2) / 2 (all lanes of
 // column c).
-template <int NB, int XLAST>
+template <int NB, int XLAST, class XOut>
 __device__ __forceinline__ double pot64_trajectory(const PotModel& mdl, AReg<NB>& ar, Shared64<NB>& sh, int w, int c, int h,
                                                    int lane, const Work<NB>& wk, const double* xin, const double* vin,
-                                                   double* xout, Tile<NB>& g, VTile<NB>& v, int L, double eps, double chalf,
+                                                   const XOut& xout_of, Tile<NB>& g, VTile<NB>& v, int L, double eps, double chalf,
                                                    float* ex, bool neg) {
-  PubWave<NB>& pub = sh.s.pub[0][w];
-  if (L == 1) kick_drift_pass<NB, 1, true, XLAST>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane, neg);
-  else kick_drift_pass<NB, 1, true, kXWork>(wk, xin, vin, xout, g, v, chalf, eps, pub, lane, neg);
+  // xout_of(): the rows that take the end point's position, formed only where the last drift needs them (an address
+  // held across the GEMM loops and the streamed passes is two registers the kernel does not have)
+  PubWave<NB>* pub0 = sh.s.pub[0];   // the X images of the four waves (this wave's: pub0[w])
+  if (L == 1) kick_drift_pass<NB, 1, true, XLAST>(wk, xin, vin, xout_of(), g, v, chalf, eps, pub0, w, lane, neg);
+  else kick_drift_pass<NB, 1, true, kXWork>(wk, xin, vin, nullptr, g, v, chalf, eps, pub0, w, lane, neg);
   for (int s = 0; s < L; ++s) {
     [[maybe_unused]] const int stamp_slot = s;
     POT_STAMP(0);
+    // The momentum (32 NB registers) is not touched by the gradient, whose GEMM loops run at the register budget: the
+    // allocator spills a few of its elements across them and reloads them inside the streamed pass, where a scratch
+    // reload is a counted load whose wait drains the pass's own loads.  A few elements sit the gradient out in LDS
+    // instead (lane-linear, conflict-free; an LDS wait drains nothing).
+    if constexpr (NB == 4) {
+#pragma unroll
+      for (int k = 0; k < kPark / 2; ++k) {
+        f64x2 two;
+        two[0] = v.b[NB - 1][15 - 2 * k];
+        two[1] = v.b[NB - 1][14 - 2 * k];
+        sh.park[k][threadIdx.x] = __builtin_bit_cast(f32x4, two);
+      }
+    }
     pot_gradient_published<NB>(mdl, ar, sh.s, w, c, h, lane, g, s == L - 1, ex, s);
+    if constexpr (NB == 4) {
+#pragma unroll
+      for (int k = 0; k < kPark / 2; ++k) {
+        const f64x2 two = __builtin_bit_cast(f64x2, sh.park[k][threadIdx.x]);
+        v.b[NB - 1][15 - 2 * k] = two[0];
+        v.b[NB - 1][14 - 2 * k] = two[1];
+      }
+      // (whatever the allocator still keeps of the momentum in scratch across the GEMM loops comes back HERE, in front of
+      // the pass's loads, not between them)
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) use_here(v.b[r][q]);
+    }
     POT_STAMP(6);
-    if (s < L - 2) kick_drift_pass<NB, 2, false, kXWork>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
-    else if (s == L - 2) kick_drift_pass<NB, 2, false, XLAST>(wk, nullptr, nullptr, xout, g, v, chalf, eps, pub, lane);
+    if (s < L - 2) kick_drift_pass<NB, 2, false, kXWork>(wk, nullptr, nullptr, nullptr, g, v, chalf, eps, pub0, w, lane);
+    else if (s == L - 2) kick_drift_pass<NB, 2, false, XLAST>(wk, nullptr, nullptr, xout_of(), g, v, chalf, eps, pub0, w, lane);
     POT_STAMP(7);
   }
   const double part = closing_kick<NB>(g, v, chalf);
@@ -321,7 +364,7 @@ __global__ void pot64_cold_list_kernel(const double* __restrict__ Hflf_in, const
   append_cold(list, count, (p < N) && !(hc == hc) && !(hs == hs), p);
 }
 
-// what the kernels that only FINISH a move need of Shared64 (pot64_fix_kernel)
+// what the kernel that only DECIDES and finishes the moves needs of Shared64 (pot64_decide_kernel)
 template <int NB>
 struct Finish64Shared {
   struct {
@@ -332,7 +375,7 @@ struct Finish64Shared {
 };
 
 // The successor's rows once the moves of a tile's columns stand in sh.s.move.  FIX = false (jump kernel): the end point's
-// position is in the output rows, its momentum in v, its dE/dX in g.  FIX = true (pot64_fix_kernel): columns that keep the
+// position is in the output rows, its momentum in v, its dE/dX in g.  FIX = true (pot64_decide_kernel): columns that keep the
 // end point are finished already (v, g unused); only the others are touched.  roff: this lane's elements of its column's row.
 template <int NB, bool REPLAY, int MODE, bool FIX, class SH>
 __device__ __forceinline__ void pot64_finish(const Pot64JumpArgs& a, SH& sh, int64_t p, bool alive, size_t roff, int w, int c,
@@ -501,37 +544,52 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
     *a.zero_count = 0;   // the list two iterations back is consumed: its counter is free for the next iteration's appends
     if (ncold) atomicAdd(&a.stats[3], (unsigned long long)ncold << 32);   // integrated here: the high half of the cold tally
   }
-  unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // tallies (meaning per mode: fill_iter_stats in api.hip)
-  bool any_bad = false;
+  // tallies (meaning per mode: fill_iter_stats in api.hip) and the failure flag live in LDS, not in registers that would be
+  // live across every GEMM loop and streamed pass of the kernel: [0..3] counts, [4] some particle met a non-finite rate
+  __shared__ unsigned tally[5];
+  if (threadIdx.x < 5) tally[threadIdx.x] = 0;
   AReg<NB> ar;
   areg_load<NB>(mdl, w, c, h, ar);
   stage_bias<NB>(mdl, sh.s);
   const Work<NB> wk = work_of<NB>(a.scratch, blockIdx.x, w, lane);
   for (int64_t item = blockIdx.x; item < nft + a.ntiles; item += gridDim.x) {
     const bool inverse = item < nft;   // (uniform over the workgroup)
-    int64_t p;
-    if (inverse) {
-      const int64_t slot = item * kP + c;
-      p = a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
-    } else {
-      p = (item - nft) * kP + c;
-    }
-    const bool alive = p < a.N;
+    auto column_of = [&](int64_t it) -> int64_t {
+      if (it < nft) {
+        const int64_t slot = it * kP + c;
+        return a.cold_list[slot < ncold ? slot : ncold - 1];  // pad the last tile with a repeat
+      }
+      return (it - nft) * kP + c;
+    };
     // (everything that is not needed during the trajectory -- the scalars of the decision, the output rows' addresses --
     // is fetched / formed after it: the kernel sits at its 512-register budget, and what is live across the GEMM loops
-    // and the streamed passes decides whether those spill; tools/check_isa.sh gates both)
-    const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;   // this lane's elements inside a [*][DIM] matrix
-    // the end point's position: into the output rows -- an inverse-L item's is wanted by nobody: into the second half of
-    // the workgroup's working rows (32 rows, the momentum's would-be working copy: unused)
-    double* xend = inverse ? a.scratch + (size_t)blockIdx.x * (Work<NB>::kArea) + Work<NB>::kArea / 2 +
-                                 (size_t)c * (128 * NB) + 32 * NB * w + 4 * NB * h
-                           : a.X_out + roff;
+    // and the streamed passes decides whether those spill; tools/check_isa.sh gates both.  That includes the column's own
+    // index: it is looked up again behind the trajectory, through an item number the compiler cannot see through)
     Tile<NB> g;
     VTile<NB> v;
-    tile_load_narrow<NB>(a.G_in + roff, g);
     float exl = 0.f;
-    const double EVL = pot64_trajectory<NB, kXRows>(mdl, ar, sh, w, c, h, lane, wk, a.X_in + roff, a.V_in + roff, xend, g, v,
-                                                    a.L, a.eps, a.chalf, &exl, inverse);
+    double EVL;
+    {
+      const int64_t p = column_of(item);
+      const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;   // this lane's elements inside a [*][DIM] matrix
+      // the end point's position: into the output rows -- an inverse-L item's is wanted by nobody: into the second half of
+      // the workgroup's working rows (32 rows, the momentum's would-be working copy: unused)
+      auto xend = [&]() -> double* {
+        int64_t it = item;
+        asm volatile("" : "+s"(it));
+        const size_t lane_part = 32 * NB * w + 4 * NB * h;
+        return it < nft ? a.scratch + (size_t)blockIdx.x * (Work<NB>::kArea) + Work<NB>::kArea / 2 + (size_t)c * (128 * NB) + lane_part
+                        : a.X_out + (size_t)column_of(it) * (128 * NB) + lane_part;
+      };
+      tile_load_narrow<NB>(a.G_in + roff, g);
+      EVL = pot64_trajectory<NB, kXRows>(mdl, ar, sh, w, c, h, lane, wk, a.X_in + roff, a.V_in + roff, xend, g, v, a.L, a.eps,
+                                         a.chalf, &exl, inverse);
+    }
+    int64_t item_again = item;
+    asm volatile("" : "+s"(item_again));
+    const int64_t p = column_of(item_again);
+    const bool alive = p < a.N;
+    const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;
     const double EXL = (double)exl;
     const double HL = EXL + EVL;
     if (inverse) {
@@ -540,59 +598,142 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
       continue;
     }
 
-    // lanes 0..31 of wave 0, one particle each
+    if constexpr (MODE == kModeMJHMC) {
+      // the jump process itself -- rates, clocks, first minimum, the successor of a move that is not L -- belongs to
+      // pot64_decide_kernel, which runs when this launch's inverse-L items are done too: here the end point of L is
+      // written as if taken (position: by the last drift), with its energies
+      if (w == 0 && h == 0) {
+        a.EX_out[p] = EXL;
+        a.EV_out[p] = EVL;
+      }
+      using DV = typename DVecN<NB>::type;
+      double* vo = a.V_out + roff;
+      double* go = a.G_out + roff;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        DV vv, gg;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          dset<NB>(vv, r, v.b[r][q]);
+          dset<NB>(gg, r, (double)g.b[r][q]);
+        }
+        dv_store<NB>(vo, q, vv);
+        dv_store<NB>(go, q, gg);
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // the discrete-time and continuous-time control samplers decide here: lanes 0..31 of wave 0, one particle each
     if (w == 0 && h == 0) {
       const int64_t pp = alive ? p : 0;
       const uint32_t pid = (uint32_t)(a.first_pid + pp);
       const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
       const double H0 = EX0 + EV0;
-      // H of the inverse-L proposal: cached; or the L proposal of the iteration in which the particle flipped; or being
-      // integrated by an inverse-L item of this very launch -- then the particle is left pending for pot64_fix_kernel
-      double Hflf = MODE == kModeMJHMC ? a.Hflf_in[p] : 0.0;
-      const bool cold = !(Hflf == Hflf);
-      bool pending = false;
-      if (cold) {
-        Hflf = a.Hspec_in[p];
-        pending = !(Hflf == Hflf);
-      }
       double best = 0.0;
       bool bad = false, gate = false;
-      int k = 0;
-      if (!pending) {
-        k = pot64_decide<REPLAY, MODE>(a, H0, HL, Hflf, pp, pid, best, bad, gate);
-        any_bad |= (bad && alive);
-        // every move but L clears the cache; of those only the R-movers need their inverse-L proposal integrated
-        if constexpr (MODE == kModeMJHMC) append_cold(a.next_list, a.next_count, alive && k == 2, p);
-        a.dwell[p] = best;
-        a.dwell_ring[p] = best;
-        a.trans[p] = (uint8_t)k;
-      }
+      const int k = pot64_decide<REPLAY, MODE>(a, H0, HL, 0.0, pp, pid, best, bad, gate);
+      if (bad && alive) tally[4] = 1;
+      a.dwell[p] = best;
+      a.dwell_ring[p] = best;
+      a.trans[p] = (uint8_t)k;
       sh.s.move[c] = k | (gate ? 4 : 0);
-      if (alive) {
+      {
+        // one LDS atomic per tally and tile (the 32 deciding lanes of wave 0)
+        unsigned long long b0, b1, b2, b3 = 0ull;
         if constexpr (MODE == kModeControl) {  // l_count, f_count, R applied, fl_count (markov_jump_hmc.py:143-148)
-          n0 += (k == 3);
-          n1 += (k == 2);
-          n2 += gate ? 1u : 0u;
-          n3 += (k == 1);
-        } else if (!pending) {
-          n0 += (k == 0);
-          n1 += (k == 1);
-          n2 += (k == 2);
+          b0 = __ballot(alive && k == 3);
+          b1 = __ballot(alive && k == 2);
+          b2 = __ballot(alive && gate);
+          b3 = __ballot(alive && k == 1);
+        } else {
+          b0 = __ballot(alive && k == 0);
+          b1 = __ballot(alive && k == 1);
+          b2 = __ballot(alive && k == 2);
         }
-        if constexpr (MODE == kModeMJHMC) n3 += cold;   // the reference integrates F L F for every one of these
+        if (c == 0) {
+          if (b0) atomicAdd(&tally[0], (unsigned)__popcll(b0));
+          if (b1) atomicAdd(&tally[1], (unsigned)__popcll(b1));
+          if (b2) atomicAdd(&tally[2], (unsigned)__popcll(b2));
+          if (b3) atomicAdd(&tally[3], (unsigned)__popcll(b3));
+        }
       }
       // scalars of the successors that keep or take whole states; a refreshed kinetic energy is filled in below
       const bool took_L = MODE == kModeControl ? (k & 1) : (k == 0);
       a.EX_out[p] = took_L ? EXL : EX0;
       a.EV_out[p] = took_L ? EVL : EV0;
-      if (!pending) {
-        a.Hflf_out[p] = (MODE == kModeMJHMC && k == 0) ? H0 : __builtin_nan("");
-        if constexpr (MODE == kModeMJHMC) a.Hspec_out[p] = (k == 1) ? HL : __builtin_nan("");
-      }
+      a.Hflf_out[p] = __builtin_nan("");
     }
     __syncthreads();
     pot64_finish<NB, REPLAY, MODE, false>(a, sh, p, alive, roff, w, c, h, v, g);
     __syncthreads();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && tally[4]) {
+    a.ctl->failed = 1;
+    a.ctl->failed_iter = a.iter;
+  }
+  if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
+// MarkovJumpHMC's jump process for every particle (markov_jump_hmc.py:366-415), once both trajectories of the iteration
+// are done -- the L proposal in the output rows with its energies in EX_out / EV_out, H of the inverse-L proposal cached
+// (H_flf), handed on by the F move of the iteration before (Hspec) or integrated by this iteration's launch (Hwork):
+// rates, clocks, first minimum, counters, the next iteration's list, and where the move is not L the pre-move position
+// and dE/dX put back and the momentum flipped / redrawn (pot_decide_kernel's twin).
+template <int NB, bool REPLAY>
+__global__ __launch_bounds__(256) void pot64_decide_kernel(const Pot64JumpArgs a) {
+  __shared__ Finish64Shared<NB> sh;
+  if (a.ctl->failed) return;
+  const int w = threadIdx.x >> 6, c = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
+  unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+  bool any_bad = false;
+  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t p = tile * kP + c;
+    const bool alive = p < a.N;
+    if (w == 0 && h == 0) {
+      const int64_t pp = alive ? p : 0;
+      const uint32_t pid = (uint32_t)(a.first_pid + pp);
+      const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+      const double H0 = EX0 + EV0;
+      const double HL = a.EX_out[p] + a.EV_out[p];
+      double Hflf = a.Hflf_in[p];
+      const bool cold = !(Hflf == Hflf);
+      if (cold) {
+        Hflf = a.Hspec_in[p];                      // the L proposal of the iteration in which the particle flipped ...
+        if (!(Hflf == Hflf)) Hflf = a.Hwork[p];    // ... or integrated by an inverse-L item of this iteration's launch
+      }
+      double best = 0.0;
+      bool bad = false, gate = false;
+      const int k = pot64_decide<REPLAY, kModeMJHMC>(a, H0, HL, Hflf, pp, pid, best, bad, gate);
+      sh.s.move[c] = alive ? k : 0;
+      any_bad |= bad && alive;
+      // every move but L clears the cache; of those only the R-movers need their inverse-L proposal integrated
+      append_cold(a.next_list, a.next_count, alive && k == 2, p);
+      a.dwell[p] = best;
+      a.dwell_ring[p] = best;
+      a.trans[p] = (uint8_t)k;
+      if (alive) {
+        n0 += (k == 0);
+        n1 += (k == 1);
+        n2 += (k == 2);
+        n3 += cold;   // the reference integrates F L F for every one of these
+      }
+      if (k != 0) {
+        a.EX_out[p] = EX0;
+        a.EV_out[p] = EV0;   // (an R-mover's: filled in by pot64_finish)
+      }
+      a.Hflf_out[p] = k == 0 ? H0 : __builtin_nan("");
+      a.Hspec_out[p] = k == 1 ? HL : __builtin_nan("");
+    }
+    __syncthreads();
+    if (__syncthreads_or(sh.s.move[c] != 0)) {   // (a tile of L-movers is finished already)
+      const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;
+      VTile<NB> v;   // (unused: FIX)
+      Tile<NB> g;
+      pot64_finish<NB, REPLAY, kModeMJHMC, true>(a, sh, p, alive, roff, w, c, h, v, g);
+      __syncthreads();
+    }
   }
   if (any_bad) {
     a.ctl->failed = 1;
@@ -607,69 +748,6 @@ __global__ __launch_bounds__(256, 1) void pot64_jump_kernel(const Pot64JumpArgs 
   if (n3) atomicAdd(&tally[3], n3);
   __syncthreads();
   if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
-}
-
-// The particles the jump kernel left pending (this iteration's list): decide them now that both of their trajectories
-// are done, and where the move is not L put the pre-move position and dE/dX back and flip / redraw the momentum
-// (pot_fix_kernel's twin)
-template <int NB, bool REPLAY>
-__global__ __launch_bounds__(256) void pot64_fix_kernel(const Pot64JumpArgs a) {
-  __shared__ Finish64Shared<NB> sh;
-  if (a.ctl->failed) return;
-  const int ncold = *a.cold_count;
-  if ((int64_t)blockIdx.x * kP >= ncold) return;
-  const int w = threadIdx.x >> 6, c = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
-  unsigned n0 = 0, n1 = 0, n2 = 0;
-  bool any_bad = false;
-  for (int64_t tile = blockIdx.x; tile * kP < ncold; tile += gridDim.x) {
-    const int64_t slot = tile * kP + c;
-    const bool valid = slot < ncold;    // the last tile repeats an entry: those columns do nothing
-    const int64_t p = a.cold_list[valid ? slot : ncold - 1];
-    if (w == 0 && h == 0) {
-      const uint32_t pid = (uint32_t)(a.first_pid + p);
-      const double EX0 = a.EX_in[p], EV0 = a.EV_in[p];
-      const double H0 = EX0 + EV0;
-      const double HL = a.EX_out[p] + a.EV_out[p];
-      double best = 0.0;
-      bool bad = false, gate = false;
-      const int k = pot64_decide<REPLAY, kModeMJHMC>(a, H0, HL, a.Hwork[p], p, pid, best, bad, gate);
-      sh.s.move[c] = valid ? k : 0;
-      if (valid) {
-        any_bad |= bad;
-        append_cold(a.next_list, a.next_count, k == 2, p);
-        a.dwell[p] = best;
-        a.dwell_ring[p] = best;
-        a.trans[p] = (uint8_t)k;
-        n0 += (k == 0);
-        n1 += (k == 1);
-        n2 += (k == 2);
-        if (k != 0) {
-          a.EX_out[p] = EX0;
-          a.EV_out[p] = EV0;   // (an R-mover's: filled in by pot64_finish)
-        }
-        a.Hflf_out[p] = k == 0 ? H0 : __builtin_nan("");
-        a.Hspec_out[p] = k == 1 ? HL : __builtin_nan("");
-      }
-    }
-    __syncthreads();
-    const size_t roff = (size_t)p * (128 * NB) + 32 * NB * w + 4 * NB * h;
-    VTile<NB> v;   // (unused: FIX)
-    Tile<NB> g;
-    pot64_finish<NB, REPLAY, kModeMJHMC, true>(a, sh, p, true, roff, w, c, h, v, g);
-    __syncthreads();
-  }
-  if (any_bad) {
-    a.ctl->failed = 1;
-    a.ctl->failed_iter = a.iter;
-  }
-  __shared__ unsigned tally[3];
-  if (threadIdx.x < 3) tally[threadIdx.x] = 0;
-  __syncthreads();
-  if (n0) atomicAdd(&tally[0], n0);
-  if (n1) atomicAdd(&tally[1], n1);
-  if (n2) atomicAdd(&tally[2], n2);
-  __syncthreads();
-  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
 static int resident_cus64() {
@@ -701,8 +779,8 @@ static void launch64_nb(const Pot64JumpArgs& a, const PotModel& mdl, hipStream_t
     const unsigned grid = (unsigned)std::min<int64_t>(2 * a.ntiles, cus);
     launch64_mode<NB, kModeMJHMC>(a, mdl, grid, st);
     const unsigned fgrid = (unsigned)std::min<int64_t>(a.ntiles, 4 * cus);
-    if (a.rexp && a.noise) hipLaunchKernelGGL((pot64_fix_kernel<NB, true>), dim3(fgrid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((pot64_fix_kernel<NB, false>), dim3(fgrid), dim3(256), 0, st, a);
+    if (a.rexp && a.noise) hipLaunchKernelGGL((pot64_decide_kernel<NB, true>), dim3(fgrid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pot64_decide_kernel<NB, false>), dim3(fgrid), dim3(256), 0, st, a);
   } else {
     const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, cus);
     if (a.mode == kModeCT) launch64_mode<NB, kModeCT>(a, mdl, grid, st);

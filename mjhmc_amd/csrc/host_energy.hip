@@ -875,6 +875,7 @@ int traj_finish_impl(mjhmc_sampler* s, const double* replay_normal, const double
 int multipass_rollback(mjhmc_sampler* s) {
   HostTraj* t = s->ht;
   if (!t) return mjhmc_fail(MJHMC_ERR_INVALID, "nothing to roll back");
+  HIPCHK(hipSetDevice(s->ctx->device));   // (a process may hold contexts on several devices)
   hipLaunchKernelGGL(hk_undo, dim3((unsigned)s->N), dim3(64), 0, s->stream, (double*)s->Xcur, (double*)s->Vbuf[s->vcur],
                      (double*)s->Gbuf[s->vcur], (double*)s->EX[s->scur], (double*)s->EV[s->scur], (double*)s->Hflf[s->scur],
                      (const double*)t->X, (const double*)t->V, (const double*)t->G, (const double*)t->hnew, s->N, s->Npad, s->D,

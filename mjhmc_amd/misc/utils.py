@@ -25,17 +25,21 @@ def min_idx(draws, device=0):
 
 def draw_from(rates, device=0):
     """Draws from exponential distributions with the given rates, shape (1, len(rates)) (utils.py:31-50): inf where a
-    rate is zero; a non-finite rate raises ValueError.  np.random's stream is consumed exactly as the reference
-    consumes it -- one standard exponential per finite non-zero rate, in order, up to the first non-finite one --
-    and the draws are bit-identical to np.random.exponential(scale=1. / rate)."""
+    rate is zero; a non-finite rate raises ValueError, and so does a negative one (np.random.exponential's own
+    "scale < 0", which is what the reference's loop runs into).  np.random's stream is consumed exactly as the
+    reference consumes it -- one standard exponential per finite non-zero rate, in order, up to the first rate that
+    raises -- and the draws are bit-identical to np.random.exponential(scale=1. / rate)."""
     rates = np.asarray(rates, dtype=np.float64)
     assert rates.ndim == 1
     finite = np.isfinite(rates)
-    stop = int(np.argmin(finite)) if not finite.all() else rates.size       # the reference raises there
+    raises = ~finite | (rates < 0)
+    stop = int(np.argmax(raises)) if raises.any() else rates.size           # the reference raises there
     takes = finite & (rates != 0)
     takes[stop:] = False
     e = np.zeros(rates.size)
     e[takes] = np.random.standard_exponential(int(takes.sum()))
+    if stop < rates.size and finite[stop]:
+        raise ValueError('scale < 0')                                       # numpy's message for exponential(scale=1 / rate), rate < 0
     out, first_bad = engine.context(device).draw_from(rates, e)
     if first_bad >= 0:
         raise ValueError("Infinite rate. This occurs when calculating transition rates "

@@ -217,7 +217,7 @@ def test_tf_distributions_import_path():
     assert bits_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize('what', ['iso', 'iso_wide', 'pot32', 'pot64', 'pot64_L0', 'host'])
+@pytest.mark.parametrize('what', ['iso', 'iso_wide', 'iso_wide32', 'pot32', 'pot64', 'pot64_L0', 'host'])
 def test_rollback_undoes_a_committed_single_iteration(what):
     """mjhmc_rollback (include/mjhmc_hip.h): after mjhmc_iterate(1) committed, the pre-move state comes back bit for bit
     -- by flipping the ping-pong parities (register / tile kernels) or by copying back the rows the multi-pass commit
@@ -229,9 +229,10 @@ def test_rollback_undoes_a_committed_single_iteration(what):
     rs = np.random.RandomState(3)
     L = 4
     if what.startswith('iso'):
-        D, N = (1030, 50) if what == 'iso_wide' else (24, 200)
+        D, N = (1030, 50) if what.startswith('iso_wide') else (24, 200)
         en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.3])
-        s = engine.DeviceSampler(en, rs.randn(D, N), seed=5)
+        # iso_wide32: float32 state on rows only the multi-pass path holds (a float64 sampler rounding its state, Shape::round32)
+        s = engine.DeviceSampler(en, rs.randn(D, N), seed=5, dtype='float32' if what == 'iso_wide32' else 'float64')
     elif what.startswith('pot'):
         D, N = 36, 100
         W, lognu = ref_init_weights(D, D)

@@ -73,3 +73,23 @@ def test_draw_from_raises_like_the_reference_and_leaves_the_stream_where_it_does
     with pytest.raises(ValueError, match='Infinite rate'):
         draw_from(rates)
     assert np.random.random() == after_ref
+
+
+def test_draw_from_negative_rate_raises_numpys_error_at_the_reference_position():
+    """np.random.exponential(scale=1 / rate) with rate < 0 raises ValueError('scale < 0') inside the reference's loop
+    (utils.py:31-49), after the draws of the rates in front of it."""
+    from mjhmc_amd.misc.utils import draw_from
+    rates = np.array([0.5, 0.0, 2.0, -1.0, 3.0, np.inf])
+    np.random.seed(9)
+    with pytest.raises(ValueError, match='scale < 0'):
+        draw_from(rates)
+    after = np.random.standard_exponential()
+    np.random.seed(9)
+    with pytest.raises(ValueError, match='scale < 0'):
+        for r in rates:                       # the reference's loop
+            if r == 0:
+                continue
+            if not np.isfinite(r):
+                raise ValueError('Infinite rate')
+            np.random.exponential(scale=1. / r)
+    assert after == np.random.standard_exponential()

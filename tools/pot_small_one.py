@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mjhmc_amd import engine, _lib
 ctx = engine.context(0)
