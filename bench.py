@@ -456,19 +456,27 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         t_b = time.perf_counter()
         smp.ring_read(0, n_s, stacked=False, out=ring)             # sample(..., out=preallocated)
         t_dl2 = time.perf_counter() - t_b
+        # what sample() does: every slot crosses PCIe while the following iterations run (mjhmc_iterate_download)
+        smp.iterate_download(n_s, 0, ring)                         # (first call: staging, pinned buffers, stream, thread)
+        t_b = time.perf_counter()
+        smp.iterate_download(n_s, 0, ring)
+        t_str = time.perf_counter() - t_b
         t_b = time.perf_counter()
         Xh = smp.read(_lib.F_X)
         smp.read(_lib.F_X, out=Xh)
         t_read2 = (time.perf_counter() - t_b) / 2
         del Xh
+        psteps = float(w['D']) * n_rank * w['L'] * n_s
         boundary = {'state_read_ms': t_read * 1e3, 'state_read_GBps': nbytes_host / t_read / 1e9,
                     'state_bytes_device': int(w['D']) * n_rank * esz, 'state_bytes_host_f64': int(nbytes_host),
                     'state_read_warm_GBps': nbytes_host / t_read2 / 1e9,
                     'sample10': {'iterate_ms': t_it * 1e3, 'download_ms': t_dl * 1e3, 'host_bytes': int(ring.nbytes),
                                  'download_GBps': ring.nbytes / t_dl / 1e9,
                                  'download_into_preallocated_GBps': ring.nbytes / t_dl2 / 1e9,
-                                 'particle_steps_per_s_incl_download': float(w['D']) * n_rank * w['L'] * n_s / (t_it + t_dl)},
-                    'what': 'host-buffer-inclusive (re-tile + PCIe) figures of the C-ABI boundary; never part of `value`'}
+                                 'iterate_then_download_particle_steps_per_s': psteps / (t_it + t_dl2),
+                                 'streamed_ms': t_str * 1e3,
+                                 'particle_steps_per_s_incl_download': psteps / t_str,
+                                 'incl_download_over_resident': t_it / t_str}}
         del ring
     smp.close()
     if rank != 0:

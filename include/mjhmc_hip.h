@@ -199,6 +199,16 @@ int mjhmc_set_hparams(mjhmc_sampler* s, double epsilon, int num_leapfrog_steps, 
 int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
                   const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done);
 
+/* The sample loop of HMCBase.sample / ContinuousTimeHMC.sample (markov_jump_hmc.py:150-173, 293-338: an iteration, then
+ * samples.append(state.copy().X)) with the copies crossing PCIe WHILE the following iterations run: mjhmc_iterate(n_iter,
+ * counter RNG, ring_slot0) plus, for every iteration i as soon as its kernels are done, ring slot ring_slot0 + i re-tiled
+ * and brought to host_out[:, (k0 + i) * N : (k0 + i + 1) * N] of a C-order float64 array (ndims, n_total * N) -- the layout
+ * of np.concatenate(samples, axis=1) -- by a second stream and a worker thread of the call.  Returns when the slots of the
+ * committed iterations are in host memory.  A ring smaller than the run (n_slots < n_total: n_total states exceed the
+ * device) is walked in several calls with growing k0.  per_iter / n_done / non-finite rates: as mjhmc_iterate. */
+int mjhmc_iterate_download(mjhmc_sampler* s, int n_iter, int ring_slot0, double* host_out, int64_t n_total, int64_t k0,
+                           mjhmc_iter_stats* per_iter, int* n_done);
+
 /* ---- energies only the caller can evaluate (MJHMC_E_HOST) ----------------------------------------------------------
  * LambdaDistribution(energy_func, energy_grad_func, init) takes two arbitrary Python callables (README.md:27-36,
  * mjhmc/misc/distributions.py:198-251).  When they match no built-in functor and are not stated as C expressions,
@@ -252,7 +262,12 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
 
 /* Sample ring for ContinuousTimeHMC.sample / HMCBase.sample (markov_jump_hmc.py:150-173,293-338):
  * n_slots snapshots of X (device resident) and of dwelling_times. */
-int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots);
+int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots);   /* (never shrinks; a request the device cannot hold fails with the
+                                                           sizes in mjhmc_last_error() and keeps the ring there was) */
+/* device bytes of one ring slot (a padded state matrix + its dwelling times); free / total device memory in bytes:
+ * what a caller sizes a sample ring by */
+int mjhmc_ring_slot_bytes(mjhmc_sampler* s, uint64_t* bytes);
+int mjhmc_mem_info(mjhmc_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 /* dwell of slots [slot0, slot0+n) -> (n, N) float64 */
 int mjhmc_ring_read_dwell(mjhmc_sampler* s, int slot0, int n, double* host_dst);
 /* out[:, k] = X_slot[idx[k] / N][:, idx[k] % N] for k < n, i.e. the column gather of

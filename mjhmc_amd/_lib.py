@@ -78,6 +78,10 @@ PROTOTYPES = {
     'mjhmc_read': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_size_t]),
     'mjhmc_write': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_size_t]),
     'mjhmc_ring_alloc': (ctypes.c_int, [_P, ctypes.c_int]),
+    'mjhmc_ring_slot_bytes': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
+    'mjhmc_mem_info': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    'mjhmc_iterate_download': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.POINTER(IterStats), ctypes.POINTER(ctypes.c_int)]),
     'mjhmc_ring_read_dwell': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
     'mjhmc_ring_gather': (ctypes.c_int, [_P, _P, ctypes.c_int64, _P]),
     'mjhmc_ring_read': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),

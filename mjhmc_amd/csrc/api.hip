@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -527,6 +529,135 @@ int download_cols(mjhmc_sampler* s, const void* src, const int64_t* dev_idx, int
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// mjhmc_iterate_download: samples cross PCIe WHILE the sampler iterates.
+// HMCBase.sample / ContinuousTimeHMC.sample (markov_jump_hmc.py:150-173, 293-338) append state.copy().X after every
+// iteration; here iteration i writes its X into ring slot ring_slot0 + i and, as soon as its kernels are done, a
+// worker thread of the call re-tiles that slot on a second stream into the reference's (ndims, particles) layout and
+// brings it to the caller's time-major array (pinned double buffer, host copy threads) -- beside iterations
+// i + 1, i + 2, ... on the sampler's own streams.  The launch code marks an iteration by recording an event on every
+// stream that runs part of it (dl_mark); the worker never reads a slot whose events have not completed.
+// ---------------------------------------------------------------------------------------------
+struct DlSession {
+  std::vector<std::vector<hipEvent_t>> ev;   // [iteration] the events that complete it
+  std::atomic<int> marked{0};                // iterations whose events are recorded
+  std::atomic<bool> launched{false};         // the iterate call has returned: nothing more will be marked
+  int n_iter = 0, ring_slot0 = 0;
+  double* host = nullptr;                    // (D, n_total * N) float64, time-major
+  int64_t n_total = 0, k0 = 0;
+  std::atomic<int> downloaded{0};            // slots [0, downloaded) are in the host array
+  std::vector<char> retiled;                 // [iteration] its slot already sits, in the host layout, in staging slot i (see dl_retile_in_stream)
+  int rc = 0;
+  std::string err;
+};
+
+// particle-major rows [start, start + ncols) of a state matrix -> columns [start, start + ncols) of the compact (D, N) float64
+// matrix `stage`: the reference's layout
+static int dl_retile(mjhmc_sampler* s, const void* rows0, int64_t start, int64_t ncols, double* stage, hipStream_t st) {
+  const char* src = (const char*)rows0 + (size_t)start * row_bytes(s);
+  dim3 grid((unsigned)((ncols + 31) / 32), (unsigned)((s->D + 31) / 32)), block(32, 8);
+  if (s->dtype == MJHMC_F64)
+    hipLaunchKernelGGL(to_dim_major<double>, grid, block, 0, st, (const double*)src, (const int64_t*)nullptr, stage, s->D, ncols,
+                       s->sh.pitch, s->N, (int64_t)1, start);
+  else if (s->dtype == MJHMC_BF16)
+    hipLaunchKernelGGL(to_dim_major<__bf16>, grid, block, 0, st, (const __bf16*)src, (const int64_t*)nullptr, stage, s->D, ncols,
+                       s->sh.pitch, s->N, (int64_t)1, start);
+  else
+    hipLaunchKernelGGL(to_dim_major<float>, grid, block, 0, st, (const float*)src, (const int64_t*)nullptr, stage, s->D, ncols,
+                       s->sh.pitch, s->N, (int64_t)1, start);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// called by the launch code once the kernels completing iterations [i0, i0 + n) of the call are queued
+static int dl_mark(mjhmc_sampler* s, int i0, int n, const hipStream_t* streams, int n_streams) {
+  DlSession* d = s->dl;
+  if (!d || i0 < d->marked.load(std::memory_order_acquire)) return 0;   // (a re-run after a failure rewrites marked slots with the same values)
+  for (int i = i0; i < i0 + n && i < d->n_iter; ++i) {
+    for (int k = 0; k < n_streams; ++k) {
+      hipEvent_t e = nullptr;
+      if (i == i0) {
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e, streams[k]));
+      } else {
+        e = d->ev[(size_t)i0][(size_t)k];    // iterations of one fused launch complete together
+      }
+      d->ev[(size_t)i].push_back(e);
+    }
+  }
+  d->marked.store(std::min(i0 + n, d->n_iter), std::memory_order_release);
+  return 0;
+}
+
+static int dl_download_slot(mjhmc_sampler* s, DlSession* d, int i) {
+  const size_t elems = (size_t)s->D * s->N;
+  const size_t bytes = elems * sizeof(double), row = (size_t)s->N * sizeof(double);
+  const void* src = (const char*)s->ring + (size_t)(d->ring_slot0 + i) * mat_bytes(s);
+  const bool retiled = d->retiled[(size_t)i] != 0;
+  const double* stage = retiled ? s->dl_stage + (size_t)i * elems : s->dl_stage;
+  if (!retiled) TRY(dl_retile(s, src, 0, s->N, s->dl_stage, s->dl_stream));
+  // compact (D, N) staging -> row d of the slot lands at host[(d * n_total + k0 + i) * N]; chunks through the pinned pair
+  char* host = (char*)d->host;
+  const size_t dst_row = (size_t)d->n_total * row, dst_off = (size_t)(d->k0 + i) * row;
+  const size_t nchunk = (bytes + kPipeChunk - 1) / kPipeChunk;
+  auto issue = [&](size_t k) -> int {
+    const size_t off = k * kPipeChunk, len = std::min(kPipeChunk, bytes - off);
+    HIPCHK(hipMemcpyAsync(s->dl_pin[k & 1], (const char*)stage + off, len, hipMemcpyDeviceToHost, s->dl_stream));
+    HIPCHK(hipEventRecord(s->dl_ev[k & 1], s->dl_stream));
+    return 0;
+  };
+  TRY(issue(0));
+  for (size_t k = 0; k < nchunk; ++k) {
+    if (k + 1 < nchunk) TRY(issue(k + 1));
+    HIPCHK(hipEventSynchronize(s->dl_ev[k & 1]));
+    const size_t off = k * kPipeChunk, len = std::min(kPipeChunk, bytes - off);
+    const char* pin = (const char*)s->dl_pin[k & 1];
+    // the chunk's bytes [off, off + len) of the compact matrix, row by row, over the copy threads
+    auto scatter = [=](size_t lo, size_t hi) {   // byte range of the chunk
+      size_t o = lo;
+      while (o < hi) {
+        const size_t g = off + o, dd = g / row, within = g % row;
+        const size_t n = std::min(row - within, hi - o);
+        std::memcpy(host + dd * dst_row + dst_off + within, pin + o, n);
+        o += n;
+      }
+    };
+    const size_t slice = (len / kCopyThreads + 4095) / 4096 * 4096;
+    std::thread th[kCopyThreads];
+    int nth = 0;
+    for (size_t o = slice; o < len; o += slice) th[nth++] = std::thread(scatter, o, std::min(o + slice, len));
+    scatter(0, std::min(slice, len));
+    for (int t = 0; t < nth; ++t) th[t].join();
+  }
+  return 0;
+}
+
+static void dl_worker(mjhmc_sampler* s, DlSession* d) {
+  if (hipSetDevice(s->ctx->device) != hipSuccess) {
+    d->rc = MJHMC_ERR_HIP;
+    d->err = "hipSetDevice failed in the download thread";
+    return;
+  }
+  for (int i = 0; i < d->n_iter; ++i) {
+    while (d->marked.load(std::memory_order_acquire) <= i && !d->launched.load(std::memory_order_acquire))
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (d->marked.load(std::memory_order_acquire) <= i) break;   // a path that marks nothing: the caller downloads afterwards
+    for (hipEvent_t e : d->ev[(size_t)i])
+      if (hipStreamWaitEvent(s->dl_stream, e, 0) != hipSuccess) {
+        d->rc = MJHMC_ERR_HIP;
+        d->err = "hipStreamWaitEvent failed in the download thread";
+        return;
+      }
+    const int rc = dl_download_slot(s, d, i);
+    if (rc) {
+      d->rc = rc;
+      d->err = g_err;   // (thread-local: hand the message to the calling thread)
+      return;
+    }
+    d->downloaded.store(i + 1, std::memory_order_release);
+  }
+}
+
 template <typename T>
 static int run_eval_t(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
   EvalArgs<T> a;
@@ -894,6 +1025,12 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   for (void* q : s->ick)
     if (q) (void)hipFree(q);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
+  if (s->dl_stage) (void)hipFree(s->dl_stage);
+  for (int i = 0; i < 2; ++i) {
+    if (s->dl_pin[i]) (void)hipHostFree(s->dl_pin[i]);
+    if (s->dl_ev[i]) (void)hipEventDestroy(s->dl_ev[i]);
+  }
+  if (s->dl_stream) (void)hipStreamDestroy(s->dl_stream);
   for (int i = 0; i < 2; ++i) {
     if (s->pipe_pin[i]) (void)hipHostFree(s->pipe_pin[i]);
     if (s->pipe_ev[i]) (void)hipEventDestroy(s->pipe_ev[i]);
@@ -1410,6 +1547,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     l.xin = xin;
     l.xout = out_of(i0, l.K, xin);
     TRY(launch(l, s->stats + 4 * (size_t)i0));
+    if (ring_slot0 >= 0) TRY(dl_mark(s, i0, l.K, &s->stream, 1));   // (the parts of a split launch have joined the sampler's stream)
     launches.push_back(l);
     xin = l.xout;
   }
@@ -1524,7 +1662,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     // take one trajectory time each: alone it ends in a partial round, and at a few hundred tiles that round is most of
     // the launch (C3 at 12 500 particles: 410 items = 1.6 rounds run as 2).  Two parts that never wait for each other fill
     // each other's partial rounds; below ~3/4 of a round of tiles there is nothing to fill.
-    int want = (allow_split && !replay_normal && !replay_exp && !replay_unif && ring_slot0 < 0 && !test_env("MJHMC_NO_SPLIT") &&
+    // (recording into ring slots changes nothing: iteration i reads slot i - 1 and writes slot i, part by part)
+    int want = (allow_split && !replay_normal && !replay_exp && !replay_unif && !test_env("MJHMC_NO_SPLIT") &&
                 4 * ntiles >= 3 * (int64_t)cus) ? 2 : 1;
     if (want > 1)
       if (const char* np = test_env("MJHMC_SPLIT_PARTS")) want = std::max(1, std::min(kMaxDenseParts, std::atoi(np)));
@@ -1870,6 +2009,22 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       }
     }
     HIPCHK(hipGetLastError());
+    if (s->dl && ring_slot0 >= 0 && i >= s->dl->marked.load(std::memory_order_acquire)) {
+      // Iteration i is complete when every stream that ran part of it gets here -- and each of them re-tiles its own
+      // columns of the new X into staging slot i on the way (0.3 ms of a 17 ms C3 iteration): on a stream of its own that
+      // kernel waited for a workgroup of the NEXT iteration's persistent grid to leave, so every slot crossed PCIe one
+      // iteration late and two of them after the run had ended.  The worker then only moves bytes (copy engine + host).
+      hipStream_t sts[kMaxDenseParts];
+      const size_t elems = (size_t)s->D * s->N;
+      const bool room = s->dl_stage_elems >= (size_t)s->dl->n_iter * elems;
+      for (int k = 0; k < n_parts; ++k) {
+        sts[k] = part_stream(k);
+        if (room) TRY(dl_retile(s, xo, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
+                                s->dl_stage + (size_t)i * elems, sts[k]));
+      }
+      s->dl->retiled[(size_t)i] = room ? 1 : 0;
+      TRY(dl_mark(s, i, 1, sts, n_parts));
+    }
     xin = xo;
   }
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
@@ -1968,6 +2123,76 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   return s->dtype == MJHMC_F64
              ? iterate_t<double>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done)
              : iterate_t<float>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
+}
+
+int mjhmc_iterate_download(mjhmc_sampler* s, int n_iter, int ring_slot0, double* host_out, int64_t n_total, int64_t k0,
+                           mjhmc_iter_stats* per_iter, int* n_done) {
+  if (!s || !host_out || n_iter < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
+  if (ring_slot0 < 0 || !s->ring || ring_slot0 + n_iter > s->ring_slots)
+    return fail(MJHMC_ERR_INVALID, "ring slots out of range (call mjhmc_ring_alloc)");
+  if (k0 < 0 || k0 + n_iter > n_total) return fail(MJHMC_ERR_INVALID, "time indices [k0, k0 + n_iter) outside the host array");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  if (!s->dl_stream) {
+    // the re-tile kernel of a finished slot should get the first CUs a finishing workgroup of the persistent grids gives up
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&s->dl_stream, hipStreamNonBlocking, hi));
+  }
+  const size_t elems = (size_t)s->D * s->N;
+  // staging in the host layout: a slot per iteration of the call where the device has the room (the iterations then
+  // re-tile their own output, see iterate_t), else one slot the worker re-tiles into
+  if (s->dl_stage_elems < (size_t)n_iter * elems) {
+    double* big = nullptr;
+    if (hipMalloc((void**)&big, (size_t)n_iter * elems * sizeof(double)) == hipSuccess) {
+      if (s->dl_stage) HIPCHK(hipFree(s->dl_stage));
+      s->dl_stage = big;
+      s->dl_stage_elems = (size_t)n_iter * elems;
+    } else {
+      (void)hipGetLastError();
+      if (s->dl_stage_elems < elems) {
+        if (s->dl_stage) HIPCHK(hipFree(s->dl_stage));
+        s->dl_stage = nullptr;
+        s->dl_stage_elems = 0;
+        HIPCHK(hipMalloc((void**)&s->dl_stage, elems * sizeof(double)));
+        s->dl_stage_elems = elems;
+      }
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!s->dl_pin[i]) HIPCHK(hipHostMalloc(&s->dl_pin[i], kPipeChunk, hipHostMallocDefault));
+    if (!s->dl_ev[i]) HIPCHK(hipEventCreateWithFlags(&s->dl_ev[i], hipEventDisableTiming));
+  }
+  DlSession d;
+  d.ev.resize((size_t)n_iter);
+  d.retiled.assign((size_t)n_iter, 0);
+  d.n_iter = n_iter;
+  d.ring_slot0 = ring_slot0;
+  d.host = host_out;
+  d.n_total = n_total;
+  d.k0 = k0;
+  s->dl = &d;
+  std::thread worker(dl_worker, s, &d);
+  int done = 0;
+  const int rc = mjhmc_iterate(s, n_iter, nullptr, nullptr, nullptr, ring_slot0, per_iter, &done);
+  d.launched.store(true, std::memory_order_release);
+  worker.join();
+  s->dl = nullptr;
+  int rc2 = d.rc;
+  if (rc2) g_err = d.err;
+  // what the worker did not bring over (a launch path that marks nothing; a re-run after a failure): plainly, now
+  if (!rc && !rc2) {
+    HIPCHK(hipStreamSynchronize(s->dl_stream));
+    for (int i = d.downloaded.load(); i < done && !rc2; ++i) rc2 = dl_download_slot(s, &d, i);
+  }
+  for (size_t i = 0; i < d.ev.size(); ++i)      // (the iterations of a fused launch share their events: destroy each once)
+    for (hipEvent_t e : d.ev[i]) {
+      bool first = true;
+      for (size_t j = 0; j < i && first; ++j)
+        for (hipEvent_t f : d.ev[j]) first = first && f != e;
+      if (first) (void)hipEventDestroy(e);
+    }
+  if (n_done) *n_done = done;
+  return rc ? rc : rc2;
 }
 
 static int read_vec(mjhmc_sampler* s, const void* dev, void* host, size_t nbytes) {
@@ -2086,9 +2311,26 @@ int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots) {
   if (!s || n_slots < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(s->ctx->device));
   if (n_slots <= s->ring_slots) return 0;
-  s->undo_valid = false;
   HIPCHK(hipStreamSynchronize(s->stream));
   const size_t mb = mat_bytes(s);
+  // the NEW ring first: a request the device cannot hold leaves the sampler with the ring it had
+  void* ring = nullptr;
+  double* dring = nullptr;
+  hipError_t e = hipMalloc(&ring, (size_t)n_slots * mb);
+  if (e == hipSuccess) e = hipMalloc((void**)&dring, (size_t)n_slots * s->Npad * sizeof(double));
+  if (e != hipSuccess) {
+    if (ring) (void)hipFree(ring);
+    (void)hipGetLastError();
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    char msg[320];
+    std::snprintf(msg, sizeof(msg), "a sample ring of %d slots x %.3f GB = %.1f GB does not fit the device (%.1f GB free of %.1f GB): "
+                  "record in chunks (mjhmc_iterate_download over a smaller ring) -- the ring the sampler had is kept",
+                  n_slots, mb / 1e9, (double)n_slots * mb / 1e9, free_b / 1e9, total_b / 1e9);
+    return fail(MJHMC_ERR_HIP, msg);
+  }
+  HIPCHK(hipMemset(ring, 0, (size_t)n_slots * mb));
+  s->undo_valid = false;
   // the live X may sit in the old ring: park it in a ping-pong buffer before freeing
   if (s->ring && (char*)s->Xcur >= (char*)s->ring && (char*)s->Xcur < (char*)s->ring + (size_t)s->ring_slots * mb) {
     HIPCHK(hipMemcpy(s->Xbuf[0], s->Xcur, mb, hipMemcpyDeviceToDevice));
@@ -2096,13 +2338,25 @@ int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots) {
   }
   if (s->ring) HIPCHK(hipFree(s->ring));
   if (s->dwell_ring) HIPCHK(hipFree(s->dwell_ring));
-  s->ring = nullptr;
-  s->dwell_ring = nullptr;
-  s->ring_slots = 0;
-  HIPCHK(hipMalloc(&s->ring, (size_t)n_slots * mb));
-  HIPCHK(hipMemset(s->ring, 0, (size_t)n_slots * mb));
-  HIPCHK(hipMalloc((void**)&s->dwell_ring, (size_t)n_slots * s->Npad * sizeof(double)));
+  s->ring = ring;
+  s->dwell_ring = dring;
   s->ring_slots = n_slots;
+  return 0;
+}
+
+int mjhmc_ring_slot_bytes(mjhmc_sampler* s, uint64_t* bytes) {
+  if (!s || !bytes) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  *bytes = (uint64_t)mat_bytes(s) + (uint64_t)s->Npad * sizeof(double);
+  return 0;
+}
+
+int mjhmc_mem_info(mjhmc_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!ctx || !free_bytes || !total_bytes) return fail(MJHMC_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  *free_bytes = f;
+  *total_bytes = t;
   return 0;
 }
 

@@ -80,6 +80,7 @@ struct Shape {
 
 constexpr int kMaxDenseParts = 4;   // free-running parts of a dense batch (iterate_t)
 
+struct DlSession;  // overlapped sample download of one mjhmc_iterate_download call (api.hip)
 struct HostTraj;  // proposal workspace of a host-energy sampler (host_energy.hip)
 
 struct mjhmc_sampler {
@@ -148,6 +149,14 @@ struct mjhmc_sampler {
   bool timing_pending = false;
   void* pipe_pin[2] = {nullptr, nullptr};       // pinned double buffer of the pipelined device -> host copies (copy_to_host)
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};
+  // mjhmc_iterate_download: the ring slot of an iteration goes to the host while the next iterations run -- its own stream,
+  // staging matrix and pinned double buffer, driven by a worker thread of the call
+  DlSession* dl = nullptr;
+  hipStream_t dl_stream = nullptr;
+  double* dl_stage = nullptr;
+  size_t dl_stage_elems = 0;
+  void* dl_pin[2] = {nullptr, nullptr};
+  hipEvent_t dl_ev[2] = {nullptr, nullptr};
   HostTraj* ht = nullptr;         // MJHMC_E_HOST: trajectory workspace (mjhmc_traj_*)
   bool host_energy_set = false;   // MJHMC_E_HOST: EX and dE/dX of the current state are the caller's (mjhmc_host_set_energy)
 };

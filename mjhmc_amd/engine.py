@@ -37,6 +37,12 @@ class Context(object):
         check(self.lib.mjhmc_ctx_info(self.handle, name, 256, ctypes.byref(ncu), ctypes.byref(hbm)), self.lib)
         return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
 
+    def mem_info(self):
+        """(free, total) device memory in bytes"""
+        f, t = ctypes.c_uint64(), ctypes.c_uint64()
+        check(self.lib.mjhmc_mem_info(self.handle, ctypes.byref(f), ctypes.byref(t)), self.lib)
+        return int(f.value), int(t.value)
+
     def autocor(self, samples, linear=False):
         """Lag sums ``out[k] = sum_series sum_t x_t x_{t+k}`` of a host array [n_dims, n_batch, n_samples]
         (circular in time unless ``linear``); see mjhmc_autocor in include/mjhmc_hip.h."""
@@ -211,6 +217,31 @@ class DeviceSampler(object):
         attempts = n_done + 1 if n_done < n_iter else n_iter
         return [stats[i] for i in range(attempts)], n_done
 
+    def iterate_download(self, n_iter, ring_slot0, out, k0=0):
+        """n_iter iterations into ring slots [ring_slot0, ring_slot0 + n_iter), each slot brought to
+        out[:, (k0 + i) * N : (k0 + i + 1) * N] while the following iterations run (mjhmc_iterate_download).  ``out``: the
+        C-contiguous float64 array (ndims, n_total * nparticles) of the whole run.  Returns (stats, n_done)."""
+        D, N = self.ndims, self.nparticles
+        if out.dtype != np.float64 or not out.flags.c_contiguous or out.ndim != 2 or out.shape[0] != D or out.shape[1] % N:
+            raise ValueError('out must be a C-contiguous float64 array (ndims, n_total * nparticles)')
+        stats = (_lib.IterStats * n_iter)()
+        done = ctypes.c_int()
+        check(self.lib.mjhmc_iterate_download(self.handle, int(n_iter), int(ring_slot0), ptr(out), out.shape[1] // N, int(k0), stats,
+                                              ctypes.byref(done)), self.lib)
+        n_done = done.value
+        attempts = n_done + 1 if n_done < n_iter else n_iter
+        return [stats[i] for i in range(attempts)], n_done
+
+    def ring_budget_slots(self, n_wanted, share=0.6):
+        """How many whole-state ring slots (of n_wanted) the device can take: those it already has, or `share` of the free
+        memory -- at least 2 (an iteration reads one slot and writes the next)."""
+        b = ctypes.c_uint64()
+        check(self.lib.mjhmc_ring_slot_bytes(self.handle, ctypes.byref(b)), self.lib)
+        per = int(b.value) + 8 * self.ndims * self.nparticles    # + the slot's staging copy in the host layout (iterate_download)
+        free, _ = self.ctx.mem_info()
+        fit = max(int(share * free // per) + self.ring_slots, 2)
+        return min(int(n_wanted), fit)
+
     def reset_flf_cache(self):
         check(self.lib.mjhmc_reset_flf_cache(self.handle), self.lib)
 
@@ -371,6 +402,14 @@ class HostEnergySampler(DeviceSampler):
             if st.nonfinite:
                 break
             done += 1
+        return stats, done
+
+    def iterate_download(self, n_iter, ring_slot0, out, k0=0):
+        """(the caller's callables pace this sampler: the slots are read once the iterations are done)"""
+        stats, done = self.iterate(n_iter, ring_slot0=ring_slot0)
+        N = self.nparticles
+        for i in range(done):
+            out[:, (k0 + i) * N:(k0 + i + 1) * N] = self.ring_read(ring_slot0 + i, 1)
         return stats, done
 
     def last_timing(self):

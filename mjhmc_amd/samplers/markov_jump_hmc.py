@@ -191,8 +191,10 @@ class HMCBase(object):
         self._account(stats[0])
         self._commit(stats[0])
 
-    def _run(self, n_iter, ring_slot0=-1, replay=None):
-        """n_iter iterations launched back to back; the host only steps in on a non-finite rate."""
+    def _run(self, n_iter, ring_slot0=-1, replay=None, download=None):
+        """n_iter iterations launched back to back; the host only steps in on a non-finite rate.  ``download = (out, k0)``:
+        ring slot ring_slot0 + i also goes to out[:, (k0 + i) * N : ...] while the following iterations run
+        (mjhmc_iterate_download)."""
         if not self._in_retry:
             self._iter_evals = []                         # the trace describes one batch call, it does not grow for ever
         if replay is not None:                            # recorded random numbers: one attempt at a time
@@ -208,7 +210,10 @@ class HMCBase(object):
             todo = n_iter - done
             if sync and todo > 1:
                 self._dev.checkpoint()                    # once per batch; a single iteration needs none (rollback)
-            stats, n_done = self._dev.iterate(todo, ring_slot0=slot)
+            if download is not None:
+                stats, n_done = self._dev.iterate_download(todo, slot, download[0], download[1] + done)
+            else:
+                stats, n_done = self._dev.iterate(todo, ring_slot0=slot)
             if sync:
                 # the reference aborts the WHOLE batch on one bad particle: every rank keeps only the
                 # iterations all ranks committed; a rank that ran ahead rolls back + replays (bit-identical:
@@ -235,6 +240,10 @@ class HMCBase(object):
             if failed_somewhere:                          # the attempt after the committed ones failed
                 self._account(stats[n_done])
                 self._retry(ring_slot0 + done if ring_slot0 >= 0 else -1, None)
+                if download is not None:                  # the retried iteration's slot, plainly
+                    N = self._dev.nparticles
+                    k = download[1] + done
+                    download[0][:, k * N:(k + 1) * N] = self._dev.ring_read(ring_slot0 + done, 1)
                 done += 1
 
     def _retry(self, ring_slot, replay):
@@ -273,8 +282,43 @@ class HMCBase(object):
     def sample(self, n_samples=1000, preserve_order=False, replay=None, out=None):
         """markov_jump_hmc.py:150-173.  ``out`` (extension): a preallocated C-contiguous float64 array of the result's
         shape, (ndims, n_samples * nbatch) or (ndims, nbatch, n_samples), filled and returned instead of a fresh one."""
+        if self._streams(preserve_order, replay):
+            return self._sample_streamed(n_samples, out)
         self._record(n_samples, replay)
         return self._stack(n_samples, preserve_order, out)
+
+    def _streams(self, preserve_order, replay):
+        """np.concatenate(samples, axis=1) of an unsharded run with the counter RNG: every sample goes to the host while the
+        next iterations run, and the device ring may be smaller than the run"""
+        return self._comm is None and replay is None and not preserve_order and hasattr(self._dev, 'iterate_download')
+
+    def _host_array(self, n_states, what, out=None):
+        shape = (self.ndims, n_states * self.nbatch)
+        if out is not None:
+            if out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError('out must be a C-contiguous float64 array of shape %r' % (shape,))
+            return out
+        try:
+            return np.empty(shape)
+        except MemoryError:
+            raise MemoryError('%s: %d states of %d x %d float64 are %.1f GB of host memory, which this machine does not give -- '
+                              'draw fewer samples per call, or thin them' % (what, n_states, self.ndims, self.nbatch,
+                                                                             8e-9 * self.ndims * self.nbatch * n_states))
+
+    def _sample_streamed(self, n_iter, out=None, what='sample()'):
+        """n_iter iterations, the state after each as columns [k N, (k + 1) N) of the returned (ndims, n_iter * nbatch) array.
+        The device ring holds as many slots as fit (all of them if it can): a run bigger than the device walks it in
+        chunks."""
+        out = self._host_array(n_iter, what, out)
+        slots = max(2, self._dev.ring_budget_slots(n_iter))
+        self._dev.ring_alloc(slots)
+        done = 0
+        while done < n_iter:
+            chunk = min(slots, n_iter - done)
+            self._run(chunk, ring_slot0=0, download=(out, done))
+            done += chunk
+        self._publish()
+        return out
 
     def _record(self, n_samples, replay=None):
         """Run n_samples iterations, snapshotting X after each into device ring slots [0, n_samples)."""
@@ -372,6 +416,8 @@ class ContinuousTimeHMC(HMCBase):
         if num_steps is not None:
             n_samples = num_steps
         if self.resample:
+            if self._streams(False, replay) and self._dev.ring_budget_slots(n_samples + 1) < n_samples + 1:
+                return self._resample_on_host(n_samples)
             self._dev.ring_alloc(n_samples + 1)
             self._run(n_samples + 1, ring_slot0=0, replay=replay)
             self._publish()
@@ -392,8 +438,36 @@ class ContinuousTimeHMC(HMCBase):
                 raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # infinite dwell time
             self._last_resample_idx = sample_idx
             return self._dev.ring_gather(sample_idx)
+        if self._streams(preserve_order, replay):
+            res = self._sample_streamed(n_samples, out)
+            self._read_dwell()
+            return res
         self._record(n_samples, replay)
         return self._stack(n_samples, preserve_order, out)
+
+    def _resample_on_host(self, n_samples):
+        """sample() with dwell-time resampling when the n_samples + 1 states do not fit the device: they are streamed to
+        the host through a ring of the slots that do fit, and the columns are picked there (same uniforms, same indices)."""
+        n_iter = n_samples + 1
+        states = self._host_array(n_iter, 'sample(n_samples=%d, resample=True)' % n_samples)
+        slots = max(2, self._dev.ring_budget_slots(n_iter))
+        self._dev.ring_alloc(slots)
+        dwell, done = [], 0
+        while done < n_iter:
+            chunk = min(slots, n_iter - done)
+            self._run(chunk, ring_slot0=0, download=(states, done))
+            dwell.append(self._dev.ring_read_dwell(0, chunk))
+            done += chunk
+        self._publish()
+        self._read_dwell()
+        dwell_t = np.concatenate(dwell)[:n_samples].reshape(-1)
+        cumul_t = np.cumsum(dwell_t)
+        rand_vals = np.sort(np.random.random(n_samples * self.nbatch)) * np.sum(dwell_t)
+        sample_idx = np.searchsorted(cumul_t, rand_vals, side='right')
+        if sample_idx.size and sample_idx[-1] >= dwell_t.size:
+            raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # infinite dwell time
+        self._last_resample_idx = sample_idx
+        return states[:, sample_idx]
 
     def _record(self, n_samples, replay=None):
         super(ContinuousTimeHMC, self)._record(n_samples, replay)

@@ -266,3 +266,101 @@ def test_rollback_undoes_a_committed_single_iteration(what):
         with pytest.raises(_lib.EngineError):
             s.rollback()                                    # a multi-iteration call cannot be undone this way
     s.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# sample(): every state goes to the host while the next iterations run (mjhmc_iterate_download), through a ring that
+# may be smaller than the run
+# ---------------------------------------------------------------------------------------------
+def _sampler_for(what, seed=11):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    from mjhmc_amd.misc import distributions as Dm
+    from tests.helpers import ref_init_weights
+    rs = np.random.RandomState(4)
+    if what == 'iso_fused':                 # Gaussian force: fused launches write the ring from inside the launch
+        D, N = 24, 5000
+        X0 = rs.randn(D, N)
+
+        class Fixed(Dm.TestGaussian):
+            def gen_init_X(self):
+                self.Xinit = X0
+        d = Fixed(ndims=D, nbatch=N, sigma=1.2)
+        kw = dict(epsilon=0.2, num_leapfrog_steps=5)
+    elif what == 'funnel_compacted':        # several particles per wave, big batch: jump kernel + compacted passes
+        D, N = 10, 20000
+        X0 = rs.randn(D, N)
+
+        class Fixed(Dm.Funnel):
+            def gen_init_X(self):
+                self.Xinit = X0
+        d = Fixed(ndims=D, nbatch=N, scale=1.5)
+        kw = dict(epsilon=0.1, num_leapfrog_steps=5)
+    else:                                   # ProductOfT on the tile kernels, two free-running parts
+        D, N = 36, 8000
+        W, lognu = ref_init_weights(D, D)
+        X0 = rs.randn(D, N)
+
+        class Fixed(Dm.ProductOfT):
+            def init_X(self):
+                self.Xinit = X0
+        d = Fixed(ndims=D, nbatch=N, lognu=lognu, W=W + np.eye(D), state_dtype='float64' if what == 'pot64' else 'float32')
+        kw = dict(epsilon=0.1, num_leapfrog_steps=6)
+    return d, kw
+
+
+@pytest.mark.parametrize('what', ['iso_fused', 'funnel_compacted', 'pot32', 'pot64'])
+@pytest.mark.parametrize('cls_name', ['MarkovJumpHMC', 'ControlHMC'])
+def test_streamed_sample_equals_the_recorded_ring(what, cls_name, monkeypatch):
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    n = 7
+    outs = []
+    for variant in ('streamed', 'ring of 3 slots', 'recorded, then read'):
+        d, kw = _sampler_for(what)
+        extra = dict(resample=False) if cls_name == 'MarkovJumpHMC' else {}
+        s = getattr(M, cls_name)(distribution=d, seed=21, beta=0.2, **extra, **kw)
+        if variant == 'recorded, then read':
+            monkeypatch.setattr(type(s), '_streams', lambda self, po, rp: False)
+        elif variant == 'ring of 3 slots':
+            monkeypatch.setattr(type(s._dev), 'ring_budget_slots', lambda self, n_wanted, share=0.6: min(n_wanted, 3))
+        outs.append((s.sample(n), s.state.X, s.l_count, s.f_count, s.r_count, d.E_count, d.dEdX_count))
+        monkeypatch.undo()
+    for o in outs[1:]:
+        assert bits_equal(outs[0][0], o[0]) and bits_equal(outs[0][1], o[1]) and outs[0][2:] == o[2:]
+    assert outs[0][0].shape[1] == n * outs[0][1].shape[1]
+    assert bits_equal(outs[0][0][:, -outs[0][1].shape[1]:], outs[0][1])        # the last sample is the live state
+
+
+def test_resampling_on_the_host_when_the_ring_does_not_fit(monkeypatch):
+    """sample() with dwell-time resampling needs all n + 1 states at once; when they exceed the device they are streamed
+    through a smaller ring and the columns are picked on the host: same uniforms, same indices, same columns."""
+    from mjhmc_amd.samplers import markov_jump_hmc as M
+    outs = []
+    for small in (False, True):
+        d, kw = _sampler_for('pot32')
+        s = M.MarkovJumpHMC(distribution=d, seed=21, beta=0.2, **kw)
+        if small:
+            monkeypatch.setattr(type(s._dev), 'ring_budget_slots', lambda self, n_wanted, share=0.6: min(n_wanted, 4))
+        np.random.seed(3)
+        outs.append((s.sample(9), s._last_resample_idx.copy(), s.dwelling_times.copy()))
+        monkeypatch.undo()
+    assert np.array_equal(outs[0][1], outs[1][1]) and bits_equal(outs[0][0], outs[1][0]) and bits_equal(outs[0][2], outs[1][2])
+
+
+def test_ring_request_beyond_the_device_keeps_the_ring_and_says_sizes():
+    from mjhmc_amd import engine, _lib
+    ctx = engine.context(0)
+    en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, 512, [1.0])
+    s = engine.DeviceSampler(en, np.random.RandomState(0).randn(512, 4096), seed=1)
+    s.set_hparams(0.1, 3, 0.05, 1.0)
+    s.ring_alloc(4)
+    s.iterate(4, ring_slot0=0)
+    before = s.ring_read(0, 4)
+    free, total = ctx.mem_info()
+    assert 0 < free <= total
+    too_many = int(2 * total // (512 * 4096 * 8)) + 8
+    with pytest.raises(_lib.EngineError, match=r'does not fit the device .* the ring the sampler had is kept'):
+        s.ring_alloc(too_many)
+    assert bits_equal(before, s.ring_read(0, 4))
+    st, done = s.iterate(2, ring_slot0=2)                           # and is still usable
+    assert done == 2
+    s.close()

@@ -225,3 +225,52 @@ def test_sic_leapfrog_conserves_energy_second_order(nc, P, cauchy):
     assert abs(m2) < 0.25 and 3.0 < m1 / m2 < 6.5, (m1, m2)
     w1, w2 = mean_dH(en2, 0.1, 4), mean_dH(en2, 0.05, 8)
     assert abs(w2) > 0.5 and abs(w2) > 4 * abs(m2) and w1 / w2 < 2.0, (w1, w2)
+
+
+@pytest.mark.parametrize('mode_name', ['MJHMC', 'CONTROL'])
+def test_sic_stationary_law_of_the_bf16_chain(mode_name):
+    """The chain that rounds its state to bfloat16 at every commit (csrc/dense_sic.hip) against the law of the energy the
+    reference writes down (tf_distributions.py:241-272), with NO oracle and no second chain:
+        p(a) ~ exp(-1/2 |y - B a|^2) * prod_i (1 + a_i^2)^(-lambda),   lambda = 0.01, B (256, 1024) of full row rank.
+    In the 256 directions the data see, the prior is all but flat (its log-density moves by < 0.01 per unit of a): the
+    residual r = y - B a is N(0, I_256) to well within the power of this test, so 1/2 |r|^2 ~ Gamma(128, 1) and every
+    pixel's r_i ~ N(0, 1); the momentum is N(0, I_1024), 1/2 |v|^2 ~ Gamma(512, 1).  (In the other 768 directions the
+    Cauchy prior with lambda = 0.01 is not normalisable: the chain diffuses there for ever, as the reference's does;
+    nothing below looks at them.)  The chains start where the benchmark starts them -- a0 + 0.1 noise, residuals five
+    times too small -- and must ARRIVE at the law with the benchmark's hyper-parameters (eps 0.05, L 25, beta 0.1).
+    The state is read back in bfloat16 values and the statistics are formed on the host in float64.
+    A chain running 3 % too hot or too cold fails: the negative controls test the same samples against those laws."""
+    from mjhmc_amd import engine, _lib
+    from tests.helpers import sic_problem
+    ctx = engine.context(0)
+    B, imgs, a0 = sic_problem(0)
+    y = imgs[:, 0]
+    N, D, n_burn = 4096, 1024, 1500
+    en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, D, np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), y]))
+    X0 = a0[:, None] + 0.1 * np.random.RandomState(12).randn(D, N)
+    mode = {'MJHMC': _lib.MODE_MJHMC, 'CONTROL': _lib.MODE_CONTROL}[mode_name]
+    s = engine.DeviceSampler(en, X0, seed=2027, dtype='bfloat16', mode=mode)
+    beta = 0.1
+    # MJHMC: refresh clock of rate p_r, full refresh share beta per R move (markov_jump_hmc.py:341-347, hmc_state.py:121-129);
+    # CONTROL: the batch-wide gate fires with probability p_r (markov_jump_hmc.py:138-141)
+    s.set_hparams(0.05, 25, -np.log(1 - beta) * 0.5 if mode_name == 'MJHMC' else 0.3, beta if mode_name == 'MJHMC' else 1.0, 1.0)
+    r0 = y[:, None] - B.dot(X0)
+    assert np.median(0.5 * np.sum(r0 ** 2, axis=0)) < 20           # the start is far from the law (128 +- 11)
+    moves = np.zeros(3)
+    for _ in range(n_burn // 100):
+        st, done = s.iterate(100)
+        assert done == 100
+        moves += [sum(t.l for t in st), sum(t.f for t in st), sum(t.r for t in st)]
+    X, V = s.read(_lib.F_X), s.read(_lib.F_V)
+    s.close()
+    r = y[:, None] - B.dot(X)
+    e_data, e_kin = 0.5 * np.sum(r ** 2, axis=0), 0.5 * np.sum(V ** 2, axis=0)
+    p_data = stats.kstest(e_data, 'gamma', args=(128.0,)).pvalue
+    p_kin = stats.kstest(e_kin, 'gamma', args=(512.0,)).pvalue
+    p_pix = np.array([stats.kstest(r[i], 'norm').pvalue for i in range(0, 256, 8)])
+    info = dict(mean_e_data=float(e_data.mean()), mean_e_kin=float(e_kin.mean()), lfr=(moves / moves.sum()).round(3).tolist(),
+                p_data=p_data, p_kin=p_kin, p_pix_min=float(p_pix.min()))
+    assert p_data > P_MIN and p_kin > P_MIN and p_pix.min() > P_MIN, info
+    # negative controls: the same samples against the laws of a chain 3 % too hot / too cold
+    for scale in (1.03, 0.97):
+        assert stats.kstest(e_data, 'gamma', args=(128.0, 0.0, scale)).pvalue < 1e-6, (scale, info)
