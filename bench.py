@@ -65,12 +65,19 @@ WORKLOADS = {
     # distr_data/dump_1024.pkl is not in its checkout)
     'c5': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25 bf16 state / fp32 accumulate',
                kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1, dtype='bfloat16', params=None),
+    # the same workload with the state rows kept as the reference keeps them (TensorFlow float32, tf_distributions.py:89); the
+    # matrix-core operands are bf16 either way.  With bf16 STATE the MarkovJumpHMC chain does not keep the law (it runs
+    # hot: tests/test_gpu_stationary.py::test_sic_stationary_law); with float32 state it does
+    'c5f32': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25, float32 state (the reference\'s) / bf16 '
+                       'matrix-core operands / fp32 accumulate', kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1,
+                  dtype='float32', params=None),
     # BASELINE.json configs[0] (README shape; plumbing)
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
 }
 DTYPE_TAG = {'float64': 'f64 state (ProductOfT: around the f32 matrix-core force)', 'float32': 'f32 state and force (the reference: f64 state arrays around its f32 Theano force)',
              'bfloat16': 'bf16 state / f32 accumulate'}
+DTYPE_TAG_SIC32 = 'f32 state / bf16 matrix-core operands / f32 accumulate'
 
 
 def pot_model(D):
@@ -510,8 +517,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
                 'counted': {'achieved': flops_counted / (kern_it_ms * 1e-3) / 1e12, 'frac': flops_counted / (kern_it_ms * 1e-3) / 1e12 / peak,
                             'flops_per_launch': flops_counted},
                 'traffic': measured_traffic(key, 1) if full_shape else None,
-                'kernel': ('pot64_jump_kernel+pot64_flf_kernel' if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
-                           'pot_jump_kernel+pot_flf_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel+sic_flf_kernel'),
+                'kernel': ('pot64_jump_kernel+pot64_decide_kernel' if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
+                           'pot_jump_kernel+pot_fix_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel+sic_fix_kernel'),
                 'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'algorithmic_flops_per_launch': flops,
                 'hbm': {'algorithmic_bytes_per_launch': dense_bytes * n_rank,
                         'achieved': dense_bytes * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s'}}
@@ -586,7 +593,7 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         'value': units / elapsed, 'unit': 'particle-steps/s', 'ms_per_step': elapsed * 1e3 / iters,
         'ms_per_step_median': float(np.median(per_step)), 'ms_per_step_min': float(per_step.min()),
         'ms_per_step_max': float(per_step.max()), 'repeats': reps, 'timed_s': elapsed,
-        'dtype': DTYPE_TAG[w['dtype']],
+        'dtype': DTYPE_TAG_SIC32 if (w['kind'] == 'sic' and w['dtype'] == 'float32') else DTYPE_TAG[w['dtype']],
         'config': {'workload': w['name'], 'ndims': w['D'], 'nparticles_per_gpu': n_rank, 'nparticles_total': n_rank * world,
                    'L': w['L'], 'epsilon': w['eps'], 'beta': w['beta'], 'rng': 'philox4x32-10',
                    'particles_x_L_per_s': n_rank * world * w['L'] * iters / elapsed,
@@ -924,7 +931,7 @@ def main(argv=None):
     ap.add_argument('--steps', type=int, default=64)     # iterations per mjhmc_iterate call (one fused launch of the elementwise kernels)
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--workload', default='all', choices=sorted(WORKLOADS) + ['all'])      # c3f64: C3 in the reference's arithmetic
-    ap.add_argument('--head', default='c3f64', choices=['c2', 'c3', 'c3f64', 'c4', 'c5'],
+    ap.add_argument('--head', default='c3f64', choices=['c2', 'c3', 'c3f64', 'c4', 'c5', 'c5f32'],
                     help='top-level workload of the line (default: C3 in the reference\'s arithmetic -- float64 state around '
                          'the float32 force --, the workload of BASELINE.json\'s numeric target; c3: its float32-state form)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
@@ -950,7 +957,7 @@ def main(argv=None):
     # spawning parent watches for the marker below), not after five workloads
     gather_info = sample_gather_check(rig) if rig.comm is not None else None
     progress('gather_done')
-    keys = ['c2', 'c3', 'c3f64', 'c4', 'c5'] if args.workload == 'all' else [args.workload]
+    keys = ['c2', 'c3', 'c3f64', 'c4', 'c5', 'c5f32'] if args.workload == 'all' else [args.workload]
     head = args.head if args.head in keys else keys[0]
     keys = [head] + [k for k in keys if k != head]
     rig.head = head
@@ -966,10 +973,11 @@ def main(argv=None):
 
     # ONE CPU baseline serves both forms of C3: the NumPy port integrates float64 state around a float32 force, which is
     # c3f64's arithmetic exactly; it is timed with whichever of the two runs as the head (else with c3f64)
-    cpu_key = {'c3': head if head in ('c3', 'c3f64') else 'c3f64', 'c3f64': head if head in ('c3', 'c3f64') else 'c3f64'}
+    cpu_key = {'c3': head if head in ('c3', 'c3f64') else 'c3f64', 'c3f64': head if head in ('c3', 'c3f64') else 'c3f64',
+               'c5': head if head in ('c5', 'c5f32') else 'c5', 'c5f32': head if head in ('c5', 'c5f32') else 'c5'}
     # run order: the two vector-pipe / HBM workloads first, then the matrix-core ones -- whichever is the head.  (Measured:
     # C2 right after the ProductOfT run reads 7 % slower than on a chip that has not just run 20 s of dense MFMA work.)
-    for key in [k for k in ('c1', 'c2', 'c4', 'c3', 'c3f64', 'c5') if k in keys]:
+    for key in [k for k in ('c1', 'c2', 'c4', 'c3', 'c3f64', 'c5', 'c5f32') if k in keys]:
         steps, warm = budget(key)
         cpu_s = 0 if (args.no_cpu_baseline or cpu_key.get(key, key) != key) else (12.0 if key == head else 6.0)
         results[key] = run_workload(rig, key, steps, warm, cpu_s, args.scaling)
@@ -998,12 +1006,12 @@ def main(argv=None):
                 strong[key].update(steps=steps, warmup=warm, scaling='strong')
     if rig.rank == 0:
         # the two forms of C3 share the CPU baseline (which IS the float64-state arithmetic)
-        pair = [results.get('c3'), results.get('c3f64')]
-        src = next((r for r in pair if r and 'cpu_baseline' in r), None)
-        for r in pair:
-            if r and src and 'cpu_baseline' not in r:
-                r['cpu_baseline'] = dict(src['cpu_baseline'], shared=True)
-                r['config']['gpu_over_cpu'] = r['value'] / src['cpu_baseline']['value']
+        for pair in ([results.get('c3'), results.get('c3f64')], [results.get('c5'), results.get('c5f32')]):
+            src = next((r for r in pair if r and 'cpu_baseline' in r), None)
+            for r in pair:
+                if r and src and 'cpu_baseline' not in r:
+                    r['cpu_baseline'] = dict(src['cpu_baseline'], shared=True)
+                    r['config']['gpu_over_cpu'] = r['value'] / src['cpu_baseline']['value']
         h = results[head]
         hr = h['roofline']
         # The printed line: the contract's keys, numbers only, <= 8 kB (the driver keeps the line's tail and the scalar keys

@@ -114,7 +114,10 @@ static int shape_for(const mjhmc_energy* e, int* dtype, Shape* sh) {
       *sh = Shape{0, 0, e->pot_dim, e->pot_dim / 4, 4};
     }
   } else if (e->is_sic()) {
-    *sh = Shape{0, 0, e->ep.ndims, e->ep.ndims / 8, 2};  // a particle row = n_patches x 1024 bfloat16
+    if (*dtype != MJHMC_BF16 && *dtype != MJHMC_F32)
+      return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE runs with BF16 state (the benchmark's) or F32 state (the reference's)");
+    // a particle row = n_patches x n_coeffs elements of the state's type (the matrix-core operands are bf16 either way)
+    *sh = *dtype == MJHMC_BF16 ? Shape{0, 0, e->ep.ndims, e->ep.ndims / 8, 2} : Shape{0, 0, e->ep.ndims, e->ep.ndims / 4, 4};
   } else {
     TRY(pick_shape(e->ep.ndims, *dtype, sh));
   }
@@ -701,15 +704,16 @@ static int run_eval_pot(mjhmc_sampler* s, const void* X, void* Gout, void* Eout,
   return 0;
 }
 
-static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen,
-                        void* EVout) {
-  SicEvalArgs a;
-  a.X = (const __bf16*)X;
+template <typename ST>
+static int run_eval_sic_t(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen,
+                          void* EVout) {
+  SicEvalArgsT<ST> a;
+  a.X = (const ST*)X;
   a.G = (float*)Gout;  // float32 [Npad][1024]
   a.E = (float*)Eout;
   a.EV = (float*)EVout;
-  a.V = (const __bf16*)V;
-  a.V_gen = (__bf16*)Vgen;
+  a.V = (const ST*)V;
+  a.V_gen = (ST*)Vgen;
   a.N = s->N;
   const int ppt = sic_particles_per_tile(s->en->sic_P);
   a.ntiles = (s->N + ppt - 1) / ppt;
@@ -718,6 +722,10 @@ static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout,
   sic_launch_eval(a, s->en->sic_model(), s->stream);
   HIPCHK(hipGetLastError());
   return 0;
+}
+static int run_eval_sic(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
+  return s->dtype == MJHMC_BF16 ? run_eval_sic_t<__bf16>(s, X, Gout, Eout, V, Vgen, EVout)
+                                : run_eval_sic_t<float>(s, X, Gout, Eout, V, Vgen, EVout);
 }
 
 static int run_eval(mjhmc_sampler* s, const void* X, void* Gout, void* Eout, const void* V, void* Vgen, void* EVout) {
@@ -1047,8 +1055,9 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
   if (nparticles < 1) return fail(MJHMC_ERR_INVALID, "nparticles must be >= 1");
   if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
-  if ((dtype == MJHMC_BF16) != e->is_sic())
-    return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
+  if (dtype == MJHMC_BF16 && !e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state: SPARSE_CODE only");
+  if (e->is_sic() && dtype == MJHMC_F64)
+    return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE runs with BF16 state (the benchmark's) or F32 state (the reference's)");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   if (e->is_host() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "host-evaluated energies run in float64");
   if (mode < MJHMC_MODE_MJHMC || mode > MJHMC_MODE_CTHMC) return fail(MJHMC_ERR_INVALID, "unknown sampler mode");
@@ -1885,52 +1894,59 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       }
     } else if (s->en->is_sic()) {
       if constexpr (sizeof(T) == 4) {
-        SicJumpArgs sa;
-        sa.X_in = (const __bf16*)xin;
-        sa.V_in = (const __bf16*)s->Vbuf[vi];
-        sa.X_out = (__bf16*)xo;
-        sa.V_out = (__bf16*)s->Vbuf[vi ^ 1];
-        sa.EX_in = a.EX_in;
-        sa.EV_in = a.EV_in;
-        sa.Hflf_in = a.Hflf_in;
-        sa.Hwork = s->Hwork;
-        sa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;
-        sa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;
-        sa.Hspec_in = (const float*)s->Hspec[si];
-        sa.Hspec_out = (float*)(spec_out_override ? spec_out_override : s->Hspec[si ^ 1]);
-        sa.rescan = spec_out_override ? 1 : 0;
-        sa.EX_out = a.EX_out;
-        sa.EV_out = a.EV_out;
-        sa.Hflf_out = a.Hflf_out;
-        sa.dwell = a.dwell;
-        sa.dwell_ring = a.dwell_ring;
-        sa.trans = a.trans;
-        sa.noise = (const __bf16*)a.noise;
-        sa.rexp = a.rexp;
-        sa.runif = a.runif;
-        sa.mode = a.mode;
-        sa.p_flip = a.p_flip;
-        sa.ctl = a.ctl;
-        sa.stats = a.stats;
-        sa.N = a.N;
-        sa.Npad = a.Npad;
-        const int ppt = sic_particles_per_tile(s->en->sic_P);
-        sa.ntiles = (a.N + ppt - 1) / ppt;
-        sa.first_pid = a.first_pid;
-        sa.L = a.L;
-        sa.iter = a.iter;
-        sa.eps = a.eps;
-        sa.chalf = a.chalf;
-        sa.r_keep = a.r_keep;
-        sa.r_mix = a.r_mix;
-        sa.p_r = a.p_r;
-        sa.key = a.key;
-        for (int k = 0; k < n_parts; ++k) {
-          SicJumpArgs h = part_args<SicJumpArgs, __bf16>(sa, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
-                                                         n_parts > 1 ? part_npad(k) : s->Npad, (size_t)s->sh.pitch, k, i, dense_counters);
-          h.ntiles = (h.N + ppt - 1) / ppt;
-          sic_launch_jump(h, s->en->sic_model(), part_stream(k));
-        }
+        auto launch_sic = [&](auto tag) {
+          using ST = decltype(tag);
+          SicJumpArgsT<ST> sa;
+          sa.X_in = (const ST*)xin;
+          sa.V_in = (const ST*)s->Vbuf[vi];
+          sa.X_out = (ST*)xo;
+          sa.V_out = (ST*)s->Vbuf[vi ^ 1];
+          sa.EX_in = a.EX_in;
+          sa.EV_in = a.EV_in;
+          sa.Hflf_in = a.Hflf_in;
+          sa.Hwork = s->Hwork;
+          sa.cold_list = s->cold_list + (size_t)(i & 1) * s->Npad;
+          sa.next_list = s->cold_list + (size_t)((i + 1) & 1) * s->Npad;
+          sa.Hspec_in = (const float*)s->Hspec[si];
+          sa.Hspec_out = (float*)(spec_out_override ? spec_out_override : s->Hspec[si ^ 1]);
+          sa.rescan = spec_out_override ? 1 : 0;
+          sa.EX_out = a.EX_out;
+          sa.EV_out = a.EV_out;
+          sa.Hflf_out = a.Hflf_out;
+          sa.dwell = a.dwell;
+          sa.dwell_ring = a.dwell_ring;
+          sa.trans = a.trans;
+          sa.noise = (const ST*)a.noise;
+          sa.rexp = a.rexp;
+          sa.runif = a.runif;
+          sa.mode = a.mode;
+          sa.p_flip = a.p_flip;
+          sa.ctl = a.ctl;
+          sa.stats = a.stats;
+          sa.N = a.N;
+          sa.Npad = a.Npad;
+          const int ppt = sic_particles_per_tile(s->en->sic_P);
+          sa.ntiles = (a.N + ppt - 1) / ppt;
+          sa.first_pid = a.first_pid;
+          sa.L = a.L;
+          sa.iter = a.iter;
+          sa.eps = a.eps;
+          sa.chalf = a.chalf;
+          sa.r_keep = a.r_keep;
+          sa.r_mix = a.r_mix;
+          sa.p_r = a.p_r;
+          sa.key = a.key;
+          for (int k = 0; k < n_parts; ++k) {
+            SicJumpArgsT<ST> h = part_args<SicJumpArgsT<ST>, ST>(sa, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
+                                                                 n_parts > 1 ? part_npad(k) : s->Npad, (size_t)s->sh.pitch, k, i,
+                                                                 dense_counters);
+            h.ntiles = (h.N + ppt - 1) / ppt;
+            sic_launch_jump(h, s->en->sic_model(), part_stream(k));
+          }
+        };
+        // the state's type: bfloat16 (BASELINE.json configs[4]) or float32 (the reference's TensorFlow float32)
+        if (s->dtype == MJHMC_BF16) launch_sic(__bf16{});
+        else launch_sic(float{});
       }
     } else {
       // Compacted passes around the jump kernel (big batches with several particles per wave):
@@ -2538,7 +2554,8 @@ int mjhmc_eval(mjhmc_energy* e, int dtype, const double* X, int64_t n, double* E
   if (!e || !X || n < 1) return fail(MJHMC_ERR_INVALID, "bad argument");
   if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
-  if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE evaluates with BF16 state");
+  if ((dtype == MJHMC_BF16 && !e->is_sic()) || (e->is_sic() && dtype == MJHMC_F64))
+    return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE evaluates with BF16 or F32 state (and BF16 state is its alone)");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   if (e->is_host()) return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy has no device evaluation: call the callables");
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -2588,7 +2605,8 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
   if (!e || !X || !V || !X_out || !V_out || n < 1 || n_steps < 0) return fail(MJHMC_ERR_INVALID, "bad argument");
   if (dtype != MJHMC_F64 && dtype != MJHMC_F32 && dtype != MJHMC_BF16)
     return fail(MJHMC_ERR_INVALID, "dtype must be F64, F32 or BF16");
-  if ((dtype == MJHMC_BF16) != e->is_sic()) return fail(MJHMC_ERR_UNSUPPORTED, "BF16 state is what SPARSE_CODE runs in (and only it)");
+  if ((dtype == MJHMC_BF16 && !e->is_sic()) || (e->is_sic() && dtype == MJHMC_F64))
+    return fail(MJHMC_ERR_UNSUPPORTED, "SPARSE_CODE runs with BF16 or F32 state (and BF16 state is its alone)");
   if (e->is_user() && dtype != MJHMC_F64) return fail(MJHMC_ERR_UNSUPPORTED, "user-expression energies run in float64");
   if (e->is_host()) return fail(MJHMC_ERR_UNSUPPORTED, "a host-evaluated energy has no device leapfrog operator");
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -2638,21 +2656,26 @@ int mjhmc_leapfrog(mjhmc_energy* e, int dtype, const double* X, const double* V,
       pot_launch_leap(a, e->pot_model(), w.stream);
       HIPCHK(hipGetLastError());
     } else if (e->is_sic()) {
-      SicLeapArgs a;
-      a.X = (const __bf16*)buf[0];
-      a.V = (const __bf16*)buf[1];
-      a.X_out = (__bf16*)buf[2];
-      a.V_out = (__bf16*)buf[3];
-      a.G = (float*)buf[4];
-      a.EX = (float*)buf[5];
-      a.EV = (float*)buf[6];
-      a.N = n;
-      const int ppt = sic_particles_per_tile(e->sic_P);
-      a.ntiles = (n + ppt - 1) / ppt;
-      a.L = n_steps;
-      a.eps = (float)eps;
-      a.chalf = (float)(-eps / 2.);
-      sic_launch_leap(a, e->sic_model(), w.stream);
+      auto leap_sic = [&](auto tag) {
+        using ST = decltype(tag);
+        SicLeapArgsT<ST> a;
+        a.X = (const ST*)buf[0];
+        a.V = (const ST*)buf[1];
+        a.X_out = (ST*)buf[2];
+        a.V_out = (ST*)buf[3];
+        a.G = (float*)buf[4];
+        a.EX = (float*)buf[5];
+        a.EV = (float*)buf[6];
+        a.N = n;
+        const int ppt = sic_particles_per_tile(e->sic_P);
+        a.ntiles = (n + ppt - 1) / ppt;
+        a.L = n_steps;
+        a.eps = (float)eps;
+        a.chalf = (float)(-eps / 2.);
+        sic_launch_leap(a, e->sic_model(), w.stream);
+      };
+      if (dtype == MJHMC_BF16) leap_sic(__bf16{});
+      else leap_sic(float{});
       HIPCHK(hipGetLastError());
     } else if (w.sh.wide) {
       TRY(wide_leapfrog(&w, (const double*)buf[0], (const double*)buf[1], (double*)buf[2], (double*)buf[3], (double*)buf[4],

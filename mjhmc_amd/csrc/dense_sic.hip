@@ -107,6 +107,26 @@ __device__ __forceinline__ void ctile_store(__bf16* base, int64_t p, int w, int 
     }
 }
 
+// float32 state rows (the reference's own state type): the same elements, 16 bytes per group of 4
+template <int NB>
+__device__ __forceinline__ void ctile_load(const float* base, int64_t p, int w, int h, CTile<NB>& t) {
+  const float* row = base + (size_t)p * kC + 32 * NB * w + 4 * h;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * b + 8 * g);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t.b[b][4 * g + k] = v[k];
+    }
+}
+template <int NB>
+__device__ __forceinline__ void ctile_store_f32(float* base, int64_t p, int w, int h, const CTile<NB>& t);
+template <int NB>
+__device__ __forceinline__ void ctile_store(float* base, int64_t p, int w, int h, const CTile<NB>& t) {
+  ctile_store_f32(base, p, w, h, t);
+}
+
 // dE/dX is handed out in float32
 template <int NB>
 __device__ __forceinline__ void ctile_store_f32(float* base, int64_t p, int w, int h, const CTile<NB>& t) {
@@ -549,17 +569,20 @@ __device__ __forceinline__ float sic_kinetic(SH& sh, int w, int c, int h, int P,
   return group_total(sh, w, c, h, P, col.g0, tot) / 2.0f;
 }
 
-template <int NB>
+// what storing a tile in the state's type does to its values (the energies reported are those of the STORED state)
+template <typename ST, int NB>
 __device__ __forceinline__ void round_to_state(CTile<NB>& t) {
+  if constexpr (sizeof(ST) == 2) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.b[b][q] = (float)(__bf16)t.b[b][q];
+      for (int q = 0; q < 16; ++q) t.b[b][q] = (float)(__bf16)t.b[b][q];
+  }
 }
 
 // L leapfrog steps with the half kicks between drifts merged (bf16 operands make the reference's
 // separate roundings meaningless).  Returns E(x_new) of the particle; x, v updated in place; R = residual at x_new.
-template <bool CAUCHY, int NB>
+template <bool CAUCHY, int NB, typename ST>
 __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& sh, const AStream& as, int w, int c, int h,
                                                 int lane, const Col& col, CTile<NB>& x, CTile<NB>& v, RTile& R, int L,
                                                 float eps, float chalf) {
@@ -579,9 +602,9 @@ __device__ __forceinline__ float sic_trajectory(const SicModel& mdl, SicShared& 
     }
     sic_pass<kPassG2, CAUCHY, NB, false>(mdl, sh, as, w, c, h, lane, col.patch, x, v, R, chalf, 0.f);   // closing half kick
   }
-  // the successor position is stored in bf16 (and G1 already saw bf16(x)): evaluate the prior on
+  // a bf16 state: the successor position is stored in bf16 (and G1 already saw bf16(x)): evaluate the prior on
   // what will be stored, so EX is the energy of the stored state
-  round_to_state(x);
+  round_to_state<ST>(x);
   return sic_energy<CAUCHY, NB>(mdl, sh, w, c, h, col, R, x);
 }
 
@@ -620,8 +643,8 @@ __device__ __forceinline__ void ctile_zero(CTile<NB>& t) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <bool CAUCHY, int NB>
-__global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, const SicModel mdl) {
+template <bool CAUCHY, int NB, typename ST>
+__global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgsT<ST> a, const SicModel mdl) {
   __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   stage_patches(mdl, sh);
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void sic_eval_kernel(const SicEvalArgs a, c
       if (a.V_gen) {
         ctile_zero(v);
         sic_add_normals(a.key, (uint32_t)(a.first_pid + col.part), col.patch, w, h, 1.0f, v);
-        round_to_state(v);  // EV matches the stored momentum
+        round_to_state<ST>(v);  // EV matches the stored momentum
         if (col.alive) ctile_store(a.V_gen, col.q, w, h, v);
       } else {
         ctile_load(a.V, col.q, w, h, v);
@@ -682,8 +705,8 @@ struct SicFinishShared {
 
 // The successor's rows once the moves of a tile's columns stand in sh.move.  FIX = false (jump kernel): x, v hold the
 // end point of L.  FIX = true (sic_fix_kernel): columns that keep the end point are finished already.
-template <bool REPLAY, int MODE, int NB, bool FIX, class SH>
-__device__ __forceinline__ void sic_finish(const SicJumpArgs& a, SH& sh, int P, const Col& col, int w, int c, int h,
+template <bool REPLAY, int MODE, int NB, bool FIX, class SH, typename ST>
+__device__ __forceinline__ void sic_finish(const SicJumpArgsT<ST>& a, SH& sh, int P, const Col& col, int w, int c, int h,
                                            CTile<NB>& x, CTile<NB>& v) {
   const int64_t p = col.part;
   const int mv = sh.move[c];
@@ -720,19 +743,16 @@ __device__ __forceinline__ void sic_finish(const SicJumpArgs& a, SH& sh, int P, 
 #pragma unroll
     for (int b = 0; b < NB; ++b) v.b[b] = v.b[b] * a.r_keep;
     if constexpr (REPLAY) {
-      const __bf16* zrow = a.noise + (size_t)col.q * kC + 32 * NB * w + 4 * h;
+      CTile<NB> z;   // the recorded normals, stored like the state
+      ctile_load(a.noise, col.q, w, h, z);
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const bf16x4 z = *reinterpret_cast<const bf16x4*>(zrow + 32 * b + 8 * g4);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) v.b[b][4 * g4 + kk] += (float)z[kk] * a.r_mix;
-        }
+        for (int q = 0; q < 16; ++q) v.b[b][q] += z.b[b][q] * a.r_mix;
     } else {
       sic_add_normals(a.key, (uint32_t)(a.first_pid + p), col.patch, w, h, a.r_mix, v);
     }
-    round_to_state(v);
+    round_to_state<ST>(v);
   }
   if (tile_refreshes) {
     const float evr = sic_kinetic(sh, w, c, h, P, col, v);
@@ -746,8 +766,8 @@ __device__ __forceinline__ void sic_finish(const SicJumpArgs& a, SH& sh, int P, 
 
 // MODE = kModeMJHMC (markov_jump_hmc.py:355-415), kModeCT (:251-290) or kModeControl (:116-148, the comparison arm of
 // the reference's sparse-coding experiments, search/control_sp_img/control_objective.py:10)
-template <bool CAUCHY, bool REPLAY, int MODE, int NB>
-__global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, const SicModel mdl) {
+template <bool CAUCHY, bool REPLAY, int MODE, int NB, typename ST>
+__global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgsT<ST> a, const SicModel mdl) {
   __shared__ SicShared sh;
   if (a.ctl->failed) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
@@ -778,8 +798,8 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
 #pragma unroll
       for (int b = 0; b < NB; ++b) v.b[b] = -v.b[b];
     }
-    const float EXL = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
-    round_to_state(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
+    const float EXL = sic_trajectory<CAUCHY, NB, ST>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
+    round_to_state<ST>(v);  // the successor state is stored in bf16: report the kinetic energy of what is stored
     const float EVL = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     const float HL = EXL + EVL;
     if (inverse) {
@@ -857,8 +877,8 @@ __global__ __launch_bounds__(512, 2) void sic_jump_kernel(const SicJumpArgs a, c
 
 // The particles the jump kernel left pending (this iteration's list): decide them now that both of their trajectories
 // are done, and where the move is not L put the pre-move position back and flip / redraw the momentum (pot_fix_kernel's twin)
-template <bool REPLAY, int NB>
-__global__ __launch_bounds__(512) void sic_fix_kernel(const SicJumpArgs a, int P) {
+template <bool REPLAY, int NB, typename ST>
+__global__ __launch_bounds__(512) void sic_fix_kernel(const SicJumpArgsT<ST> a, int P) {
   __shared__ SicFinishShared sh;
   if (a.ctl->failed) return;
   const int ncold = *a.cold_count;
@@ -916,8 +936,8 @@ __global__ __launch_bounds__(512) void sic_fix_kernel(const SicJumpArgs a, int P
 }
 
 // HMCState.leapfrog / HMCState.L on caller-supplied states (hmc_state.py:86-100)
-template <bool CAUCHY, int NB>
-__global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, const SicModel mdl) {
+template <bool CAUCHY, int NB, typename ST>
+__global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgsT<ST> a, const SicModel mdl) {
   __shared__ SicShared sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   stage_patches(mdl, sh);
@@ -928,8 +948,8 @@ __global__ __launch_bounds__(512, 2) void sic_leap_kernel(const SicLeapArgs a, c
     RTile R;
     ctile_load(a.X, col.q, w, h, x);
     ctile_load(a.V, col.q, w, h, v);
-    const float ex = sic_trajectory<CAUCHY, NB>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
-    round_to_state(v);
+    const float ex = sic_trajectory<CAUCHY, NB, ST>(mdl, sh, as, w, c, h, lane, col, x, v, R, a.L, a.eps, a.chalf);
+    round_to_state<ST>(v);
     const float ev = sic_kinetic(sh, w, c, h, mdl.P, col, v);
     if (col.alive) {
       ctile_store(a.X_out, col.q, w, h, x);
@@ -965,15 +985,15 @@ static int sic_cus() {
   return std::max(1, cus);
 }
 
-template <bool CAUCHY, int MODE, int NB>
-static void sic_launch_mode(const SicJumpArgs& a, const SicModel& mdl, unsigned grid, hipStream_t st) {
+template <bool CAUCHY, int MODE, int NB, typename ST>
+static void sic_launch_mode(const SicJumpArgsT<ST>& a, const SicModel& mdl, unsigned grid, hipStream_t st) {
   const bool replay = MODE == kModeControl ? (a.runif && a.noise) : (a.rexp && a.noise);
-  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
-  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB>), dim3(grid), dim3(512), 0, st, a, mdl);
+  if (replay) hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, true, MODE, NB, ST>), dim3(grid), dim3(512), 0, st, a, mdl);
+  else hipLaunchKernelGGL((sic_jump_kernel<CAUCHY, false, MODE, NB, ST>), dim3(grid), dim3(512), 0, st, a, mdl);
 }
 
-template <bool CAUCHY, int NB>
-static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
+template <bool CAUCHY, int NB, typename ST>
+static void sic_launch_jump_t(const SicJumpArgsT<ST>& a, const SicModel& mdl, hipStream_t st) {
   const int cus = sic_cus();
   if (a.mode == kModeMJHMC) {  // only MJHMC has the inverse-L proposal and its cache
     if (a.iter == 0 || a.rescan) {  // first iteration of a call: the three counters cleared (they are adjacent), the list from a scan
@@ -983,14 +1003,14 @@ static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStre
     }
     // forward tiles + at most as many inverse-L tiles (workgroups without an item leave at once)
     const unsigned grid = (unsigned)std::min<int64_t>(2 * a.ntiles, cus);
-    sic_launch_mode<CAUCHY, kModeMJHMC, NB>(a, mdl, grid, st);
+    sic_launch_mode<CAUCHY, kModeMJHMC, NB, ST>(a, mdl, grid, st);
     const unsigned fgrid = (unsigned)std::min<int64_t>(a.ntiles, 4 * cus);
-    if (a.rexp && a.noise) hipLaunchKernelGGL((sic_fix_kernel<true, NB>), dim3(fgrid), dim3(512), 0, st, a, mdl.P);
-    else hipLaunchKernelGGL((sic_fix_kernel<false, NB>), dim3(fgrid), dim3(512), 0, st, a, mdl.P);
+    if (a.rexp && a.noise) hipLaunchKernelGGL((sic_fix_kernel<true, NB, ST>), dim3(fgrid), dim3(512), 0, st, a, mdl.P);
+    else hipLaunchKernelGGL((sic_fix_kernel<false, NB, ST>), dim3(fgrid), dim3(512), 0, st, a, mdl.P);
   } else {
     const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, cus);
-    if (a.mode == kModeCT) sic_launch_mode<CAUCHY, kModeCT, NB>(a, mdl, grid, st);
-    else sic_launch_mode<CAUCHY, kModeControl, NB>(a, mdl, grid, st);
+    if (a.mode == kModeCT) sic_launch_mode<CAUCHY, kModeCT, NB, ST>(a, mdl, grid, st);
+    else sic_launch_mode<CAUCHY, kModeControl, NB, ST>(a, mdl, grid, st);
   }
 }
 
@@ -1004,21 +1024,29 @@ static void sic_launch_jump_t(const SicJumpArgs& a, const SicModel& mdl, hipStre
     }                                                        \
   } while (0)
 
-void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st) {
-#define SIC_JUMP(C, NBV) sic_launch_jump_t<C, NBV>(a, mdl, st)
+template <typename ST>
+static void sic_launch_jump_st(const SicJumpArgsT<ST>& a, const SicModel& mdl, hipStream_t st) {
+#define SIC_JUMP(C, NBV) sic_launch_jump_t<C, NBV, ST>(a, mdl, st)
   SIC_DISPATCH(SIC_JUMP);
 }
-
-void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st) {
+template <typename ST>
+static void sic_launch_eval_st(const SicEvalArgsT<ST>& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-#define SIC_EVAL(C, NBV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
+#define SIC_EVAL(C, NBV) hipLaunchKernelGGL((sic_eval_kernel<C, NBV, ST>), dim3(grid), dim3(512), 0, st, a, mdl)
   SIC_DISPATCH(SIC_EVAL);
 }
-
-void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st) {
+template <typename ST>
+static void sic_launch_leap_st(const SicLeapArgsT<ST>& a, const SicModel& mdl, hipStream_t st) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, sic_cus());
-#define SIC_LEAP(C, NBV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV>), dim3(grid), dim3(512), 0, st, a, mdl)
+#define SIC_LEAP(C, NBV) hipLaunchKernelGGL((sic_leap_kernel<C, NBV, ST>), dim3(grid), dim3(512), 0, st, a, mdl)
   SIC_DISPATCH(SIC_LEAP);
 }
+
+void sic_launch_jump(const SicJumpArgsT<__bf16>& a, const SicModel& mdl, hipStream_t st) { sic_launch_jump_st(a, mdl, st); }
+void sic_launch_eval(const SicEvalArgsT<__bf16>& a, const SicModel& mdl, hipStream_t st) { sic_launch_eval_st(a, mdl, st); }
+void sic_launch_leap(const SicLeapArgsT<__bf16>& a, const SicModel& mdl, hipStream_t st) { sic_launch_leap_st(a, mdl, st); }
+void sic_launch_jump(const SicJumpArgsT<float>& a, const SicModel& mdl, hipStream_t st) { sic_launch_jump_st(a, mdl, st); }
+void sic_launch_eval(const SicEvalArgsT<float>& a, const SicModel& mdl, hipStream_t st) { sic_launch_eval_st(a, mdl, st); }
+void sic_launch_leap(const SicLeapArgsT<float>& a, const SicModel& mdl, hipStream_t st) { sic_launch_leap_st(a, mdl, st); }
 
 }  // namespace mjhmc

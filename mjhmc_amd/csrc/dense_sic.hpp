@@ -24,11 +24,14 @@ struct SicModel {
 };
 constexpr int kSicCopies = 1;
 
-struct SicJumpArgs {
-  const __bf16* X_in;
-  const __bf16* V_in;
-  __bf16* X_out;
-  __bf16* V_out;
+// ST = the type the state rows are STORED in: __bf16 (BASELINE.json configs[4]: "bf16 state / fp32 accumulate") or float
+// (the reference's own: TensorFlow float32 placeholders, tf_distributions.py:89).  The matrix-core operands are bf16 either way.
+template <typename ST>
+struct SicJumpArgsT {
+  const ST* X_in;
+  const ST* V_in;
+  ST* X_out;
+  ST* V_out;
   const float* EX_in;
   const float* EV_in;
   const float* Hflf_in;
@@ -47,7 +50,7 @@ struct SicJumpArgs {
   double* dwell;
   double* dwell_ring;
   uint8_t* trans;
-  const __bf16* noise;
+  const ST* noise;
   const double* rexp;
   const double* runif;  // replay uniforms of the discrete-time samplers [2N+1] or nullptr
   Control* ctl;
@@ -61,11 +64,12 @@ struct SicJumpArgs {
 };
 
 // stand-alone leapfrog operator on caller-supplied states (HMCState.leapfrog / L, hmc_state.py:86-100)
-struct SicLeapArgs {
-  const __bf16* X;
-  const __bf16* V;
-  __bf16* X_out;
-  __bf16* V_out;
+template <typename ST>
+struct SicLeapArgsT {
+  const ST* X;
+  const ST* V;
+  ST* X_out;
+  ST* V_out;
   float* G;        // float32 dE/dX at the end point [n][P * 1024], or nullptr
   float* EX;
   float* EV;
@@ -74,20 +78,27 @@ struct SicLeapArgs {
   float eps, chalf;
 };
 
-struct SicEvalArgs {
-  const __bf16* X;
+template <typename ST>
+struct SicEvalArgsT {
+  const ST* X;
   float* G;         // float32 [Npad][1024] or nullptr
   float* E;
   float* EV;
-  const __bf16* V;
-  __bf16* V_gen;
+  const ST* V;
+  ST* V_gen;
   int64_t N, ntiles, first_pid;
   RngKey key;
 };
 
-void sic_launch_jump(const SicJumpArgs& a, const SicModel& mdl, hipStream_t st);
-void sic_launch_eval(const SicEvalArgs& a, const SicModel& mdl, hipStream_t st);
-void sic_launch_leap(const SicLeapArgs& a, const SicModel& mdl, hipStream_t st);
+using SicJumpArgs = SicJumpArgsT<__bf16>;
+using SicLeapArgs = SicLeapArgsT<__bf16>;
+using SicEvalArgs = SicEvalArgsT<__bf16>;
+void sic_launch_jump(const SicJumpArgsT<__bf16>& a, const SicModel& mdl, hipStream_t st);
+void sic_launch_eval(const SicEvalArgsT<__bf16>& a, const SicModel& mdl, hipStream_t st);
+void sic_launch_leap(const SicLeapArgsT<__bf16>& a, const SicModel& mdl, hipStream_t st);
+void sic_launch_jump(const SicJumpArgsT<float>& a, const SicModel& mdl, hipStream_t st);
+void sic_launch_eval(const SicEvalArgsT<float>& a, const SicModel& mdl, hipStream_t st);
+void sic_launch_leap(const SicLeapArgsT<float>& a, const SicModel& mdl, hipStream_t st);
 // particles per 32-column tile: a tile holds whole particles (P columns each)
 inline int sic_particles_per_tile(int P) { return 32 / P; }
 

@@ -401,10 +401,18 @@ class SparseImageCode(Distribution):
     The reference reads ``distr_data/dump_{n_basis}.pkl`` (basis (256, n_basis) and image patches), which is
     not part of the reference checkout; pass ``basis`` (img_size, n_coeffs) and ``imgs`` (img_size, >= n_patches)
     instead.  State rows are patch-major (row p * n_coeffs + c), which is what the reference's reshape yields for
-    one active column.  The device kernel (bf16 state, bf16 MFMA operands, fp32 accumulation) covers
-    n_patches = 1, img_size = 256, n_coeffs = 1024 -- BASELINE.json configs[4]."""
+    one active column.  The device kernels (bf16 matrix-core operands, fp32 accumulation) cover img_size = 256,
+    n_coeffs = 1024 or 512, n_patches 1 ... 32.
 
-    def __init__(self, n_patches=9, n_batches=10, cauchy=True, n_basis=1024, basis=None, imgs=None, init=None):
+    ``state_dtype``: 'float32' (default) keeps the state as the reference does (TensorFlow float32 placeholders,
+    tf_distributions.py:89); 'bfloat16' is BASELINE.json configs[4] ("bf16 state / fp32 accumulate"): half the state bytes,
+    the same kernel time -- and a MarkovJumpHMC chain that runs measurably hot, because a state rounded to 8 bits at every
+    commit makes L irreversible (F L F L z != z at the 2^-9 level) while the jump process relies on exactly that identity
+    (DESIGN.md section 3.5, tests/test_gpu_stationary.py::test_sic_stationary_law).  The discrete-time samplers
+    (ControlHMC / HMC: Metropolis accept) keep the law with either."""
+
+    def __init__(self, n_patches=9, n_batches=10, cauchy=True, n_basis=1024, basis=None, imgs=None, init=None,
+                 state_dtype='float32'):
         self.max_n_particles = 50
         self.lmbda = 0.01
         if basis is None or imgs is None:
@@ -417,7 +425,9 @@ class SparseImageCode(Distribution):
         self.cauchy = cauchy
         self.patches = self.imgs[:, :n_patches].T            # (n_patches, img_size)
         self._init = init
-        self.state_dtype = 'bfloat16'
+        if state_dtype not in ('float32', 'bfloat16'):
+            raise ValueError("SparseImageCode state_dtype must be 'float32' or 'bfloat16'")
+        self.state_dtype = state_dtype
         self.backend = 'hip-mfma-bf16'
         super(SparseImageCode, self).__init__(ndims=n_patches * self.n_coeffs, nbatch=n_batches)
 

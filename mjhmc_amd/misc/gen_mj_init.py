@@ -103,6 +103,11 @@ def stable_digest(distribution):
         h.update(str(getattr(distribution, 'name', '')).encode())
     else:
         h.update(np.ascontiguousarray(params, dtype=np.float64).tobytes())
+    # the arithmetic the burn-in ran in, where the distribution offers a choice (ProductOfT: float64 / float32 state,
+    # SparseImageCode: float32 / bfloat16): its end points are those of THAT chain
+    dt = getattr(distribution, 'state_dtype', 'float64')
+    if dt != 'float64':
+        h.update(str(dt).encode())
     return h.hexdigest()[:16]
 
 

@@ -147,11 +147,19 @@ def test_pot_more_than_512_dims(D, N, state):
 # ---------------------------------------------------------------------------------------------
 # SparseImageCode: single evaluations
 # ---------------------------------------------------------------------------------------------
-def _sic(P, n, cauchy, X0):
+def _sic(P, n, cauchy, X0, state_dtype='bfloat16'):
     from mjhmc_amd.misc.distributions import SparseImageCode
     B, imgs, a0 = sic_problem(0, n_patches=P)
-    d = SparseImageCode(n_patches=P, n_batches=n, cauchy=cauchy, n_basis=1024, basis=B, imgs=imgs, init=X0)
+    d = SparseImageCode(n_patches=P, n_batches=n, cauchy=cauchy, n_basis=1024, basis=B, imgs=imgs, init=X0, state_dtype=state_dtype)
     return d, B, imgs
+
+
+def to_f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+# what storing the state does to it: SparseImageCode(state_dtype=...) -> the oracle's state_rounding
+_SIC_STATES = {'bfloat16': to_bf16, 'float32': to_f32}
 
 
 def _sic_cases():
@@ -297,22 +305,26 @@ def test_pot_iterations_from_the_reference_states():
     assert ties <= 0.002 * 6 * N + 2, ties            # near ties are rare by construction
 
 
-def test_sic_iterations_from_the_reference_states():
+@pytest.mark.parametrize('state', ['bfloat16', 'float32'])
+def test_sic_iterations_from_the_reference_states(state):
     """MJHMC on SparseImageCode (one patch, 1024 coefficients) from the end points the reference ships
-    (initializations/SparseImageCode_...pickle[0] and [3]; the dictionary itself is not in the reference checkout)."""
+    (initializations/SparseImageCode_...pickle[0] and [3]; the dictionary itself is not in the reference checkout).
+    `state`: the benchmark's bfloat16 state rows, or float32 rows as the reference's TensorFlow placeholders hold them
+    (the matrix-core operands are bf16 either way)."""
     from mjhmc_amd.samplers.markov_jump_hmc import MarkovJumpHMC
+    to_state = _SIC_STATES[state]
     r = load('ref_init_states')
-    X0 = to_bf16(np.concatenate([r['sic_mj_X'], r['sic_ctl_X']], axis=1))
+    X0 = to_state(np.concatenate([r['sic_mj_X'], r['sic_ctl_X']], axis=1))
     N = X0.shape[1]
-    d, B, imgs = _sic(1, N, True, X0)
+    d, B, imgs = _sic(1, N, True, X0, state)
     en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
     eps, L = 0.0625, 8             # a power of two: rounding the scaled residual == scaling the rounded residual
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=0.2, num_leapfrog_steps=L, seed=23, resample=False)
     o = orc.MarkovJumpHMC(en, X0, epsilon=eps, beta=0.2, num_leapfrog_steps=L, resample=False,
-                          rng=orc.PhiloxRNG(23, np.arange(N)), state_rounding=to_bf16)
+                          rng=orc.PhiloxRNG(23, np.arange(N)), state_rounding=to_state)
     _resync(s, o)
     for t in range(5):
-        check_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='sic it %d' % t)
+        check_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='sic %s it %d' % (state, t))
         assert s.l_count + s.f_count + s.r_count == (t + 1) * N
         _resync(s, o)
 
@@ -367,21 +379,22 @@ def test_pot_continuous_time_sampler_vs_oracle():
         _resync(s, o)
 
 
-@pytest.mark.parametrize('cls_name', ['ControlHMC', 'HMC'])
-def test_sic_discrete_time_samplers_vs_oracle(cls_name):
+@pytest.mark.parametrize('cls_name,state', [('ControlHMC', 'bfloat16'), ('HMC', 'bfloat16'), ('ControlHMC', 'float32')])
+def test_sic_discrete_time_samplers_vs_oracle(cls_name, state):
     from mjhmc_amd.samplers import markov_jump_hmc as M
     N = 40
+    to_state = _SIC_STATES[state]
     B, imgs, a0 = sic_problem(0)
-    X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(2).randn(1024, N))
-    d, B, imgs = _sic(1, N, True, X0)
+    X0 = to_state(a0[:, None] + 0.2 * np.random.RandomState(2).randn(1024, N))
+    d, B, imgs = _sic(1, N, True, X0, state)
     en = orc.SparseImageCode(B, imgs[:, :1].T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
     kw = dict(epsilon=0.0625, beta=0.6, num_leapfrog_steps=6)
     s = getattr(M, cls_name)(distribution=d, seed=47, **kw)
-    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(47, np.arange(N)), state_rounding=to_bf16, **kw)
+    o = getattr(orc, cls_name)(en, X0, rng=orc.PhiloxRNG(47, np.arange(N)), state_rounding=to_state, **kw)
     _resync(s, o)
     ties = 0
     for t in range(5):
-        ties += check_control_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='%s sic it %d' % (cls_name, t))
+        ties += check_control_iteration(s, o, delta_rel=5e-4, x_tol=1.0 / 128, e_rtol=5e-4, tag='%s sic %s it %d' % (cls_name, state, t))
         _resync(s, o)
     assert ties <= 1
     assert s.r_count > 0 or cls_name != 'ControlHMC'
@@ -466,7 +479,7 @@ def test_sic_several_patches_iterations_vs_oracle(P, N):
 def _sic512(P, n, cauchy, X0):
     from mjhmc_amd.misc.distributions import SparseImageCode
     B, imgs, a0 = sic_problem(3, n_patches=P, n_coeffs=512)
-    return SparseImageCode(n_patches=P, n_batches=n, cauchy=cauchy, n_basis=512, basis=B, imgs=imgs, init=X0), B, imgs, a0
+    return SparseImageCode(n_patches=P, n_batches=n, cauchy=cauchy, n_basis=512, basis=B, imgs=imgs, init=X0, state_dtype='bfloat16'), B, imgs, a0
 
 
 @pytest.mark.parametrize('P,n,cauchy', [(1, 40, True), (1, 5, False), (9, 4, True)])

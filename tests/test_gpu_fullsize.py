@@ -147,7 +147,7 @@ def test_full_size_c5_sparse_image_code(eps, n_iter):
     assert eps in (0.0625, w['eps'])
     B, y, a0 = bench.sic_model()
     X0 = to_bf16(bench.initial_state(w, N, 0))
-    d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y.reshape(256, 1), init=X0)
+    d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y.reshape(256, 1), init=X0, state_dtype='bfloat16')
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=31, resample=False)
     cols = np.sort(np.random.RandomState(6).choice(N, size=48, replace=False))
     en = orc.SparseImageCode(B, y.reshape(1, -1), lmbda=0.01, cauchy=True, operand_rounding=to_bf16)

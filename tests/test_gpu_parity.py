@@ -771,7 +771,7 @@ def test_sic_energy_and_gradient(cauchy):
     n = 70
     rs = np.random.RandomState(1)
     X = to_bf16(a0[:, None] + 0.3 * rs.randn(1024, n))           # representable in the state dtype
-    d = SparseImageCode(n_patches=1, n_batches=n, cauchy=cauchy, n_basis=1024, basis=B, imgs=y, init=X)
+    d = SparseImageCode(n_patches=1, n_batches=n, cauchy=cauchy, n_basis=1024, basis=B, imgs=y, init=X, state_dtype='bfloat16')
     o = orc.SparseImageCode(to_bf16(B), y.T, lmbda=0.01, cauchy=cauchy)   # the dictionary is an MFMA operand: bf16
     E, G = d.E(X), d.dEdX(X)
     Eo, Go = o.E_val(X), o.dEdX_val(X)
@@ -797,7 +797,7 @@ def test_sic_iterations_vs_oracle():
     B, y, a0 = sic_problem()
     N, eps, L, beta, seed = 96, 0.0625, 10, 0.2, 5
     X0 = to_bf16(a0[:, None] + 0.2 * np.random.RandomState(2).randn(1024, N))
-    d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y, init=X0)
+    d = SparseImageCode(n_patches=1, n_batches=N, cauchy=True, n_basis=1024, basis=B, imgs=y, init=X0, state_dtype='bfloat16')
     en = orc.SparseImageCode(B, y.T, lmbda=0.01, cauchy=True, operand_rounding=to_bf16)
     s = MarkovJumpHMC(distribution=d, epsilon=eps, beta=beta, num_leapfrog_steps=L, seed=seed, resample=False)
     o = orc.MarkovJumpHMC(en, X0, epsilon=eps, beta=beta, num_leapfrog_steps=L, resample=False,

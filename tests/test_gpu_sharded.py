@@ -221,7 +221,7 @@ def test_rccl_communicator_entry_points(tmp_path):
     X0 = to_bf16(a0[:, None] + 0.1 * np.random.RandomState(3).randn(1024, 40))
     outs = []
     for c in (comm, None):
-        d = SparseImageCode(n_patches=1, n_batches=40, n_basis=1024, basis=B, imgs=imgs, init=X0)
+        d = SparseImageCode(n_patches=1, n_batches=40, n_basis=1024, basis=B, imgs=imgs, init=X0, state_dtype='bfloat16')
         s = MarkovJumpHMC(distribution=d, epsilon=0.05, beta=0.2, num_leapfrog_steps=4, seed=6, comm=c, resample=False)
         outs.append(s.sample(3))
     assert np.array_equal(outs[0], outs[1])
