@@ -405,6 +405,37 @@ int dispatch_flf<float>(int kind, const FlfArgs<float>& a, const EnergyParams& e
 }
 
 template <typename T>
+static int dispatch_step(int kind, const TrajArgs<T>* ta, const JumpDecideArgs<T>* da, const EnergyParams& ep, int E, hipStream_t st);
+template <>
+int dispatch_step<double>(int kind, const TrajArgs<double>* ta, const JumpDecideArgs<double>* da, const EnergyParams& ep, int E,
+                          hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_step_f64(ta, da, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_step_f64(ta, da, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_step_f64(ta, da, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_step_f64(ta, da, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_step_f64(ta, da, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_step_f64(ta, da, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no trajectory / jump-process kernel");
+  }
+  return 0;
+}
+template <>
+int dispatch_step<float>(int kind, const TrajArgs<float>* ta, const JumpDecideArgs<float>* da, const EnergyParams& ep, int E,
+                         hipStream_t st) {
+  switch (kind) {
+    case MJHMC_E_ISO_GAUSS: iso_step_f32(ta, da, ep, E, st); break;
+    case MJHMC_E_DIAG_GAUSS: diag_step_f32(ta, da, ep, E, st); break;
+    case MJHMC_E_ROUGH_WELL: rough_step_f32(ta, da, ep, E, st); break;
+    case MJHMC_E_MM_GAUSS: mm_step_f32(ta, da, ep, E, st); break;
+    case MJHMC_E_FUNNEL_NEAL: funnel_neal_step_f32(ta, da, ep, E, st); break;
+    case MJHMC_E_FUNNEL_REF: funnel_ref_step_f32(ta, da, ep, E, st); break;
+    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no trajectory / jump-process kernel");
+  }
+  return 0;
+}
+
+template <typename T>
 static int dispatch_eval(int kind, const EvalArgs<T>& a, const EnergyParams& ep, int E, hipStream_t st);
 template <>
 int dispatch_eval<double>(int kind, const EvalArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {
@@ -1556,7 +1587,6 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     l.xin = xin;
     l.xout = out_of(i0, l.K, xin);
     TRY(launch(l, s->stats + 4 * (size_t)i0));
-    if (ring_slot0 >= 0) TRY(dl_mark(s, i0, l.K, &s->stream, 1));   // (the parts of a split launch have joined the sampler's stream)
     launches.push_back(l);
     xin = l.xout;
   }
@@ -1608,8 +1638,9 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   return 0;
 }
 
-// batches of the non-Gaussian elementwise energies below this many particles run fused (tools/sweep_shard_c4.py)
-constexpr int64_t kFuseBelow = 16384;
+// batches of the non-Gaussian elementwise energies below this many particles run fused (tools/sweep_shard_c4.py: the funnel at
+// 125 000 particles 0.047 ms per iteration fused, 0.051 as trajectory + jump-process launches; at 250 000 0.094 against 0.082)
+constexpr int64_t kFuseBelow = 160000;
 
 template <typename T>
 static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, const double* replay_exp,
@@ -1640,21 +1671,21 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   HIPCHK(hipMemsetAsync(s->stats, 0, (size_t)n_iter * 4 * sizeof(long long), s->stream));
 
   // Several particles per wave and a big batch: the inverse-L trajectory of the cold-cache particles runs in its
-  // own compacted pass (mjhmc_flf_kernel) instead of in every wave of the jump kernel that holds a cold particle.
+  // the list's own workgroups of mjhmc_traj_kernel instead of in every wave of the jump kernel that holds a cold particle.
   const bool compact = s->mode == MJHMC_MODE_MJHMC && !s->en->is_dense() && !s->en->is_user() && !replay_normal && !replay_exp &&
-                       s->sh.logG < 6 && s->N >= 16384 && !test_env("MJHMC_NO_COMPACT");
+                       s->sh.logG < 6 && s->N >= 16384 && !test_env("MJHMC_NO_COMPACT");   // (reached from kFuseBelow particles up, or MJHMC_NO_FUSE)
   if (compact) {
     if (!s->flf_list) {
-      HIPCHK(hipMalloc((void**)&s->flf_list, (size_t)s->Npad * sizeof(int)));
+      HIPCHK(hipMalloc((void**)&s->flf_list, (size_t)2 * s->Npad * sizeof(int)));   // two lists: iterations alternate
       HIPCHK(hipMalloc(&s->Hpre, (size_t)2 * s->Npad * ssize(s)));
     }
-    if (s->flf_cap < n_iter) {  // [n_iter] cold counts, then [n_iter] R-mover counts
+    if (s->flf_cap < n_iter + 1) {  // a counter per iteration of the call (+ the one the last iteration's movers go to)
       if (s->flf_counts) HIPCHK(hipFree(s->flf_counts));
       s->flf_counts = nullptr;
-      HIPCHK(hipMalloc((void**)&s->flf_counts, (size_t)2 * n_iter * sizeof(int)));
-      s->flf_cap = n_iter;
+      HIPCHK(hipMalloc((void**)&s->flf_counts, (size_t)(n_iter + 1) * sizeof(int)));
+      s->flf_cap = n_iter + 1;
     }
-    HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)2 * n_iter * sizeof(int), s->stream));
+    HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)(n_iter + 1) * sizeof(int), s->stream));
   }
 
   // dense batches: free-running parts on their own streams (part_args; the story is above iterate_fused_t)
@@ -1949,73 +1980,77 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         else launch_sic(float{});
       }
     } else {
-      // Compacted passes around the jump kernel (big batches with several particles per wave):
-      //   [cold list of iteration 0]  { inverse-L pass i (+ the momentum refresh iteration i-1 left pending) ; jump i ;
-      //   cold list of iteration i+1 }  ...  [R list + refresh of the last iteration]
-      // -- three launches per iteration.  The R-movers of an iteration are all on the next iteration's cold list (an R
-      // move clears the cache), so their refresh rides in that inverse-L pass; only the call's last iteration needs
-      // the stand-alone refresh.  The state every iteration hands on is complete before anything reads it.
-      T* hpre = (T*)s->Hpre + (size_t)(i & 1) * s->Npad;
-      const dim3 list_grid((unsigned)((s->N + kColdChunk - 1) / kColdChunk));
       if (compact) {
-        if (i == 0)
+        // elementwise.hpp (mjhmc_step_kernel): the iteration's trajectories -- the L proposals and, beside them, the
+        // inverse-L proposals of the listed cold caches --, then its jump process with a lane per particle, which finishes
+        // the movers and hands them on as the next iteration's list (only the first iteration of a call scans the cache).
+        // (Measured and dropped: the batch as two halves on two free-running streams, 0.2551 ms against 0.2623 for C4 on the
+        // device but more launches than the host issues in that time; and the halves staggered by half an iteration inside
+        // ONE launch sequence -- every launch the trajectories of one half beside the jump process of the other --,
+        // 0.2586 ms: the trajectories keep the vector pipe half busy themselves, there is no idle unit to hide the jump
+        // process under.  DESIGN.md section 8c.)
+        TrajArgs<T> ta;
+        JumpDecideArgs<T> da;
+        ta.X_in = a.X_in;
+        ta.V_in = a.V_in;
+        ta.X_out = a.X_out;
+        ta.V_out = a.V_out;
+        ta.EX_out = a.EX_out;
+        ta.EV_out = a.EV_out;
+        ta.Hwork = (T*)s->Hpre;
+        ta.list = s->flf_list + (size_t)(i & 1) * s->Npad;
+        ta.count = s->flf_counts + i;
+        ta.ctl = s->ctl;
+        ta.N = a.N;
+        ta.D = a.D;
+        ta.pitch = a.pitch;
+        ta.CH = a.CH;
+        ta.logG = a.logG;
+        ta.L = a.L;
+        const int64_t ppb = 256 >> a.logG;   // the list's walkers: sized for a typical list (a few per cent of the batch)
+        ta.inv_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.N + ppb - 1) / ppb / 8, 2048));
+        ta.eps = a.eps;
+        ta.chalf = a.chalf;
+        da.X_in = a.X_in;
+        da.V_in = a.V_in;
+        da.X_out = a.X_out;
+        da.V_out = a.V_out;
+        da.EX_in = a.EX_in;
+        da.EV_in = a.EV_in;
+        da.EX_out = a.EX_out;
+        da.EV_out = a.EV_out;
+        da.Hflf_in = a.Hflf_in;
+        da.Hwork = ta.Hwork;
+        da.Hflf_out = a.Hflf_out;
+        da.dwell = a.dwell;
+        da.dwell_ring = a.dwell_ring;
+        da.trans = a.trans;
+        da.next_list = s->flf_list + (size_t)((i + 1) & 1) * s->Npad;
+        da.next_count = s->flf_counts + i + 1;
+        da.ctl = s->ctl;
+        da.stats = a.stats;
+        da.N = a.N;
+        da.first_pid = a.first_pid;
+        da.D = a.D;
+        da.pitch = a.pitch;
+        da.CH = a.CH;
+        da.logG = a.logG;
+        da.iter = a.iter;
+        da.r_keep = a.r_keep;
+        da.r_mix = a.r_mix;
+        da.p_r = a.p_r;
+        da.key = a.key;
+        if (i == 0) {
+          const dim3 list_grid((unsigned)((s->N + kColdChunk - 1) / kColdChunk));
           hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, list_grid, dim3(1024), 0, s->stream,
-                             ColdCache<T>{a.Hflf_in, hpre}, s->N, s->ctl, s->flf_list, s->flf_counts);
-        FlfArgs<T> fa;
-        fa.X = a.X_in;
-        fa.V = const_cast<T*>(a.V_in);
-        fa.H_out = hpre;
-        fa.list = s->flf_list;
-        fa.count = s->flf_counts + i;
-        fa.ctl = s->ctl;
-        fa.D = a.D;
-        fa.pitch = a.pitch;
-        fa.CH = a.CH;
-        fa.logG = a.logG;
-        fa.L = a.L;
-        fa.eps = a.eps;
-        fa.chalf = a.chalf;
-        fa.pending_r = i > 0 ? 1 : 0;
-        fa.trans = s->trans;
-        fa.EV = const_cast<T*>(a.EV_in);
-        fa.first_pid = s->first_pid;
-        fa.r_keep = a.r_keep;
-        fa.r_mix = a.r_mix;
-        const uint64_t tick_prev = tick - 1;
-        fa.key_prev = RngKey{a.key.k0, a.key.k1, (uint32_t)(tick_prev & 0xFFFFFFFFu), (uint32_t)(tick_prev >> 32)};
-        TRY(dispatch_flf<T>(s->en->ep.kind, fa, s->en->ep, s->sh.E, s->N, s->stream));
-        a.Hflf_in = hpre;  // every cache reads as warm in the jump kernel
-        a.defer_r = 1;     // and the R-movers keep their old momentum for now
-      }
-      if (s->en->is_user()) {
+                             ColdCache<T>{a.Hflf_in, (T*)s->Hpre + s->Npad}, s->N, s->ctl, s->flf_list, s->flf_counts);
+        }
+        TRY(dispatch_step<T>(s->en->ep.kind, &ta, nullptr, s->en->ep, s->sh.E, s->stream));
+        TRY(dispatch_step<T>(s->en->ep.kind, nullptr, &da, s->en->ep, s->sh.E, s->stream));
+      } else if (s->en->is_user()) {
         if constexpr (sizeof(T) == 8) TRY(user_launch_jump(s->en, a, s->stream));
       } else {
         TRY(dispatch_jump<T>(s->en->ep.kind, a, s->en->ep, s->sh.E, s->stream));
-      }
-      if (compact && i + 1 < n_iter) {
-        hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, list_grid, dim3(1024), 0, s->stream,
-                           ColdCache<T>{a.Hflf_out, (T*)s->Hpre + (size_t)((i + 1) & 1) * s->Npad}, s->N, s->ctl, s->flf_list,
-                           s->flf_counts + i + 1);
-      } else if (compact) {
-        int* r_count = s->flf_counts + n_iter;
-        hipLaunchKernelGGL(compact_list_kernel<MovedBy>, list_grid, dim3(1024), 0, s->stream, MovedBy{s->trans, 2}, s->N, s->ctl,
-                           s->flf_list, r_count);
-        RefreshArgs<T> ra;
-        ra.V_in = a.V_in;
-        ra.V_out = a.V_out;
-        ra.EV_out = a.EV_out;
-        ra.list = s->flf_list;
-        ra.count = r_count;
-        ra.ctl = s->ctl;
-        ra.first_pid = s->first_pid;
-        ra.D = a.D;
-        ra.pitch = a.pitch;
-        ra.CH = a.CH;
-        ra.logG = a.logG;
-        ra.r_keep = a.r_keep;
-        ra.r_mix = a.r_mix;
-        ra.key = a.key;
-        launch_refresh<T>(ra, s->sh.E, s->N, s->stream);
       }
     }
     if (n_parts > 1 && i + 1 == n_iter) {  // the read-back follows every part
@@ -2025,22 +2060,25 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       }
     }
     HIPCHK(hipGetLastError());
-    if (s->dl && ring_slot0 >= 0 && i >= s->dl->marked.load(std::memory_order_acquire)) {
-      // Iteration i is complete when every stream that ran part of it gets here -- and each of them re-tiles its own
-      // columns of the new X into staging slot i on the way (0.3 ms of a 17 ms C3 iteration): on a stream of its own that
-      // kernel waited for a workgroup of the NEXT iteration's persistent grid to leave, so every slot crossed PCIe one
-      // iteration late and two of them after the run had ended.  The worker then only moves bytes (copy engine + host).
+    // sample download (mjhmc_iterate_download): iteration j is complete when every stream that ran part of it gets here --
+    // and each of them re-tiles its own columns of the new X into staging slot j on the way (0.3 ms of a 17 ms C3
+    // iteration): on a stream of its own that kernel waited for a workgroup of the NEXT iteration's persistent grid to
+    // leave, so every slot crossed PCIe one iteration late and two of them after the run had ended.  The worker then only
+    // moves bytes (copy engine + host).
+    auto dl_done = [&](int j, const void* xj) -> int {
+      if (!(s->dl && ring_slot0 >= 0 && j >= s->dl->marked.load(std::memory_order_acquire))) return 0;
       hipStream_t sts[kMaxDenseParts];
       const size_t elems = (size_t)s->D * s->N;
       const bool room = s->dl_stage_elems >= (size_t)s->dl->n_iter * elems;
       for (int k = 0; k < n_parts; ++k) {
         sts[k] = part_stream(k);
-        if (room) TRY(dl_retile(s, xo, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
-                                s->dl_stage + (size_t)i * elems, sts[k]));
+        if (room) TRY(dl_retile(s, xj, n_parts > 1 ? part_start(k) : 0, n_parts > 1 ? part_count(k) : s->N,
+                                s->dl_stage + (size_t)j * elems, sts[k]));
       }
-      s->dl->retiled[(size_t)i] = room ? 1 : 0;
-      TRY(dl_mark(s, i, 1, sts, n_parts));
-    }
+      s->dl->retiled[(size_t)j] = room ? 1 : 0;
+      return dl_mark(s, j, 1, sts, n_parts);
+    };
+    TRY(dl_done(i, xo));
     xin = xo;
   }
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
@@ -2059,7 +2097,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
 
   const int done = hc.failed ? hc.failed_iter : n_iter;
   const int attempts = hc.failed ? done + 1 : n_iter;
-  if (compact) {  // the jump kernel saw warm caches only: the cold tallies are the list lengths
+  if (compact) {  // the cold tallies are the list lengths (of every part)
     std::vector<int> hcnt((size_t)attempts);
     HIPCHK(hipMemcpy(hcnt.data(), s->flf_counts, hcnt.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < attempts; ++i) hs[4 * (size_t)i + 3] = hcnt[(size_t)i];
@@ -2345,7 +2383,9 @@ int mjhmc_ring_alloc(mjhmc_sampler* s, int n_slots) {
                   n_slots, mb / 1e9, (double)n_slots * mb / 1e9, free_b / 1e9, total_b / 1e9);
     return fail(MJHMC_ERR_HIP, msg);
   }
-  HIPCHK(hipMemset(ring, 0, (size_t)n_slots * mb));
+  // (on the sampler's stream: it does not wait for the null stream, and a memset there can land AFTER the first slots are written)
+  HIPCHK(hipMemsetAsync(ring, 0, (size_t)n_slots * mb, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
   s->undo_valid = false;
   // the live X may sit in the old ring: park it in a ping-pong buffer before freeing
   if (s->ring && (char*)s->Xcur >= (char*)s->ring && (char*)s->Xcur < (char*)s->ring + (size_t)s->ring_slots * mb) {

@@ -617,6 +617,57 @@ struct RefreshArgs {
   RngKey key;         // the attempt's tick: the same normals the jump kernel would have drawn
 };
 
+// Round 5: a MarkovJumpHMC iteration of a big batch with several particles per wavefront as TWO launches --
+// mjhmc_traj_kernel integrates (the L proposal of every particle, and beside it the inverse-L proposal of the listed
+// cold-cache particles), mjhmc_decide_kernel runs the jump process (see there).
+template <typename T>
+struct TrajArgs {
+  const T* X_in;      // [Npad][pitch] pre-move state
+  const T* V_in;
+  T* X_out;           // the end point of L, written for every particle as if the move were taken
+  T* V_out;
+  T* EX_out;          // [Npad] its energies
+  T* EV_out;
+  T* Hwork;           // [Npad] H() of the inverse-L proposal F L F, written for the listed particles only
+  const int* list;    // the particles with a cold cache
+  const int* count;   // how many
+  const Control* ctl;
+  int64_t N;
+  int D, pitch, CH, logG;
+  int L;
+  int inv_blocks;     // leading workgroups of the grid that walk the list (the rest: one forward slot each)
+  T eps, chalf;
+};
+
+template <typename T>
+struct JumpDecideArgs {
+  const T* X_in;      // pre-move state: what an F / R mover keeps
+  const T* V_in;
+  T* X_out;           // in: the L proposal; out: the successor
+  T* V_out;
+  const T* EX_in;
+  const T* EV_in;
+  T* EX_out;          // in: energies of the L proposal
+  T* EV_out;
+  const T* Hflf_in;   // H() of the cached inverse-L state, NaN = cold: then Hwork has it
+  const T* Hwork;
+  T* Hflf_out;
+  double* dwell;
+  double* dwell_ring;
+  uint8_t* trans;
+  int* next_list;     // the next iteration's cold caches: this iteration's F- and R-movers
+  int* next_count;
+  Control* ctl;
+  unsigned long long* stats;   // [4]: #L, #F, #R (the cold tally is the list's length)
+  int64_t N;
+  int64_t first_pid;
+  int D, pitch, CH, logG;
+  int iter;
+  T r_keep, r_mix;
+  double p_r;
+  RngKey key;
+};
+
 // ------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------
@@ -1720,6 +1771,246 @@ __global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T>
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5.  A MarkovJumpHMC iteration of a big batch with several particles per wavefront (C4: 16 particles per wave)
+// used to be three launches on one stream -- inverse-L pass over the compacted cold caches (a trajectory's latency on a
+// few waves: 32 us of C4's 269), jump kernel, list scan -- with the jump process inside the jump kernel: its ~350
+// instructions per wave run on the lanes of the particles' groups between the trajectory and the stores of every slot.
+// Now two launches of two KINDS:
+//
+//   mjhmc_traj_kernel    integrates and nothing else: memory-bound (C4: 1.02 GB in 0.20 ms = 5.1 TB/s).  Leading
+//                        workgroups walk the list (the inverse-L proposals, beside the forward slots instead of in front of
+//                        them); every other workgroup is one forward slot: load, trajectory, energies, store the end point
+//                        AS IF the move were taken.  No LDS, no decision code, no second register set.
+//   mjhmc_decide_kernel  the jump process with ONE LANE PER PARTICLE (64 live lanes of a wave instead of 16 groups'
+//                        worth): rates, clocks, first minimum, dwelling time, counters (markov_jump_hmc.py:366-415):
+//                        vector-pipe-bound.  The workgroup's movers (7 % of C4) are compacted in LDS and finished by lane
+//                        groups: pre-move position put back, momentum flipped or redrawn (HMCState.R, with its kinetic
+//                        energy); and they ARE the next iteration's list: one atomic per workgroup, no list scan.
+//
+// The same device functions as the jump kernel (trajectory, state_energies, decide, refresh_stash, kinetic) on the same
+// inputs: the same bits (tests/test_gpu_fused.py compares the paths).  C4: 0.269 -> 0.262 ms per iteration, 125 000
+// particles 0.057 -> 0.051.  (mjhmc_step_kernel can carry the trajectories of one part of a batch beside the jump process
+// of another; api.hip does not use that: measured, no gain -- the trajectories keep the vector pipe half busy themselves.)
+// ------------------------------------------------------------------------------------------
+template <class En, typename T, int E>
+__device__ __forceinline__ void traj_block(const TrajArgs<T>& a, const En& en, int vblock) {
+  const int G = 1 << a.logG;
+  const int lane = threadIdx.x & 63;
+  LaneMap m;
+  m.j = (int)(threadIdx.x & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = lane & ~(G - 1);
+  m.wpp = 0;
+  const auto lc = en.template local<E>(m);
+  const int ppb = 256 >> a.logG;  // particles per workgroup
+  if (vblock < a.inv_blocks) {
+    // inverse-L proposal F L F of the listed particles; only H() of it is ever read (markov_jump_hmc.py:360,367)
+    const int n_cold = *a.count;
+    for (int64_t first = (int64_t)vblock * ppb; first < n_cold; first += (int64_t)a.inv_blocks * ppb) {
+      const int64_t idx = first + (threadIdx.x >> a.logG);
+      const bool live = idx < n_cold;
+      const int64_t p = a.list[live ? idx : 0];
+      T x[E], v[E];
+      load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, x);
+      load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = -v[e];
+      trajectory<En, T, E, false>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+      T ex, ev;
+      state_energies<En, T, E>(en, lc, m, x, v, ex, ev);
+      if (live && m.j == 0) a.Hwork[p] = ex + ev;
+    }
+    return;
+  }
+  const int64_t p_raw = (int64_t)(vblock - a.inv_blocks) * ppb + (threadIdx.x >> a.logG);
+  const bool alive = p_raw < a.N;
+  const int64_t p = alive ? p_raw : a.N - 1;
+  T x[E], v[E];
+  load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, x);
+  load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
+  trajectory<En, T, E, false>(en, lc, m, x, v, a.L, a.eps, a.chalf);
+  T EXL, EVL;
+  state_energies<En, T, E>(en, lc, m, x, v, EXL, EVL);
+  if (alive) {
+    store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
+    store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+    if (m.j == 0) {
+      a.EX_out[p] = EXL;
+      a.EV_out[p] = EVL;
+    }
+  }
+}
+
+template <typename T, int E>
+struct DecideShared {
+  typename VecOf<T>::type stash[4][E / VecOf<T>::n][64];
+  int movers[256];       // this workgroup's movers: particle of the workgroup << 2 | move
+  int n_f, n_r, list_base;
+  unsigned tally[3];
+  int any_bad;
+};
+template <typename T, int E>
+__device__ __forceinline__ void decide_block(const JumpDecideArgs<T>& a, DecideShared<T, E>& sh, int vblock) {
+  auto& stash = sh.stash;
+  auto& movers = sh.movers;
+  int& n_f = sh.n_f;
+  int& n_r = sh.n_r;
+  int& list_base = sh.list_base;
+  auto& tally = sh.tally;
+  int& any_bad = sh.any_bad;
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    n_f = 0;
+    n_r = 0;
+    any_bad = 0;
+  }
+  if (threadIdx.x < 3) tally[threadIdx.x] = 0;
+  __syncthreads();
+  // ---- the jump process, one lane per particle ------------------------------------------------------------------------
+  {
+    const int64_t p_raw = (int64_t)vblock * 256 + threadIdx.x;
+    const bool alive = p_raw < a.N;
+    const int64_t p = alive ? p_raw : a.N - 1;
+    const T EX0 = a.EX_in[p], EV0 = a.EV_in[p];
+    const T H0 = EX0 + EV0;                   // HMCState.H (hmc_state.py:80-84)
+    const T HL = a.EX_out[p] + a.EV_out[p];
+    T Hflf = a.Hflf_in[p];
+    if (!(Hflf == Hflf)) Hflf = a.Hwork[p];   // cold cache: integrated by this iteration's mjhmc_traj_kernel
+    JumpArgs<T> ja;
+    ja.p_r = a.p_r;
+    ja.rexp = nullptr;
+    ja.runif = nullptr;
+    ja.N = a.N;
+    LaneMap m1;
+    m1.j = 0;
+    m1.G = 1;
+    m1.D = 1;
+    m1.CH = 1;
+    m1.lane0 = 0;
+    m1.wpp = 0;
+    int k = 0;
+    double dwell = 0.0;
+    bool bad = false;
+    decide<T, false>(ja, a.key, m1, H0, HL, Hflf, p, (uint32_t)(a.first_pid + p), k, dwell, bad);
+    if (alive) {
+      a.Hflf_out[p] = (k == 0) ? H0 : (T)__builtin_nan("");   // L: the pre-move state becomes the cached inverse-L state
+      a.dwell[p] = dwell;
+      a.dwell_ring[p] = dwell;
+      a.trans[p] = (uint8_t)k;
+      if (k != 0) {                            // F / R keep the position; an R-mover's kinetic energy follows below
+        a.EX_out[p] = EX0;
+        a.EV_out[p] = EV0;
+      }
+      if (bad) any_bad = 1;
+    }
+    const unsigned long long b0 = __ballot(alive && k == 0), b1 = __ballot(alive && k == 1), b2 = __ballot(alive && k == 2);
+    if (lane == 0) {
+      if (b0) atomicAdd(&tally[0], (unsigned)__popcll(b0));
+      if (b1) atomicAdd(&tally[1], (unsigned)__popcll(b1));
+      if (b2) atomicAdd(&tally[2], (unsigned)__popcll(b2));
+    }
+    // the R-movers from the front of the array, the F-movers from its back: the lane groups that redraw a momentum
+    // (Philox + Box-Muller: ~1000 instructions) sit together in as few waves as possible
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (b2) {
+      int at = 0;
+      if (lane == 0) at = atomicAdd(&n_r, (int)__popcll(b2));
+      at = __shfl(at, 0);
+      if (alive && k == 2) movers[at + (int)__popcll(b2 & below)] = ((int)threadIdx.x << 2) | 2;
+    }
+    if (b1) {
+      int at = 0;
+      if (lane == 0) at = atomicAdd(&n_f, (int)__popcll(b1));
+      at = __shfl(at, 0);
+      if (alive && k == 1) movers[255 - (at + (int)__popcll(b1 & below))] = ((int)threadIdx.x << 2) | 1;
+    }
+  }
+  __syncthreads();
+  const int nr = n_r, nf = n_f, nm = nr + nf;
+  if (threadIdx.x == 0) {
+    if (any_bad) {  // draw_from's ValueError (utils.py:43-48): the host rolls this attempt back
+      a.ctl->failed = 1;
+      a.ctl->failed_iter = a.iter;
+    }
+    list_base = nm ? atomicAdd(a.next_count, nm) : 0;
+  }
+  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+  __syncthreads();
+  auto mover = [&](int i) { return movers[i < nr ? i : 255 - (i - nr)]; };
+  // every move but L clears the cache (markov_jump_hmc.py:409-410): the movers are the next iteration's list
+  for (int i = threadIdx.x; i < nm; i += 256) a.next_list[list_base + i] = (int)((int64_t)vblock * 256 + (mover(i) >> 2));
+  // ---- the movers' successor states, a lane group per mover ------------------------------------------------------------
+  const int G = 1 << a.logG;
+  LaneMap m;
+  m.j = (int)(threadIdx.x & (G - 1));
+  m.G = G;
+  m.D = a.D;
+  m.CH = a.CH;
+  m.lane0 = lane & ~(G - 1);
+  m.wpp = 0;
+  const int ppb = 256 >> a.logG;
+  for (int first = 0; first < nm; first += ppb) {
+    const int idx = first + (threadIdx.x >> a.logG);
+    const bool live = idx < nm;
+    const int code = mover(live ? idx : 0);
+    const int64_t p = (int64_t)vblock * 256 + (code >> 2);
+    const int k = code & 3;
+    if (__ballot(live) == 0ull) continue;   // (a wave without a mover has nothing to do)
+    T x[E], v[E];
+    load_row<T, E>(a.X_in + (size_t)p * a.pitch, m, x);
+    load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
+    const bool r = live && k == 2;
+    if (__ballot(r) != 0ull) {  // HMCState.R (hmc_state.py:121-129)
+      stash_put<T, E>(stash[wib], lane, v);
+      refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key, (uint32_t)(a.first_pid + p), m, a.r_keep, a.r_mix);
+      T vr[E];
+      stash_get<T, E>(stash[wib], lane, vr);
+      const T evr = kinetic<T, E>(vr, m);
+      if (r) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = vr[e];
+        if (m.j == 0) a.EV_out[p] = evr;
+      }
+    }
+    if (live && k == 1) {       // HMCState.F
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = -v[e];
+    }
+    if (live) {
+      store_row<T, E>(a.X_out + (size_t)p * a.pitch, m, x);
+      store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
+    }
+  }
+}
+
+
+// One launch = the trajectories of one half of the batch (TrajArgs) BESIDE the jump process of the other half
+// (JumpDecideArgs), their workgroups interleaved four to one -- the ratio of their grids -- so that every CU holds both
+// kinds at any time; either side may be absent (n_traj or n_decide zero: the first and the last launch of a call).
+template <class En, typename T, int E>
+__global__ __launch_bounds__(256) void mjhmc_step_kernel(const TrajArgs<T> ta, const JumpDecideArgs<T> da, const En en,
+                                                         int n_traj, int n_decide) {
+  __shared__ DecideShared<T, E> sh;
+  if ((n_traj ? ta.ctl : da.ctl)->failed) return;
+  const int b = blockIdx.x;
+  const int groups = min(n_decide, n_traj / 4);      // [4 trajectory workgroups, 1 deciding workgroup] x groups, then the rest
+  int role, vb;                                      // role 0: trajectories, 1: jump process
+  if (b < 5 * groups) {
+    const int g = b / 5, r = b % 5;
+    role = r == 4;
+    vb = role ? g : 4 * g + r;
+  } else {
+    const int rest = b - 5 * groups, left_t = n_traj - 4 * groups;
+    role = rest >= left_t;
+    vb = role ? groups + (rest - left_t) : 4 * groups + rest;
+  }
+  if (role == 0) traj_block<En, T, E>(ta, en, vb);
+  else decide_block<T, E>(da, sh, vb);
+}
+
 #ifndef __HIPCC_RTC__
 constexpr int64_t kListGrid = 256 * 16;  // workgroups of the compacted-list passes (256 CUs x 8 resident + a second round)
 template <typename T>
@@ -1924,6 +2215,21 @@ inline void launch_flf_t(const FlfArgs<T>& a, const En& en, int64_t n_max, hipSt
                      dim3(256), 0, st, a, en);
 }
 
+// trajectories: one workgroup per 256 >> logG particles + the list's walkers in front; jump process: one per 256 particles
+template <class En, typename T, int E>
+inline void launch_step_t(const TrajArgs<T>* ta, const JumpDecideArgs<T>* da, const En& en, hipStream_t st) {
+  int n_traj = 0, n_decide = 0;
+  if (ta) {
+    const int64_t ppb = 256 >> ta->logG;
+    n_traj = (int)((ta->N + ppb - 1) / ppb) + ta->inv_blocks;
+  }
+  if (da) n_decide = (int)((da->N + 255) / 256);
+  const TrajArgs<T> t = ta ? *ta : TrajArgs<T>{};
+  const JumpDecideArgs<T> d = da ? *da : JumpDecideArgs<T>{};
+  hipLaunchKernelGGL((mjhmc_step_kernel<En, T, E>), dim3((unsigned)(n_traj + n_decide)), dim3(256), 0, st, t, d, en, n_traj,
+                     n_decide);
+}
+
 template <class En, typename T, int E>
 inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
   const int64_t threads = a.N << a.logG;
@@ -1969,6 +2275,18 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
     else if (E == 16) launch_flf_t<decltype(en), float, 16>(a, en, n, st);                                \
     else launch_flf_t<decltype(en), float, 32>(a, en, n, st);                                             \
   }                                                                                                       \
+  void NAME##_step_f64(const TrajArgs<double>* ta, const JumpDecideArgs<double>* da, const EnergyParams& ep, int E, hipStream_t st) { \
+    const auto en = MAKE64(ep);                                                                           \
+    if (E == 2) launch_step_t<decltype(en), double, 2>(ta, da, en, st);                                   \
+    else if (E == 8) launch_step_t<decltype(en), double, 8>(ta, da, en, st);                              \
+    else launch_step_t<decltype(en), double, 16>(ta, da, en, st);                                         \
+  }                                                                                                       \
+  void NAME##_step_f32(const TrajArgs<float>* ta, const JumpDecideArgs<float>* da, const EnergyParams& ep, int E, hipStream_t st) { \
+    const auto en = MAKE32(ep);                                                                           \
+    if (E == 4) launch_step_t<decltype(en), float, 4>(ta, da, en, st);                                    \
+    else if (E == 16) launch_step_t<decltype(en), float, 16>(ta, da, en, st);                             \
+    else launch_step_t<decltype(en), float, 32>(ta, da, en, st);                                          \
+  }                                                                                                       \
   void NAME##_eval_f64(const EvalArgs<double>& a, const EnergyParams& ep, int E, hipStream_t st) {        \
     const auto en = MAKE64(ep);                                                                           \
     if (E == 2) launch_eval_t<decltype(en), double, 2>(a, en, st);                                        \
@@ -1989,6 +2307,8 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
   void NAME##_leap_f32(const LeapArgs<float>&, const EnergyParams&, int, hipStream_t);            \
   void NAME##_flf_f64(const FlfArgs<double>&, const EnergyParams&, int, int64_t, hipStream_t);    \
   void NAME##_flf_f32(const FlfArgs<float>&, const EnergyParams&, int, int64_t, hipStream_t);     \
+  void NAME##_step_f64(const TrajArgs<double>*, const JumpDecideArgs<double>*, const EnergyParams&, int, hipStream_t); \
+  void NAME##_step_f32(const TrajArgs<float>*, const JumpDecideArgs<float>*, const EnergyParams&, int, hipStream_t);  \
   void NAME##_eval_f64(const EvalArgs<double>&, const EnergyParams&, int, hipStream_t);           \
   void NAME##_eval_f32(const EvalArgs<float>&, const EnergyParams&, int, hipStream_t);
 

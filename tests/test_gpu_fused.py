@@ -167,12 +167,16 @@ def test_float32_state(kind, D, N):
 
 @pytest.mark.parametrize('kind,D,N', [('E_FUNNEL_NEAL', 32, 20000), ('E_ISO_GAUSS', 6, 70001), ('E_ROUGH_WELL', 40, 16400)])
 def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
-    """Big batches with several particles per wave run the inverse-L trajectory of the cold-cache particles in a
-    separate compacted pass (cold_list_kernel + mjhmc_flf_kernel); it must be invisible: state, scalars, transitions
-    and the per-iteration counters (the cold tallies now come from the list lengths) equal the in-kernel form."""
+    """Big batches with several particles per wave run an iteration as two launches -- every trajectory (the inverse-L
+    proposals of the cold caches in workgroups of their own), then the jump process with a lane per particle, whose movers
+    are the next iteration's list (elementwise.hpp: mjhmc_step_kernel); it must be invisible: state, scalars, transitions
+    and the per-iteration counters (the cold tallies come from the list lengths) equal the jump kernel's, which does
+    all of it per slot.  (Both samplers from the test build with fused launches switched off: below 160 000 particles
+    the product would fuse the multi-iteration calls.)"""
     from mjhmc_amd import _lib
     params = {'E_FUNNEL_NEAL': [3.0], 'E_ROUGH_WELL': [100.0, 4.0]}.get(kind, [1.0])
-    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, libs='ph')
+    monkeypatch.setenv('MJHMC_NO_FUSE', '1')
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, libs='hh')
     for s in (a, b):
         s.set_hparams(0.05, 7, 0.1, 1.0, 0.5)
     stats_a, stats_b = [], []

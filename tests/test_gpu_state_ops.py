@@ -286,8 +286,8 @@ def _sampler_for(what, seed=11):
                 self.Xinit = X0
         d = Fixed(ndims=D, nbatch=N, sigma=1.2)
         kw = dict(epsilon=0.2, num_leapfrog_steps=5)
-    elif what == 'funnel_compacted':        # several particles per wave, big batch: jump kernel + compacted passes
-        D, N = 10, 20000
+    elif what == 'funnel_compacted':        # several particles per wave, big batch: trajectory + jump-process launches
+        D, N = 10, 170000
         X0 = rs.randn(D, N)
 
         class Fixed(Dm.Funnel):
@@ -325,6 +325,11 @@ def test_streamed_sample_equals_the_recorded_ring(what, cls_name, monkeypatch):
         outs.append((s.sample(n), s.state.X, s.l_count, s.f_count, s.r_count, d.E_count, d.dEdX_count))
         monkeypatch.undo()
     for o in outs[1:]:
+        if not bits_equal(outs[0][0], o[0]):
+            bad = np.argwhere(outs[0][0] != o[0])
+            Nn = outs[0][1].shape[1]
+            raise AssertionError(('samples differ', len(bad), 'first', bad[:6].tolist(), 'time slots', sorted(set((bad[:, 1] // Nn).tolist())),
+                                  'particles', sorted(set((bad[:, 1] % Nn).tolist()))[:12], 'a', outs[0][0][tuple(bad[0])], 'b', o[0][tuple(bad[0])]))
         assert bits_equal(outs[0][0], o[0]) and bits_equal(outs[0][1], o[1]) and outs[0][2:] == o[2:]
     assert outs[0][0].shape[1] == n * outs[0][1].shape[1]
     assert bits_equal(outs[0][0][:, -outs[0][1].shape[1]:], outs[0][1])        # the last sample is the live state
