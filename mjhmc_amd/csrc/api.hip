@@ -282,11 +282,6 @@ struct ColdCache {  // H_flf is NaN; the scan also writes the copy of H_flf that
     return v != v;
   }
 };
-struct MovedBy {  // trans[p] == k
-  const uint8_t* trans;
-  uint8_t k;
-  __device__ bool operator()(int64_t p) const { return trans[p] == k; }
-};
 template <class Pred>
 __global__ __launch_bounds__(1024) void compact_list_kernel(const Pred pred, int64_t N, const Control* ctl,
                                                             int* __restrict__ list, int* __restrict__ count) {
@@ -371,35 +366,6 @@ int dispatch_leap<float>(int kind, const LeapArgs<float>& a, const EnergyParams&
     case MJHMC_E_FUNNEL_NEAL: funnel_neal_leap_f32(a, ep, E, st); break;
     case MJHMC_E_FUNNEL_REF: funnel_ref_leap_f32(a, ep, E, st); break;
     default: return fail(MJHMC_ERR_UNSUPPORTED, "the stand-alone leapfrog operator exists for the elementwise energies");
-  }
-  return 0;
-}
-
-template <typename T>
-static int dispatch_flf(int kind, const FlfArgs<T>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st);
-template <>
-int dispatch_flf<double>(int kind, const FlfArgs<double>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) {
-  switch (kind) {
-    case MJHMC_E_ISO_GAUSS: iso_flf_f64(a, ep, E, n, st); break;
-    case MJHMC_E_DIAG_GAUSS: diag_flf_f64(a, ep, E, n, st); break;
-    case MJHMC_E_ROUGH_WELL: rough_flf_f64(a, ep, E, n, st); break;
-    case MJHMC_E_MM_GAUSS: mm_flf_f64(a, ep, E, n, st); break;
-    case MJHMC_E_FUNNEL_NEAL: funnel_neal_flf_f64(a, ep, E, n, st); break;
-    case MJHMC_E_FUNNEL_REF: funnel_ref_flf_f64(a, ep, E, n, st); break;
-    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no inverse-L kernel");
-  }
-  return 0;
-}
-template <>
-int dispatch_flf<float>(int kind, const FlfArgs<float>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) {
-  switch (kind) {
-    case MJHMC_E_ISO_GAUSS: iso_flf_f32(a, ep, E, n, st); break;
-    case MJHMC_E_DIAG_GAUSS: diag_flf_f32(a, ep, E, n, st); break;
-    case MJHMC_E_ROUGH_WELL: rough_flf_f32(a, ep, E, n, st); break;
-    case MJHMC_E_MM_GAUSS: mm_flf_f32(a, ep, E, n, st); break;
-    case MJHMC_E_FUNNEL_NEAL: funnel_neal_flf_f32(a, ep, E, n, st); break;
-    case MJHMC_E_FUNNEL_REF: funnel_ref_flf_f32(a, ep, E, n, st); break;
-    default: return fail(MJHMC_ERR_UNSUPPORTED, "energy kind has no inverse-L kernel");
   }
   return 0;
 }

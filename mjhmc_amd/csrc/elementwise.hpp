@@ -537,7 +537,7 @@ struct JumpArgs {
   // registers / LDS between them (iteration it uses RNG tick key.tick + it and stats[4 * it ...]).
   // xiter != nullptr: X after iteration it is also recorded at xiter + it * xiter_stride (ring slots) and
   // its dwelling times at dwell_ring + it * Npad; X_out is then not written (the last slot is the live state).
-  int defer_r;          // != 0: R-movers keep their old momentum here; mjhmc_refresh_kernel draws the new one
+  int defer_r;          // != 0: R-movers keep their old momentum here (always 0 since round 5: their refresh is the jump-process kernel's)
   int n_fuse;
   int ab;               // host-side launch A/B flags (kAb*): always 0 in the shipped library, set by the test build's switches
   T* xiter;
@@ -563,29 +563,6 @@ struct EvalArgs {
   RngKey key;
 };
 
-// inverse-L pass over a compacted list of cold-cache particles (see mjhmc_flf_kernel)
-template <typename T>
-struct FlfArgs {
-  const T* X;         // [N][pitch] pre-move state
-  T* V;               // read; rows of particles with a pending momentum refresh are rewritten first (pending_r)
-  T* H_out;           // [N]: H() of the inverse-L proposal, written for the listed particles only
-  const int* list;    // particle indices with a cold cache
-  const int* count;   // how many
-  const Control* ctl;
-  int D, pitch, CH, logG;
-  int L;
-  T eps, chalf;
-  // != 0: the PREVIOUS iteration of this mjhmc_iterate call left its R-movers (trans == 2) with their old momentum
-  // (JumpArgs::defer_r).  They are all on this list -- an R move clears the cache -- so their HMCState.R is applied
-  // here, with the previous iteration's RNG tick, before the inverse-L trajectory starts from the refreshed momentum.
-  int pending_r;
-  const uint8_t* trans;
-  T* EV;              // [N] kinetic energy of the pre-move state: rewritten for the refreshed particles
-  int64_t first_pid;
-  T r_keep, r_mix;
-  RngKey key_prev;
-};
-
 // stand-alone leapfrog operator (see mjhmc_leap_kernel)
 template <typename T>
 struct LeapArgs {
@@ -600,21 +577,6 @@ struct LeapArgs {
   int D, pitch, CH, logG;
   int L;
   T eps, chalf;
-};
-
-// momentum refresh of the compacted R-movers (see mjhmc_refresh_kernel)
-template <typename T>
-struct RefreshArgs {
-  const T* V_in;      // [N][pitch] pre-move momentum
-  T* V_out;           // rows of the listed particles are overwritten with the refreshed momentum
-  T* EV_out;          // and their kinetic energy
-  const int* list;
-  const int* count;
-  const Control* ctl;
-  int64_t first_pid;
-  int D, pitch, CH, logG;
-  T r_keep, r_mix;
-  RngKey key;         // the attempt's tick: the same normals the jump kernel would have drawn
 };
 
 // Round 5: a MarkovJumpHMC iteration of a big batch with several particles per wavefront as TWO launches --
@@ -1483,7 +1445,7 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
         EVn = EV0;
       } else {  // R: refresh the momentum (hmc_state.py:121-129)
         stash_get<T, E>(stash_x, lane, x);
-        if (!REPLAY && a.defer_r) {  // done by mjhmc_refresh_kernel on the compacted R-movers (see there)
+        if (!REPLAY && a.defer_r) {  // (no caller sets it any more: rounds 1-4 left the refresh to a compacted pass)
           stash_get<T, E>(stash_v, lane, v);
           EVn = EV0;
         } else {
@@ -1668,106 +1630,6 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
     const unsigned long long t =
         (unsigned long long)tally[0][threadIdx.x] + tally[1][threadIdx.x] + tally[2][threadIdx.x] + tally[3][threadIdx.x];
     if (t) atomicAdd(&a.stats[threadIdx.x], t);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Inverse-L proposal (F L F, hmc_state.py:109-119) of the cold-cache particles only, compacted.
-// With several particles per wavefront the jump kernel pays for the second trajectory in every wave that holds
-// at least ONE cold particle (C4, 16 particles per wave, 7 % cold: 69 % of the waves).  This kernel runs the same
-// trajectory code on the cold particles packed densely -- the list comes from cold_list_kernel -- and writes
-// H_flf into the vector the jump kernel then reads as "cache warm".  Same code, same inputs: same bits.
-// ------------------------------------------------------------------------------------------
-template <class En, typename T, int E>
-__global__ __launch_bounds__(256) void mjhmc_flf_kernel(const FlfArgs<T> a, const En en) {
-  if (a.ctl->failed) return;
-  const int n_cold = *a.count;
-  const int G = 1 << a.logG;
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const int ppb = 256 >> a.logG;  // particles per pass of a block
-  using Vec = typename VecOf<T>::type;
-  constexpr int C = E / VecOf<T>::n;
-  __shared__ Vec stash[4][C][64];
-  LaneMap m;
-  m.j = (int)(threadIdx.x & (G - 1));
-  m.G = G;
-  m.D = a.D;
-  m.CH = a.CH;
-  m.lane0 = lane & ~(G - 1);
-  m.wpp = 0;
-  const auto lc = en.template local<E>(m);
-  // the grid is sized for a typical list, not for the worst case: blocks walk the list
-  for (int64_t first = (int64_t)blockIdx.x * ppb; first < n_cold; first += (int64_t)gridDim.x * ppb) {
-    const int64_t idx = first + (threadIdx.x >> a.logG);
-    const bool live = idx < n_cold;
-    const int64_t p = a.list[live ? idx : 0];
-    T x[E], v[E];
-    load_row<T, E>(a.X + (size_t)p * a.pitch, m, x);
-    load_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
-    if (a.pending_r) {
-      const bool r = live && a.trans[p] == 2;
-      if (__ballot(r) != 0ull) {  // HMCState.R of the previous iteration (hmc_state.py:121-129)
-        stash_put<T, E>(stash[wib], lane, v);
-        refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key_prev, (uint32_t)(a.first_pid + p), m, a.r_keep,
-                                   a.r_mix);
-        T vr[E];
-        stash_get<T, E>(stash[wib], lane, vr);
-        const T evr = kinetic<T, E>(vr, m);
-        if (r) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) v[e] = vr[e];
-          store_row<T, E>(a.V + (size_t)p * a.pitch, m, v);
-          if (m.j == 0) a.EV[p] = evr;
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = -v[e];
-    trajectory<En, T, E, false>(en, lc, m, x, v, a.L, a.eps, a.chalf);
-    const T ev = kinetic<T, E>(v, m);
-    const T ex = en.energy(x, m, lc);
-    if (live && m.j == 0) a.H_out[p] = ex + ev;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// HMCState.R (hmc_state.py:121-129) for the particles that chose R, compacted.  With 16 particles per wavefront and
-// ~5 % R-movers more than half of the jump kernel's waves would run the Philox + Box-Muller block for one lane
-// group's sake (~1000 vector instructions for 8 elements per lane).  The jump kernel leaves those particles' old
-// momentum in place, trans == 2 marks them, and this kernel draws the same normals (same key, tick, particle id)
-// for the listed particles packed densely.  Same code on the same inputs: same bits.
-// ------------------------------------------------------------------------------------------
-template <typename T, int E>
-__global__ __launch_bounds__(256) void mjhmc_refresh_kernel(const RefreshArgs<T> a) {
-  if (a.ctl->failed) return;
-  const int n = *a.count;
-  const int G = 1 << a.logG;
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const int ppb = 256 >> a.logG;
-  LaneMap m;
-  m.j = (int)(threadIdx.x & (G - 1));
-  m.G = G;
-  m.D = a.D;
-  m.CH = a.CH;
-  m.lane0 = lane & ~(G - 1);
-  m.wpp = 0;
-  using Vec = typename VecOf<T>::type;
-  constexpr int C = E / VecOf<T>::n;
-  __shared__ Vec stash[4][C][64];
-  for (int64_t first = (int64_t)blockIdx.x * ppb; first < n; first += (int64_t)gridDim.x * ppb) {
-    const int64_t idx = first + (threadIdx.x >> a.logG);
-    const bool live = idx < n;
-    const int64_t p = a.list[live ? idx : 0];
-    T v[E];
-    load_row<T, E>(a.V_in + (size_t)p * a.pitch, m, v);
-    stash_put<T, E>(stash[wib], lane, v);
-    refresh_stash<T, E, false>(stash[wib], lane, nullptr, a.key, (uint32_t)(a.first_pid + p), m, a.r_keep, a.r_mix);
-    stash_get<T, E>(stash[wib], lane, v);
-    const T ev = kinetic<T, E>(v, m);
-    if (live) {
-      store_row<T, E>(a.V_out + (size_t)p * a.pitch, m, v);
-      if (m.j == 0) a.EV_out[p] = ev;
-    }
   }
 }
 
@@ -2011,20 +1873,6 @@ __global__ __launch_bounds__(256) void mjhmc_step_kernel(const TrajArgs<T> ta, c
   else decide_block<T, E>(da, sh, vb);
 }
 
-#ifndef __HIPCC_RTC__
-constexpr int64_t kListGrid = 256 * 16;  // workgroups of the compacted-list passes (256 CUs x 8 resident + a second round)
-template <typename T>
-inline void launch_refresh(const RefreshArgs<T>& a, int E, int64_t n_max, hipStream_t st) {
-  const int64_t threads = n_max << a.logG;
-  const dim3 grid((unsigned)std::min<int64_t>((threads + 255) / 256, kListGrid)), block(256);  // blocks walk the list
-  constexpr int VEC = VecOf<T>::n;
-  if (E == VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, VEC>), grid, block, 0, st, a);
-  else if (E == 4 * VEC) hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 4 * VEC>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((mjhmc_refresh_kernel<T, 8 * VEC>), grid, block, 0, st, a);
-}
-
-#endif  // !__HIPCC_RTC__
-
 // ------------------------------------------------------------------------------------------
 // HMCState.leapfrog / HMCState.L as an operator on caller-supplied states (hmc_state.py:86-100): the reference's
 // literal operation order (the EXACT trajectory), then EV, EX and dE/dX of the end point.
@@ -2208,13 +2056,6 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   }
 }
 
-template <class En, typename T, int E>
-inline void launch_flf_t(const FlfArgs<T>& a, const En& en, int64_t n_max, hipStream_t st) {
-  const int64_t threads = n_max << a.logG;  // worst case; typical lists are a few per cent of it: blocks walk the list
-  hipLaunchKernelGGL((mjhmc_flf_kernel<En, T, E>), dim3((unsigned)std::min<int64_t>((threads + 255) / 256, kListGrid)),
-                     dim3(256), 0, st, a, en);
-}
-
 // trajectories: one workgroup per 256 >> logG particles + the list's walkers in front; jump process: one per 256 particles
 template <class En, typename T, int E>
 inline void launch_step_t(const TrajArgs<T>* ta, const JumpDecideArgs<T>* da, const En& en, hipStream_t st) {
@@ -2263,18 +2104,6 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
     else if (E == 16) launch_leap_t<decltype(en), float, 16>(a, en, st);                                  \
     else launch_leap_t<decltype(en), float, 32>(a, en, st);                                               \
   }                                                                                                       \
-  void NAME##_flf_f64(const FlfArgs<double>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) { \
-    const auto en = MAKE64(ep);                                                                           \
-    if (E == 2) launch_flf_t<decltype(en), double, 2>(a, en, n, st);                                      \
-    else if (E == 8) launch_flf_t<decltype(en), double, 8>(a, en, n, st);                                 \
-    else launch_flf_t<decltype(en), double, 16>(a, en, n, st);                                            \
-  }                                                                                                       \
-  void NAME##_flf_f32(const FlfArgs<float>& a, const EnergyParams& ep, int E, int64_t n, hipStream_t st) { \
-    const auto en = MAKE32(ep);                                                                           \
-    if (E == 4) launch_flf_t<decltype(en), float, 4>(a, en, n, st);                                       \
-    else if (E == 16) launch_flf_t<decltype(en), float, 16>(a, en, n, st);                                \
-    else launch_flf_t<decltype(en), float, 32>(a, en, n, st);                                             \
-  }                                                                                                       \
   void NAME##_step_f64(const TrajArgs<double>* ta, const JumpDecideArgs<double>* da, const EnergyParams& ep, int E, hipStream_t st) { \
     const auto en = MAKE64(ep);                                                                           \
     if (E == 2) launch_step_t<decltype(en), double, 2>(ta, da, en, st);                                   \
@@ -2305,8 +2134,6 @@ inline void launch_eval_t(const EvalArgs<T>& a, const En& en, hipStream_t st) {
   void NAME##_jump_f32(const JumpArgs<float>&, const EnergyParams&, int, hipStream_t);            \
   void NAME##_leap_f64(const LeapArgs<double>&, const EnergyParams&, int, hipStream_t);           \
   void NAME##_leap_f32(const LeapArgs<float>&, const EnergyParams&, int, hipStream_t);            \
-  void NAME##_flf_f64(const FlfArgs<double>&, const EnergyParams&, int, int64_t, hipStream_t);    \
-  void NAME##_flf_f32(const FlfArgs<float>&, const EnergyParams&, int, int64_t, hipStream_t);     \
   void NAME##_step_f64(const TrajArgs<double>*, const JumpDecideArgs<double>*, const EnergyParams&, int, hipStream_t); \
   void NAME##_step_f32(const TrajArgs<float>*, const JumpDecideArgs<float>*, const EnergyParams&, int, hipStream_t);  \
   void NAME##_eval_f64(const EvalArgs<double>&, const EnergyParams&, int, hipStream_t);           \

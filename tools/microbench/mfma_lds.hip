@@ -3,8 +3,14 @@
 // Each test: one workgroup per CU, N iterations of a loop body, cycles (s_memtime) per iteration on wave 0 and the
 // wall-clock time of the launch (hipEvents), which calibrates the cycle counter.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <string>
+#include <thread>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -138,7 +144,121 @@ void run(const char* what, int threads, int ncu, unsigned long long* d_out, floa
          threads / 256, (double)cyc / kIter, per, ms, cyc / (ms * 1e6), ms * 1e6 / kIter);
 }
 
-int main() {
+// ---- `mfma_lds energy`: where the watts of a SparseImageCode round go --------------------------------
+// Every component of a round's instruction mix alone and stacked, on the WHOLE chip (one 512-thread workgroup per CU) for
+// ~3 s each, with the socket power and the shader clock sampled from sysfs every 20 ms while it runs:
+// joules per MFMA issued = socket watts x seconds / (CUs x 8 waves x iterations).
+static std::string find_hwmon() {   // the hwmon directory of THE device this process computes on (by PCI address)
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), 0) != hipSuccess) return "";
+  for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+  const std::string base = std::string("/sys/bus/pci/devices/") + bus + "/hwmon";
+  DIR* d = opendir(base.c_str());
+  if (!d) return "";
+  std::string found;
+  while (dirent* e = readdir(d)) {
+    if (std::strncmp(e->d_name, "hwmon", 5)) continue;
+    const std::string h = base + "/" + e->d_name;
+    FILE* f = fopen((h + "/freq1_input").c_str(), "r");
+    if (f) {
+      fclose(f);
+      found = h;
+      break;
+    }
+  }
+  closedir(d);
+  return found;
+}
+static double read_num(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  double v = -1;
+  if (fscanf(f, "%lf", &v) != 1) v = -1;
+  fclose(f);
+  return v;
+}
+
+template <int MODE>
+void energy_row(const char* what, int mfma_per_iter, int ncu, unsigned long long* d_out, float* d_sink, const char* d_src,
+                const std::string& hw) {
+  CHECK(hipFuncSetAttribute((const void*)bench<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  std::atomic<bool> stop{false};
+  std::vector<double> watts, mhz;
+  std::thread sampler([&] {
+    while (!stop.load()) {
+      double w = read_num(hw + "/power1_input");
+      if (w < 0) w = read_num(hw + "/power1_average");
+      const double f = read_num(hw + "/freq1_input");
+      if (w > 0) watts.push_back(w / 1e6);
+      if (f > 0) mhz.push_back(f / 1e6);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+  });
+  for (int i = 0; i < 50; ++i) bench<MODE><<<ncu, 512, 128 * 1024>>>(d_out, d_sink, d_src);   // clocks and power settle
+  CHECK(hipDeviceSynchronize());
+  watts.clear();
+  mhz.clear();
+  const auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 3.0) {
+    for (int i = 0; i < 20; ++i) bench<MODE><<<ncu, 512, 128 * 1024>>>(d_out, d_sink, d_src);
+    CHECK(hipDeviceSynchronize());
+    launches += 20;
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  stop.store(true);
+  sampler.join();
+  double w = 0, f = 0;
+  for (double x : watts) w += x;
+  for (double x : mhz) f += x;
+  w /= watts.empty() ? 1 : watts.size();
+  f /= mhz.empty() ? 1 : mhz.size();
+  const double iters = (double)launches * kIter;             // per wave
+  const double ns_iter = secs * 1e9 / iters;
+  const double nj_iter_wave = w * secs * 1e9 / (iters * ncu * 8.0);   // socket nanojoules per iteration of ONE wave
+  printf("%-62s %7.1f ns/iteration  %6.0f W  %5.0f MHz  %6.2f nJ per iteration and wave", what, ns_iter, w, f, nj_iter_wave);
+  if (mfma_per_iter) printf("  (%.2f nJ per MFMA)", nj_iter_wave / mfma_per_iter);
+  printf("\n");
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !std::strcmp(argv[1], "energy")) {
+    hipDeviceProp_t p;
+    CHECK(hipGetDeviceProperties(&p, 0));
+    const int ncu = p.multiProcessorCount;
+    const std::string hw = find_hwmon();
+    printf("%s, %d CUs; one 512-thread workgroup per CU, ~3 s per row; power / clock: %s\n", p.name, ncu, hw.c_str());
+    unsigned long long* d_out;
+    float* d_sink;
+    char* d_src;
+    CHECK(hipMalloc(&d_out, 64));
+    CHECK(hipMalloc(&d_sink, sizeof(float) * 512 * ncu));
+    CHECK(hipMalloc(&d_src, 1 << 20));
+    CHECK(hipMemset(d_src, 0, 1 << 20));
+    {   // the socket with nothing running, 2 s
+      std::this_thread::sleep_for(std::chrono::milliseconds(500));
+      double w = 0;
+      int n = 0;
+      for (int i = 0; i < 75; ++i) {
+        double x = read_num(hw + "/power1_input");
+        if (x < 0) x = read_num(hw + "/power1_average");
+        if (x > 0) { w += x / 1e6; ++n; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      }
+      printf("%-62s %25s %6.0f W\n", "idle (no kernel)", "", n ? w / n : 0.0);
+    }
+    energy_row<0>("MFMA chain, operands in registers", 1, ncu, d_out, d_sink, d_src, hw);
+    energy_row<1>("two independent MFMA chains per wave, operands in registers", 2, ncu, d_out, d_sink, d_src, hw);
+    energy_row<11>("MFMA + ONE operand from LDS (ds_read_b128)", 1, ncu, d_out, d_sink, d_src, hw);
+    energy_row<2>("MFMA + BOTH operands from LDS, row reads (the kick product)", 1, ncu, d_out, d_sink, d_src, hw);
+    energy_row<3>("MFMA + BOTH operands from LDS, transposed reads (the residual product)", 1, ncu, d_out, d_sink, d_src, hw);
+    energy_row<7>("  ... + one 1 KB LDS-DMA request per two MFMAs (the dictionary landing)", 1, ncu, d_out, d_sink, d_src, hw);
+    energy_row<4>("  ... + the prior's vector work (5 VALU with a v_rcp per MFMA)", 1, ncu, d_out, d_sink, d_src, hw);
+    energy_row<6>("the kick product's LDS reads alone (no MFMA)", 0, ncu, d_out, d_sink, d_src, hw);
+    energy_row<5>("the residual product's LDS reads alone (no MFMA)", 0, ncu, d_out, d_sink, d_src, hw);
+    energy_row<9>("the LDS-DMA landing alone (1 KB per iteration and wave, out of L2)", 0, ncu, d_out, d_sink, d_src, hw);
+    return 0;
+  }
   hipDeviceProp_t p;
   CHECK(hipGetDeviceProperties(&p, 0));
   const int ncu = p.multiProcessorCount;

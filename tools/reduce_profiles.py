@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAIN = {'c2': 'mjhmc_jump_kernel', 'c2nofuse': 'mjhmc_jump_kernel', 'c3': 'pot_jump_kernel', 'c3f64': 'pot64_jump_kernel',
-        'c4': 'mjhmc_jump_kernel', 'c5': 'sic_jump_kernel'}
+        'c4': 'mjhmc_step_kernel', 'c5': 'sic_jump_kernel', 'c5f32': 'sic_jump_kernel'}
 OURS = ('mjhmc', 'pot_', 'pot64_', 'sic_', 'compact_list', 'cold_list')
 
 
@@ -54,7 +54,7 @@ def main():
     traffic_path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
     notes = []
-    for w in ('c2', 'c2nofuse', 'c3', 'c3f64', 'c4', 'c5'):
+    for w in ('c2', 'c2nofuse', 'c3', 'c3f64', 'c4', 'c5', 'c5f32'):
         ks = find(os.path.join(src, 'kt_' + w), 'kernel_stats.csv')
         if ks:
             shutil.copy(ks, os.path.join(dst, w + '_kernel_stats.csv'))
@@ -83,7 +83,8 @@ def main():
                 single = [v for k, vals in cs.items() if MAIN[w] in k and not k.rstrip().endswith(fused_tag) for v in vals]
                 per[c] = sum(single) / max(len(single), 1)
             else:
-                n_units = len(main) / float(launches_per_iteration(p, MAIN[w]))
+                # (C4 since round 5: an iteration is two dispatches of mjhmc_step_kernel -- trajectories, jump process -- on one queue)
+                n_units = len(main) / float(launches_per_iteration(p, MAIN[w]) * (2 if w == 'c4' else 1))
                 per[c] = sum(ours) / n_units            # every kernel of an iteration, per iteration
             # keep a trimmed copy of the pass: our kernels only
             with open(p) as f, open(os.path.join(dst, '%s_pmc_%s.csv' % (w, c.lower())), 'w') as g:
@@ -114,7 +115,7 @@ def main():
                 for cname, per_k in counters(p).items():
                     vals = [v for k, vs in per_k.items() if MAIN[w] in k and (w != 'c2' or 'true>(' in k) for v in vs]
                     if vals:
-                        parts = launches_per_iteration(p, 'true>(' if w == 'c2' else MAIN[w])
+                        parts = launches_per_iteration(p, 'true>(' if w == 'c2' else MAIN[w]) * (2 if w == 'c4' else 1)
                         sq[cname] = (sum(vals) / (len(vals) / float(parts)), int(len(vals) / parts))
         if sq:
             with open(os.path.join(dst, '%s_pmc_sq.txt' % w), 'w') as g:
