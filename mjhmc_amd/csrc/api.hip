@@ -35,7 +35,7 @@ static int pow2ceil(int v) {
 }
 
 // The A/B switches of the measurement tools and of the launch-strategy tests (MJHMC_NO_FUSE, MJHMC_NO_COMPACT,
-// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_FUSE_BELOW, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
+// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_NO_ROWS, MJHMC_FUSE_BELOW, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
 // MJHMC_SIC_COPIES) and the failure-placing hook MJHMC_DEBUG_POISON exist only in libmjhmc_hip_test.so (built with
 // -DMJHMC_TEST_HOOKS, `make test_hooks`).  The shipped library consults no environment variable on the sampling path:
 // the only ones it reads at all name libraries to dlopen (MJHMC_RCCL_LIB; hipRTC / hipFFT by their sonames).
@@ -1975,6 +1975,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         ta.L = a.L;
         const int64_t ppb = 256 >> a.logG;   // the list's walkers: sized for a typical list (a few per cent of the batch)
         ta.inv_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.N + ppb - 1) / ppb / 8, 2048));
+        ta.rows = test_env("MJHMC_NO_ROWS") ? 0 : 1;
         ta.eps = a.eps;
         ta.chalf = a.chalf;
         da.X_in = a.X_in;

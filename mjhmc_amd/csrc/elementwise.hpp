@@ -397,6 +397,33 @@ struct MMGaussF {
   }
 };
 
+// group_sum()'s pairing on the G per-lane partial sums of a particle held by ONE lane (the row form): the same bits
+template <typename T, int G>
+__device__ __forceinline__ T rows_sum(const T (&p)[G]) {
+  static_assert(G == 1 || G == 2 || G == 4, "groups inside a quad");
+  if constexpr (G == 1) return p[0];
+  else if constexpr (G == 2) return p[0] + p[1];
+  else return (p[0] + p[1]) + (p[2] + p[3]);
+}
+// prep() of the two funnels on a whole row: lane j's partial sum exactly as prep() forms it, the partials paired as
+// group_sum pairs them, exp(-x0) once per particle (prep() spends the instructions in all G lanes of the group)
+template <class Ctx, typename T, int E, int G>
+__device__ __forceinline__ Ctx funnel_prep_rows(const T (&x)[G][E]) {
+  T part[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    T s = (j == 0) ? T(0) : x[j][0] * x[j][0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) s = __builtin_fma(x[j][e], x[j][e], s);
+    part[j] = s;
+  }
+  Ctx c;
+  c.S = rows_sum<T, G>(part);
+  c.x0 = x[0][0];
+  c.ex = exp_neg(x[0][0]);
+  return c;
+}
+
 // Neal's funnel, x0 ~ N(0, s^2), x_k ~ N(0, e^{x0}) (tf_distributions.py:143-147):
 // E = x0^2/(2 s^2) + e^{-x0} sum_k x_k^2 / 2 + (D-1) x0 / 2
 template <typename T>
@@ -443,10 +470,18 @@ struct FunnelNealF {
     return (e == 0 && d == 0) ? __builtin_fma(ck, c.x0 * inv_s2 - T(0.5) * c.ex * c.S + half_dm1, ve)
                               : __builtin_fma(xe, ck * c.ex, ve);
   }
+  __device__ __forceinline__ T energy_of(const Ctx& c) const {
+    return c.x0 * c.x0 * (T(0.5) * inv_s2) + T(0.5) * c.ex * c.S + half_dm1 * c.x0;
+  }
   template <int E>
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
-    const Ctx c = prep(x, m);
-    return c.x0 * c.x0 * (T(0.5) * inv_s2) + T(0.5) * c.ex * c.S + half_dm1 * c.x0;
+    return energy_of(prep(x, m));
+  }
+  // the row form (mjhmc_traj_rows_kernel): the whole particle in one lane, x[j] = what lane j of its group would hold
+  static constexpr bool kRowForm = true;
+  template <int E, int G>
+  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E]) const {
+    return funnel_prep_rows<Ctx, T, E, G>(x);
   }
 };
 
@@ -493,10 +528,15 @@ struct FunnelRefF {
     return (e == 0 && d == 0) ? __builtin_fma(ck, T(-2) * dm1 * c.x0 * inv_s2 + c.ex * c.S, ve)
                               : __builtin_fma(xe, ck * (T(-2) * c.ex), ve);
   }
+  __device__ __forceinline__ T energy_of(const Ctx& c) const { return -(dm1 * c.x0 * c.x0 * inv_s2) - c.ex * c.S; }
   template <int E>
   __device__ __forceinline__ T energy(const T (&x)[E], const LaneMap& m, const Local<E>&) const {
-    const Ctx c = prep(x, m);
-    return -(dm1 * c.x0 * c.x0 * inv_s2) - c.ex * c.S;
+    return energy_of(prep(x, m));
+  }
+  static constexpr bool kRowForm = true;   // as FunnelNealF
+  template <int E, int G>
+  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E]) const {
+    return funnel_prep_rows<Ctx, T, E, G>(x);
   }
 };
 
@@ -598,6 +638,7 @@ struct TrajArgs {
   int D, pitch, CH, logG;
   int L;
   int inv_blocks;     // leading workgroups of the grid that walk the list (the rest: one forward slot each)
+  int rows;           // energies with a row form: a lane per particle (mjhmc_traj_rows_kernel); 0 = the group form (A/B)
   T eps, chalf;
 };
 
@@ -1706,6 +1747,290 @@ __device__ __forceinline__ void traj_block(const TrajArgs<T>& a, const En& en, i
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The trajectory launch in ROW FORM: a lane per particle (energies with kRowForm; float64 rows of up to 16 chunks held by
+// groups of 2 or 4 lanes elsewhere -- ndims 9 ... 32, C4).
+//
+// A group of G lanes per particle repeats the per-PARTICLE work of a force G times: the funnel's exp(-x0) (~25 float64
+// instructions), the group reduction and broadcasts, the index and loop arithmetic.  With the whole row in one lane they
+// are paid once per particle and the element updates stay what they were: C4's leapfrog step goes from ~110 vector
+// instructions per 16 particles to ~125 per 64, and the launch becomes what its bytes say it is -- HBM-bound.
+//
+// HBM keeps the particle-major rows every other kernel reads (the jump-process launch, uploads, downloads): a wavefront
+// (= a workgroup) moves its 64 rows between HBM and registers through a 16 KB LDS tile.  HBM side: chunk q of the tile's
+// 64 * CH 16-byte chunks belongs to lane q % 64 -- consecutive lanes, consecutive addresses.  LDS side: row r, chunk c
+// sits at slot r * 16 + (c ^ (r & 15)), so that both the row-order side (16 lanes = one row) and the lane-owns-a-row side
+// (16 lanes = 16 rows, the same chunk) spread over all banks.  The listed cold caches' rows are gathered the same way,
+// 16 lanes per row.
+//
+// The same arithmetic as the group form, operation for operation: lane j's partial sums in its element order, the partials
+// paired as group_sum pairs them (rows_sum), exp_neg on the same argument, the same multiply-adds on the elements -- the
+// same bits (tests/test_gpu_fused.py compares the launch strategies).
+// ------------------------------------------------------------------------------------------
+template <class En, typename = void>
+struct HasRowForm {
+  static constexpr bool value = false;
+};
+template <class En>
+struct HasRowForm<En, decltype((void)En::kRowForm)> {
+  static constexpr bool value = true;
+};
+
+template <int G>
+__device__ __forceinline__ constexpr int row_dim(int j, int e) {   // dim_of for float64 (two elements per chunk)
+  return ((e / 2) * G + j) * 2 + (e % 2);
+}
+
+template <class En, typename T, int E, int G>
+__device__ __forceinline__ void trajectory_rows(const En& en, T (&x)[G][E], T (&v)[G][E], int L, T eps, T chalf) {
+  if (L <= 0) return;   // trajectory<.., EXACT = false>, a row at a time
+  {
+    const auto ctx = en.template prep_rows<E, G>(x);
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[j][e] = en.template kick<E>(chalf, x[j][e], v[j][e], e, row_dim<G>(j, e), ctx);
+  }
+  const T cfull = chalf + chalf;
+  for (int s = 0; s < L; ++s) {
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[j][e] = __builtin_fma(eps, v[j][e], x[j][e]);
+    const auto ctx = en.template prep_rows<E, G>(x);
+    const T c = (s == L - 1) ? chalf : cfull;
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[j][e] = en.template kick<E>(c, x[j][e], v[j][e], e, row_dim<G>(j, e), ctx);
+  }
+}
+
+template <typename T, int E, int G>
+__device__ __forceinline__ T kinetic_rows(const T (&v)[G][E]) {
+  T part[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s = __builtin_fma(v[j][e], v[j][e], s);
+    part[j] = s;
+  }
+  return rows_sum<T, G>(part) / T(2);
+}
+
+// order the wavefront's LDS traffic: the tile is written by one set of lanes and read by another.  LDS operations of a wave
+// execute in order; what is needed is that the compiler keeps them in order and that the writes have landed -- NOT a
+// fence: a release fence also waits for the wave's global stores (vmcnt(0): the X rows' way to HBM, 2-5 us, in front of
+// the V rows' pass through the tile).
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class En, typename T, int E, int LOGG, bool FULL>
+__global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T> a, const En en, int n_walk) {
+  static_assert(sizeof(T) == 8, "float64 rows");
+  constexpr int G = 1 << LOGG, C = E / 2, RC = C * G;   // RC: chunks of a full row
+  static_assert(RC == 8 || RC == 16, "rows of 8 or 16 chunks");
+  using V = double2;
+  // the chunks on their way between HBM and the tile: ONE vector value, not an array (an array of 16 chunks indexed from
+  // unrolled loops was left in scratch memory -- 512 bytes written and read back per wave and matrix)
+  using Stage = double __attribute__((ext_vector_type(2 * RC)));
+  __shared__ V tile[64 * 16];
+  if (a.ctl->failed) return;
+  const int CH = FULL ? RC : a.CH;   // FULL: every row has all its chunks (ndims 31, 32 / 15, 16): no predicate anywhere
+  // Every phase forms its own addresses from an opaque copy of the lane index: formed once, the compiler carries 16 + 16 LDS
+  // and 2 x 16 global addresses across the trajectory loop in scratch memory -- and each reload in the store phase is a
+  // vmcnt(0) wait, i.e. it waits for the previous STORE to reach memory (16 round trips per matrix).
+  auto fresh_lane = [&]() __attribute__((always_inline)) {
+    int l = threadIdx.x;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  // The tile in row order: chunk q = i * 64 + lane is (row, col) = (q / CH, q % CH), slot row * 16 + (col ^ (row & 15)).
+  // FULL: i = P * m + k walks rows 16 m + RPI * k + lane / RC, so the slot is one of P per-lane bases + m * 256.
+  constexpr int RPI = 64 / RC, P = 16 / RPI;
+  struct Walk {   // short rows: (row, col) stepped, not divided
+    int row, col, drow, dcol, CH;
+    __device__ __forceinline__ void step() {
+      col += dcol;
+      row += drow;
+      if (col >= CH) {
+        col -= CH;
+        row += 1;
+      }
+    }
+  };
+  auto walk0 = [&](int l) __attribute__((always_inline)) {
+    Walk w;
+    w.CH = CH;
+    w.row = l / CH;
+    w.col = l - w.row * CH;
+    w.drow = 64 / CH;
+    w.dcol = 64 - w.drow * CH;
+    return w;
+  };
+
+  // HBM rows -> registers, still in row order.  All loads are issued before anything waits; the passes a short row does
+  // not need re-read the tile's last chunk and are dropped.
+  auto fetch = [&](const T* M, int64_t base, Stage& t) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    const char* tb = reinterpret_cast<const char*>(M + (size_t)base * a.pitch);
+    const uint32_t last_chunk = (uint32_t)(64 * CH - 1) * 16u;
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+      uint32_t off = (uint32_t)(i * 64 + l) * 16u;
+      if (!FULL) off = min(off, last_chunk);
+      const V q = *reinterpret_cast<const V*>(tb + off);
+      t[2 * i] = q.x;
+      t[2 * i + 1] = q.y;
+    }
+  };
+  // the listed particles' rows, RC lanes per row
+  auto fetch_listed = [&](const T* M, int p_lane, Stage& t) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    Walk w = walk0(l);
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+      const int pr = __shfl(p_lane, FULL ? w.row : min(w.row, 63));
+      const V q = *reinterpret_cast<const V*>(M + (size_t)pr * a.pitch + w.col * 2);
+      t[2 * i] = q.x;
+      t[2 * i + 1] = q.y;
+      w.step();
+    }
+  };
+  // ... through the tile into the lane that owns the row
+  auto to_rows = [&](const Stage& t, T (&r)[G][E]) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    if constexpr (FULL) {
+      const int h = l / RC, col = l % RC;
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int rk = RPI * k + h, slot = rk * 16 + (col ^ rk);
+#pragma unroll
+        for (int m = 0; m < RC / P; ++m) tile[slot + m * 256] = V{t[2 * (P * m + k)], t[2 * (P * m + k) + 1]};
+      }
+    } else {
+      Walk w = walk0(l);
+#pragma unroll
+      for (int i = 0; i < RC; ++i) {
+        if (i < CH) tile[w.row * 16 + (w.col ^ (w.row & 15))] = V{t[2 * i], t[2 * i + 1]};
+        w.step();
+      }
+    }
+    wave_lds_fence();
+    const int mine = l * 16, key = l & 15;
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      V q = tile[mine + (c ^ key)];
+      if (!FULL && c >= CH) q = V{0, 0};
+      r[c % G][(c / G) * 2] = q.x;
+      r[c % G][(c / G) * 2 + 1] = q.y;
+    }
+    wave_lds_fence();
+  };
+  // registers -> the tile -> registers in row order (from_rows), then HBM (store).  Both matrices go through the tile
+  // before the first store is issued: a wait for anything older than a store (a reloaded spill on some path of the
+  // compiler's, say) is then a wait for that store's round trip to memory.
+  auto from_rows = [&](const T (&r)[G][E], Stage& t) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    const int mine = l * 16, key = l & 15;
+#pragma unroll
+    for (int c = 0; c < RC; ++c) tile[mine + (c ^ key)] = V{r[c % G][(c / G) * 2], r[c % G][(c / G) * 2 + 1]};
+    wave_lds_fence();
+    if constexpr (FULL) {
+      const int h = l / RC, col = l % RC;
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int rk = RPI * k + h, slot = rk * 16 + (col ^ rk);
+#pragma unroll
+        for (int m = 0; m < RC / P; ++m) {
+          const V q = tile[slot + m * 256];
+          t[2 * (P * m + k)] = q.x;
+          t[2 * (P * m + k) + 1] = q.y;
+        }
+      }
+    } else {
+      Walk w = walk0(l);
+#pragma unroll
+      for (int i = 0; i < RC; ++i) {
+        const V q = tile[min(w.row, 63) * 16 + (w.col ^ (w.row & 15))];
+        t[2 * i] = q.x;
+        t[2 * i + 1] = q.y;
+        w.step();
+      }
+    }
+    wave_lds_fence();
+  };
+  auto store = [&](T* M, int64_t base, const Stage& t) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    char* tb = reinterpret_cast<char*>(M + (size_t)base * a.pitch);
+    const int live_rows = (int)min((int64_t)64, a.N - base);   // < 64 in the batch's last tile only
+    if (FULL && live_rows == 64) {
+#pragma unroll
+      for (int i = 0; i < RC; ++i) *reinterpret_cast<V*>(tb + (uint32_t)(i * 64 + l) * 16u) = V{t[2 * i], t[2 * i + 1]};
+    } else {
+      Walk w = walk0(l);
+#pragma unroll
+      for (int i = 0; i < RC; ++i) {
+        if ((FULL || i < CH) && w.row < live_rows) *reinterpret_cast<V*>(tb + (uint32_t)(i * 64 + l) * 16u) = V{t[2 * i], t[2 * i + 1]};
+        w.step();
+      }
+    }
+  };
+
+  const int lane = threadIdx.x;
+  T x[G][E], v[G][E];
+  if ((int)blockIdx.x < n_walk) {
+    // inverse-L proposal F L F of the listed particles; only H() of it is ever read (markov_jump_hmc.py:360,367)
+    const int n_cold = *a.count;
+    for (int64_t first = (int64_t)blockIdx.x * 64; first < n_cold; first += (int64_t)n_walk * 64) {
+      const int64_t idx = first + lane;
+      const bool live = idx < n_cold;
+      const int p = a.list[live ? idx : 0];
+      {
+        Stage tx, tv;
+        fetch_listed(a.X_in, p, tx);
+        fetch_listed(a.V_in, p, tv);
+        to_rows(tx, x);
+        to_rows(tv, v);
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[j][e] = -v[j][e];
+      trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
+      const T ev = kinetic_rows<T, E, G>(v);
+      const T ex = en.energy_of(en.template prep_rows<E, G>(x));
+      if (live) a.Hwork[p] = ex + ev;
+    }
+    return;
+  }
+  const int64_t base = (int64_t)((int)blockIdx.x - n_walk) * 64;
+  {
+    Stage tx, tv;
+    fetch(a.X_in, base, tx);
+    fetch(a.V_in, base, tv);
+    to_rows(tx, x);
+    to_rows(tv, v);
+  }
+  trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
+  const T EVL = kinetic_rows<T, E, G>(v);
+  const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
+  {
+    Stage tx, tv;
+    from_rows(x, tx);
+    from_rows(v, tv);
+    store(a.X_out, base, tx);
+    store(a.V_out, base, tv);
+  }
+  if (base + lane < a.N) {
+    a.EX_out[base + lane] = EXL;
+    a.EV_out[base + lane] = EVL;
+  }
+}
+
 template <typename T, int E>
 struct DecideShared {
   typename VecOf<T>::type stash[4][E / VecOf<T>::n][64];
@@ -2065,6 +2390,19 @@ inline void launch_step_t(const TrajArgs<T>* ta, const JumpDecideArgs<T>* da, co
     n_traj = (int)((ta->N + ppb - 1) / ppb) + ta->inv_blocks;
   }
   if (da) n_decide = (int)((da->N + 255) / 256);
+  if constexpr (HasRowForm<En>::value && sizeof(T) == 8 && E == 8) {
+    if (ta && !da && ta->rows && (ta->logG == 1 || ta->logG == 2)) {   // a lane per particle, a wavefront per workgroup
+      const int64_t fwd = (ta->N + 63) / 64;
+      const int n_walk = (int)std::max<int64_t>(1, std::min<int64_t>(fwd / 8, 4096));
+      const dim3 grid((unsigned)(fwd + n_walk));
+      const bool full = ta->CH == 4 << ta->logG;
+      if (ta->logG == 2 && full) hipLaunchKernelGGL((mjhmc_traj_rows_kernel<En, T, E, 2, true>), grid, dim3(64), 0, st, *ta, en, n_walk);
+      else if (ta->logG == 2) hipLaunchKernelGGL((mjhmc_traj_rows_kernel<En, T, E, 2, false>), grid, dim3(64), 0, st, *ta, en, n_walk);
+      else if (full) hipLaunchKernelGGL((mjhmc_traj_rows_kernel<En, T, E, 1, true>), grid, dim3(64), 0, st, *ta, en, n_walk);
+      else hipLaunchKernelGGL((mjhmc_traj_rows_kernel<En, T, E, 1, false>), grid, dim3(64), 0, st, *ta, en, n_walk);
+      return;
+    }
+  }
   const TrajArgs<T> t = ta ? *ta : TrajArgs<T>{};
   const JumpDecideArgs<T> d = da ? *da : JumpDecideArgs<T>{};
   hipLaunchKernelGGL((mjhmc_step_kernel<En, T, E>), dim3((unsigned)(n_traj + n_decide)), dim3(256), 0, st, t, d, en, n_traj,

@@ -165,7 +165,11 @@ def test_float32_state(kind, D, N):
     assert np.allclose(c.read(_lib.F_EX)[same], d.read(_lib.F_EX)[same], rtol=2e-4, atol=2e-4 * scale)
 
 
-@pytest.mark.parametrize('kind,D,N', [('E_FUNNEL_NEAL', 32, 20000), ('E_ISO_GAUSS', 6, 70001), ('E_ROUGH_WELL', 40, 16400)])
+@pytest.mark.parametrize('kind,D,N', [('E_FUNNEL_NEAL', 32, 20000), ('E_ISO_GAUSS', 6, 70001), ('E_ROUGH_WELL', 40, 16400),
+                                      # the trajectory launch in row form (a lane per particle, mjhmc_traj_rows_kernel): full and
+                                      # short rows of four-lane and two-lane groups, a last tile with padding rows
+                                      ('E_FUNNEL_NEAL', 31, 20011), ('E_FUNNEL_NEAL', 21, 9000), ('E_FUNNEL_REF', 16, 40001),
+                                      ('E_FUNNEL_REF', 11, 33000), ('E_FUNNEL_NEAL', 9, 16385)])
 def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
     """Big batches with several particles per wave run an iteration as two launches -- every trajectory (the inverse-L
     proposals of the cold caches in workgroups of their own), then the jump process with a lane per particle, whose movers
@@ -174,7 +178,7 @@ def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
     all of it per slot.  (Both samplers from the test build with fused launches switched off: below 160 000 particles
     the product would fuse the multi-iteration calls.)"""
     from mjhmc_amd import _lib
-    params = {'E_FUNNEL_NEAL': [3.0], 'E_ROUGH_WELL': [100.0, 4.0]}.get(kind, [1.0])
+    params = {'E_FUNNEL_NEAL': [3.0], 'E_FUNNEL_REF': [3.0], 'E_ROUGH_WELL': [100.0, 4.0]}.get(kind, [1.0])
     monkeypatch.setenv('MJHMC_NO_FUSE', '1')
     (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, libs='hh')
     for s in (a, b):

@@ -1,5 +1,5 @@
 """C4 (Neal funnel, ndims 32, L 15, float64) at shard sizes: the compacted three-launch iteration against fused launches.
-usage: python tools/sweep_shard_c4.py [steps]      (test build: MJHMC_FUSE_BELOW moves the fused / compacted threshold)"""
+usage: python tools/sweep_shard_c4.py [steps]      (test build: MJHMC_FUSE_BELOW moves the fused / compacted threshold, MJHMC_NO_ROWS)"""
 import os as _os
 _os.environ.setdefault('MJHMC_HIP_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mjhmc_amd', 'lib', 'libmjhmc_hip_test.so'))
 import os
@@ -38,14 +38,18 @@ def main():
         smp = engine.DeviceSampler(en, X0, seed=1)
         smp.set_hparams(0.05, 15, -np.log(0.9) * 0.5, 1.0)
         row = {}
-        for tag, env in (('compacted', '0'), ('fused', '100000000')):
+        for tag, env in (('compacted', '0'), ('groups', '0'), ('fused', '100000000')):
             os.environ['MJHMC_FUSE_BELOW'] = env
+            if tag == 'groups':      # the trajectory launch with a group of lanes per particle (before the row form)
+                os.environ['MJHMC_NO_ROWS'] = '1'
+            else:
+                os.environ.pop('MJHMC_NO_ROWS', None)
             row[tag] = time_ms(smp, steps)
         if full is None:
             full = min(row['compacted'][1], row['fused'][1])
         g = 1000000 // N
-        print('N=%8d steps=%d  compacted %.4f ms (wall %.4f)  fused %.4f ms (wall %.4f)   shard efficiency at G=%d: compacted %.2f fused %.2f'
-              % (N, steps, row['compacted'][0], row['compacted'][1], row['fused'][0], row['fused'][1], g,
+        print('N=%8d steps=%d  compacted %.4f ms (wall %.4f)  [lane groups: %.4f (wall %.4f)]  fused %.4f ms (wall %.4f)   shard efficiency at G=%d: compacted %.2f fused %.2f'
+              % (N, steps, row['compacted'][0], row['compacted'][1], row['groups'][0], row['groups'][1], row['fused'][0], row['fused'][1], g,
                  full / (g * row['compacted'][1]), full / (g * row['fused'][1])), flush=True)
         smp.close()
 
