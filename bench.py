@@ -428,7 +428,9 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
     elapsed = float(np.sum(call_s))
     iters = steps * reps
 
-    fused = w['kind'] == 'iso' and steps >= 2          # mjhmc_iterate fuses the Gaussian forces whenever a call has >= 2 iterations
+    # mjhmc_iterate fuses the Gaussian forces whenever a call has >= 2 iterations -- and the funnels, whose float64 rows of up
+    # to 32 dims run a lane per particle (mjhmc_fused_rows_kernel: bound by the vector pipe at any batch size)
+    fused = (w['kind'] == 'iso' or (w['kind'] == 'funnel' and w['dtype'] == 'float64' and 9 <= w['D'] <= 32)) and steps >= 2
     # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel: what every
     # sampling_iteration() caller gets -- a call of ONE iteration is never fused), after the timed region
     unfused_ms = None
@@ -558,7 +560,10 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         # element and leapfrog step (drift, merged kick), on the forward trajectory of every particle and the
         # inverse one of the cold-cache particles, plus 4 flop per element for the two energy sums (rates, draws,
         # reductions and bookkeeping are vector instructions too, not flops).
-        vflops = (1.0 + cold_frac) * (4.0 * w['L'] + 6.0) * w['D'] * n_rank
+        # (the funnel's force needs sum_k x_k^2 at every step: one more multiply-add per element and step; its exp(-x0),
+        # once per particle and step, is not counted)
+        fl_step = 6.0 if w['kind'] == 'funnel' else 4.0
+        vflops = (1.0 + cold_frac) * (fl_step * w['L'] + 6.0) * w['D'] * n_rank
         valu_tf = vflops / (kern_it_ms * 1e-3) / 1e12
         valu_peak = 78.6 if w['dtype'] == 'float64' else 157.3
         valu = {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak}
@@ -566,10 +571,19 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         if fused:
             # the state crosses HBM once per LAUNCH, not once per iteration: HBM does not bound the launch (the
             # algorithmic byte rate of SURVEY 8d exceeds the HBM peak); the fp64 vector pipe does
-            roof = dict(valu, bound='fp64_valu', traffic=traffic, kernel='mjhmc_jump_kernel<FUSED>',
+            roof = dict(valu, bound='fp64_valu', traffic=traffic,
+                        kernel='mjhmc_fused_rows_kernel' if w['kind'] == 'funnel' else 'mjhmc_jump_kernel<FUSED>',
                         avg_launch_ms=kern_it_ms * it_per_launch, launches_timed=launches / it_per_launch,
                         iterations_per_launch=it_per_launch, algorithmic_flops_per_launch=vflops * it_per_launch)
             roof['hbm_algorithmic'] = hbm
+            if w['kind'] == 'funnel':
+                # a wave of 64 particles integrates the inverse-L trajectory in all its lanes whenever ONE of its caches is
+                # cold: what the pipe executes, beside what the chain needs (`achieved`)
+                waves_inv = 1.0 - (1.0 - cold_frac) ** 64
+                ex_flops = (1.0 + waves_inv) * (fl_step * w['L'] + 6.0) * w['D'] * n_rank
+                roof['executed'] = {'achieved': ex_flops / (kern_it_ms * 1e-3) / 1e12, 'unit': 'TFLOP/s',
+                                    'frac': ex_flops / (kern_it_ms * 1e-3) / 1e12 / valu_peak,
+                                    'waves_integrating_inverse_L': waves_inv}
             if unfused_ms:
                 roof['one_iteration_per_launch'] = {
                     'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,

@@ -47,7 +47,7 @@ static const char* test_env(const char*) { return nullptr; }
 
 static int ab_flags() {
   return (test_env("MJHMC_NO_BLOCK_DECIDE") ? kAbNoBlockDecide : 0) | (test_env("MJHMC_NO_WPP") ? kAbNoWpp : 0) |
-         (test_env("MJHMC_NO_QUAD") ? kAbNoQuad : 0);
+         (test_env("MJHMC_NO_QUAD") ? kAbNoQuad : 0) | (test_env("MJHMC_NO_ROWS") ? kAbNoRows : 0);
 }
 
 static int ilog2(int v) {
@@ -57,6 +57,13 @@ static int ilog2(int v) {
 }
 
 // lanes-per-particle / elements-per-lane selection (see elementwise.hpp header comment)
+// fused MarkovJumpHMC launches of this sampler run in row form (elementwise.hpp: mjhmc_fused_rows_kernel)
+static bool fused_rows(const mjhmc_sampler* s) {
+  const int kind = s->en->ep.kind;
+  return (kind == MJHMC_E_FUNNEL_NEAL || kind == MJHMC_E_FUNNEL_REF) && s->dtype == MJHMC_F64 && s->sh.E == 8 &&
+         fused_rows_shape(s->mode, s->sh.logG, ab_flags());
+}
+
 int pick_shape(int D, int dtype, Shape* out) {
   const int esize = dtype == MJHMC_F64 ? 8 : 4;
   const int VEC = 16 / esize;
@@ -1428,7 +1435,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   if (ring_slot0 < 0 && !test_env("MJHMC_NO_SPLIT")) {
     if (const char* np = test_env("MJHMC_SPLIT_PARTS")) n_parts = std::max(2, std::min(8, std::atoi(np)));
     const int64_t nslots = s->Npad >> (6 - s->sh.logG);
-    if (nslots >= 8 * 4096) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part
+    if (nslots >= 8 * 4096 && !fused_rows(s)) split_at = (s->Npad / n_parts) / 256 * 256;  // whole workgroups' worth of slots in every part
     if (split_at <= 0 || split_at * (n_parts - 1) >= s->N) split_at = 0;
     if (split_at) TRY(ensure_part_streams(s, n_parts));
   }
@@ -1617,7 +1624,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
   int64_t fuse_below = kFuseBelow;
   if (const char* fb = test_env("MJHMC_FUSE_BELOW")) fuse_below = std::atoll(fb);
-  const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || s->N < fuse_below || s->D <= 4);
+  // (the funnels in row form -- a lane per particle, mjhmc_fused_rows_kernel -- are bound by the vector pipe at any batch size)
+  const bool rows = fused_rows(s) && !test_env("MJHMC_FUSE_BELOW");
+  const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || rows || s->N < fuse_below || s->D <= 4);
   if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !test_env("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);

@@ -545,7 +545,7 @@ struct FunnelRefF {
 // ------------------------------------------------------------------------------------------
 
 // launch_jump_t's A/B flags (JumpArgs::ab): take the generic instance instead of a specialised lane mapping
-constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4;
+constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4, kAbNoRows = 8;
 
 template <typename T>
 struct JumpArgs {
@@ -1316,9 +1316,15 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
   if (a.ctl->failed) {  // an earlier attempt of this batch was rolled back: do nothing
     // ... unless the failure belongs to THIS fused launch (another workgroup met it first): this workgroup must still run,
     // report an earlier first failure of its own particles if it has one, and flush its tallies of the good iterations
-    if (!FUSED) return;
-    const int first = 0x7fffffff - __hip_atomic_load(&a.ctl->inv_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (first < a.iter) return;
+    // (single-iteration launches too: a workgroup that starts after another one of ITS launch has raised the flag -- two
+    // processes sharing the GPU delay each other's workgroups by more than a short kernel runs -- must still tally its cold
+    // caches: the failed attempt's evaluations count, Distribution.E_count)
+    if (!FUSED) {
+      if (__hip_atomic_load(&a.ctl->failed_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.iter) return;
+    } else {
+      const int first = 0x7fffffff - __hip_atomic_load(&a.ctl->inv_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (first < a.iter) return;
+    }
   }
   // Persistent waves: wave w handles slots w, w + W, w + 2W, ... (a slot = the 64/G particles one
   // wavefront works on).  The NEXT slot's X, V and scalars are loaded into a second register set
@@ -1647,8 +1653,9 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
     return;
   }
   if (any_bad) {  // draw_from's ValueError (utils.py:43-48): the host rolls this attempt back
+    a.ctl->failed_iter = a.iter;   // (first: whoever sees the flag sees which launch raised it)
+    __threadfence();
     a.ctl->failed = 1;
-    a.ctl->failed_iter = a.iter;
   }
 
   // integer bookkeeping: l/f/r counts and the number of cold inverse-L caches of this attempt
@@ -1828,29 +1835,32 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <class En, typename T, int E, int LOGG, bool FULL>
-__global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T> a, const En en, int n_walk) {
+// The tile traffic of the row-form kernels: 64 rows between HBM (row order: chunk q = i * 64 + lane of the tile's 64 * CH
+// chunks, (row, col) = (q / CH, q % CH)) and the lanes that own them, through tile[64 * 16] (slot row * 16 + (col ^ (row & 15))).
+// FULL: every row has all its chunks (ndims 31, 32 / 15, 16): no predicate anywhere, and i = P * m + k walks rows
+// 16 m + RPI * k + lane / RC, so a row-order slot is one of P per-lane bases + m * 256.
+template <typename T, int E, int LOGG, bool FULL>
+struct RowTile {
   static_assert(sizeof(T) == 8, "float64 rows");
-  constexpr int G = 1 << LOGG, C = E / 2, RC = C * G;   // RC: chunks of a full row
+  static constexpr int G = 1 << LOGG, C = E / 2, RC = C * G;   // RC: chunks of a full row
   static_assert(RC == 8 || RC == 16, "rows of 8 or 16 chunks");
+  static constexpr int RPI = 64 / RC, P = 16 / RPI;
   using V = double2;
   // the chunks on their way between HBM and the tile: ONE vector value, not an array (an array of 16 chunks indexed from
   // unrolled loops was left in scratch memory -- 512 bytes written and read back per wave and matrix)
   using Stage = double __attribute__((ext_vector_type(2 * RC)));
-  __shared__ V tile[64 * 16];
-  if (a.ctl->failed) return;
-  const int CH = FULL ? RC : a.CH;   // FULL: every row has all its chunks (ndims 31, 32 / 15, 16): no predicate anywhere
+  V* tile;
+  int CH, pitch;
+  int64_t N;
+
   // Every phase forms its own addresses from an opaque copy of the lane index: formed once, the compiler carries 16 + 16 LDS
   // and 2 x 16 global addresses across the trajectory loop in scratch memory -- and each reload in the store phase is a
   // vmcnt(0) wait, i.e. it waits for the previous STORE to reach memory (16 round trips per matrix).
-  auto fresh_lane = [&]() __attribute__((always_inline)) {
+  static __device__ __forceinline__ int fresh_lane() {
     int l = threadIdx.x;
     asm volatile("" : "+v"(l));
     return l;
-  };
-  // The tile in row order: chunk q = i * 64 + lane is (row, col) = (q / CH, q % CH), slot row * 16 + (col ^ (row & 15)).
-  // FULL: i = P * m + k walks rows 16 m + RPI * k + lane / RC, so the slot is one of P per-lane bases + m * 256.
-  constexpr int RPI = 64 / RC, P = 16 / RPI;
+  }
   struct Walk {   // short rows: (row, col) stepped, not divided
     int row, col, drow, dcol, CH;
     __device__ __forceinline__ void step() {
@@ -1862,7 +1872,7 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
       }
     }
   };
-  auto walk0 = [&](int l) __attribute__((always_inline)) {
+  __device__ __forceinline__ Walk walk0(int l) const {
     Walk w;
     w.CH = CH;
     w.row = l / CH;
@@ -1870,13 +1880,12 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
     w.drow = 64 / CH;
     w.dcol = 64 - w.drow * CH;
     return w;
-  };
-
+  }
   // HBM rows -> registers, still in row order.  All loads are issued before anything waits; the passes a short row does
   // not need re-read the tile's last chunk and are dropped.
-  auto fetch = [&](const T* M, int64_t base, Stage& t) __attribute__((always_inline)) {
+  __device__ __forceinline__ void fetch(const T* M, int64_t base, Stage& t) const {
     const int l = fresh_lane();
-    const char* tb = reinterpret_cast<const char*>(M + (size_t)base * a.pitch);
+    const char* tb = reinterpret_cast<const char*>(M + (size_t)base * pitch);
     const uint32_t last_chunk = (uint32_t)(64 * CH - 1) * 16u;
 #pragma unroll
     for (int i = 0; i < RC; ++i) {
@@ -1886,22 +1895,22 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
       t[2 * i] = q.x;
       t[2 * i + 1] = q.y;
     }
-  };
-  // the listed particles' rows, RC lanes per row
-  auto fetch_listed = [&](const T* M, int p_lane, Stage& t) __attribute__((always_inline)) {
+  }
+  // the listed particles' rows (p_lane: the particle whose row this lane will own), RC lanes per row
+  __device__ __forceinline__ void fetch_listed(const T* M, int p_lane, Stage& t) const {
     const int l = fresh_lane();
     Walk w = walk0(l);
 #pragma unroll
     for (int i = 0; i < RC; ++i) {
       const int pr = __shfl(p_lane, FULL ? w.row : min(w.row, 63));
-      const V q = *reinterpret_cast<const V*>(M + (size_t)pr * a.pitch + w.col * 2);
+      const V q = *reinterpret_cast<const V*>(M + (size_t)pr * pitch + w.col * 2);
       t[2 * i] = q.x;
       t[2 * i + 1] = q.y;
       w.step();
     }
-  };
-  // ... through the tile into the lane that owns the row
-  auto to_rows = [&](const Stage& t, T (&r)[G][E]) __attribute__((always_inline)) {
+  }
+  // ... through the tile into the lane that owns the row: r[j] = what lane j of the particle's group holds elsewhere
+  __device__ __forceinline__ void to_rows(const Stage& t, T (&r)[G][E]) const {
     const int l = fresh_lane();
     if constexpr (FULL) {
       const int h = l / RC, col = l % RC;
@@ -1920,6 +1929,12 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
       }
     }
     wave_lds_fence();
+    read_own(r);
+    wave_lds_fence();
+  }
+  // the lane's own row of the tile <-> registers
+  __device__ __forceinline__ void read_own(T (&r)[G][E]) const {
+    const int l = fresh_lane();
     const int mine = l * 16, key = l & 15;
 #pragma unroll
     for (int c = 0; c < RC; ++c) {
@@ -1928,17 +1943,20 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
       r[c % G][(c / G) * 2] = q.x;
       r[c % G][(c / G) * 2 + 1] = q.y;
     }
-    wave_lds_fence();
-  };
-  // registers -> the tile -> registers in row order (from_rows), then HBM (store).  Both matrices go through the tile
-  // before the first store is issued: a wait for anything older than a store (a reloaded spill on some path of the
-  // compiler's, say) is then a wait for that store's round trip to memory.
-  auto from_rows = [&](const T (&r)[G][E], Stage& t) __attribute__((always_inline)) {
+  }
+  __device__ __forceinline__ void write_own(const T (&r)[G][E]) const {
     const int l = fresh_lane();
     const int mine = l * 16, key = l & 15;
 #pragma unroll
     for (int c = 0; c < RC; ++c) tile[mine + (c ^ key)] = V{r[c % G][(c / G) * 2], r[c % G][(c / G) * 2 + 1]};
+  }
+  // registers -> the tile -> registers in row order (from_rows), then HBM (store).  Both matrices of a state go through
+  // the tile before the first store is issued: a wait for anything older than a store (a reloaded spill on some path of
+  // the compiler's, say) is then a wait for that store's round trip to memory.
+  __device__ __forceinline__ void from_rows(const T (&r)[G][E], Stage& t) const {
+    write_own(r);
     wave_lds_fence();
+    const int l = fresh_lane();
     if constexpr (FULL) {
       const int h = l / RC, col = l % RC;
 #pragma unroll
@@ -1962,11 +1980,11 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
       }
     }
     wave_lds_fence();
-  };
-  auto store = [&](T* M, int64_t base, const Stage& t) __attribute__((always_inline)) {
+  }
+  __device__ __forceinline__ void store(T* M, int64_t base, const Stage& t) const {
     const int l = fresh_lane();
-    char* tb = reinterpret_cast<char*>(M + (size_t)base * a.pitch);
-    const int live_rows = (int)min((int64_t)64, a.N - base);   // < 64 in the batch's last tile only
+    char* tb = reinterpret_cast<char*>(M + (size_t)base * pitch);
+    const int live_rows = (int)min((int64_t)64, N - base);   // < 64 in the batch's last tile only
     if (FULL && live_rows == 64) {
 #pragma unroll
       for (int i = 0; i < RC; ++i) *reinterpret_cast<V*>(tb + (uint32_t)(i * 64 + l) * 16u) = V{t[2 * i], t[2 * i + 1]};
@@ -1978,8 +1996,17 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
         w.step();
       }
     }
-  };
+  }
+};
 
+template <class En, typename T, int E, int LOGG, bool FULL>
+__global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T> a, const En en, int n_walk) {
+  using RT = RowTile<T, E, LOGG, FULL>;
+  using Stage = typename RT::Stage;
+  constexpr int G = RT::G;
+  __shared__ typename RT::V tile[64 * 16];
+  if (a.ctl->failed) return;
+  const RT rt{tile, FULL ? RT::RC : a.CH, a.pitch, a.N};
   const int lane = threadIdx.x;
   T x[G][E], v[G][E];
   if ((int)blockIdx.x < n_walk) {
@@ -1991,10 +2018,10 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
       const int p = a.list[live ? idx : 0];
       {
         Stage tx, tv;
-        fetch_listed(a.X_in, p, tx);
-        fetch_listed(a.V_in, p, tv);
-        to_rows(tx, x);
-        to_rows(tv, v);
+        rt.fetch_listed(a.X_in, p, tx);
+        rt.fetch_listed(a.V_in, p, tv);
+        rt.to_rows(tx, x);
+        rt.to_rows(tv, v);
       }
 #pragma unroll
       for (int j = 0; j < G; ++j)
@@ -2010,24 +2037,215 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
   const int64_t base = (int64_t)((int)blockIdx.x - n_walk) * 64;
   {
     Stage tx, tv;
-    fetch(a.X_in, base, tx);
-    fetch(a.V_in, base, tv);
-    to_rows(tx, x);
-    to_rows(tv, v);
+    rt.fetch(a.X_in, base, tx);
+    rt.fetch(a.V_in, base, tv);
+    rt.to_rows(tx, x);
+    rt.to_rows(tv, v);
   }
   trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
   const T EVL = kinetic_rows<T, E, G>(v);
   const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
   {
     Stage tx, tv;
-    from_rows(x, tx);
-    from_rows(v, tv);
-    store(a.X_out, base, tx);
-    store(a.V_out, base, tv);
+    rt.from_rows(x, tx);
+    rt.from_rows(v, tv);
+    rt.store(a.X_out, base, tx);
+    rt.store(a.V_out, base, tv);
   }
   if (base + lane < a.N) {
     a.EX_out[base + lane] = EXL;
     a.EV_out[base + lane] = EVL;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused MarkovJumpHMC iterations in row form: n_fuse sampling iterations of 64 particles per wavefront with the state in
+// registers between them -- what mjhmc_jump_kernel<.., FUSED> does for a group of lanes per particle, with a lane per
+// particle.  Per iteration a wave runs the inverse-L trajectory (whenever one of its 64 caches is cold: nearly always),
+// the L trajectory, the jump process (decide() in its one-lane form, as the jump-process launch of the compacted path)
+// and the successor selection; HBM sees the state once per launch (+ the ring snapshots when samples are recorded).
+// With ~125 vector instructions per leapfrog step and 64 particles this is bound by the vector pipe at about half the
+// time the two launches of the compacted path need for their bytes (C4).
+//
+// The momentum refresh of the wave's R-movers (a few per iteration) is spread over all lanes: the movers' rows go into
+// the tile, every lane redraws one CHUNK of one mover -- normal_pair(key, particle, chunk) and the two products and the
+// sum of refresh_stash, the same bits -- and the movers read their rows back.
+// One wavefront per SIMD (x, v, their pre-move copies and the inverse-L trajectory's working state: ~400 registers),
+// persistent: a wave strides over the tiles and adds its tallies up in LDS.
+// ------------------------------------------------------------------------------------------
+template <class En, typename T, int E, int LOGG, bool FULL>
+__global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<T> a, const En en) {
+  using RT = RowTile<T, E, LOGG, FULL>;
+  using Stage = typename RT::Stage;
+  using V = typename RT::V;
+  constexpr int G = RT::G, RC = RT::RC;
+  __shared__ V tile[64 * 16];
+  __shared__ unsigned tally[kMaxFuse][4];
+  __shared__ int rtab[64];
+  if (a.ctl->failed) return;   // an earlier attempt of this batch was rolled back: do nothing
+  const RT rt{tile, FULL ? RC : a.CH, a.pitch, a.N};
+  const int lane = threadIdx.x;
+  const int n_it = a.n_fuse;
+#pragma unroll
+  for (int i = 0; i < kMaxFuse * 4 / 64; ++i) (&tally[0][0])[i * 64 + lane] = 0;
+  wave_lds_fence();
+  int first_bad = 0x7fffffff;
+  LaneMap m1;   // decide() with the three clocks in one lane
+  m1.j = 0;
+  m1.G = 1;
+  m1.D = 1;
+  m1.CH = 1;
+  m1.lane0 = 0;
+  m1.wpp = 0;
+  const int64_t n_tiles = a.Npad >> 6;
+#pragma unroll 1
+  for (int64_t ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+    const int64_t base = ti * 64, p = base + lane;
+    const bool alive = p < a.N;
+    const int64_t pc = alive ? p : a.N - 1;   // padding rows: somebody's scalars, nothing of theirs is stored
+    T x[G][E], v[G][E];
+    {
+      Stage tx, tv;
+      rt.fetch(a.X_in, base, tx);
+      rt.fetch(a.V_in, base, tv);
+      rt.to_rows(tx, x);
+      rt.to_rows(tv, v);
+    }
+    T EX0 = a.EX_in[pc], EV0 = a.EV_in[pc], Hcached = a.Hflf_in[pc];
+    const uint32_t pid = (uint32_t)(a.first_pid + p);
+    RngKey key = a.key;
+    int k = 0;
+    double dwell = 0.0;
+    T EXn = EX0, EVn = EV0, Hc = Hcached;
+#pragma unroll 1
+    for (int it = 0; it < n_it; ++it) {
+      T x0[G][E], v0[G][E];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          x0[j][e] = x[j][e];
+          v0[j][e] = v[j][e];
+        }
+      const bool warm = Hcached == Hcached;   // cache_active (hmc_state.py:43-44) is carried as "H_flf is not NaN"
+      const T H0 = EX0 + EV0;                 // HMCState.H (hmc_state.py:80-84)
+      // inverse-L proposal F L F of the cold caches; only H() of it is ever read (markov_jump_hmc.py:360,367).  (Stepping it
+      // TOGETHER with the L proposal -- two independent dependency chains for one wave per SIMD -- needs more than the 256
+      // registers vector instructions can address: 389 instead of 2 x 129 instructions per step, the rest register moves.)
+      T Hflf = Hcached;
+      if (__ballot(!warm) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[j][e] = -v[j][e];
+        trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
+        const T ev = kinetic_rows<T, E, G>(v);
+        const T ex = en.energy_of(en.template prep_rows<E, G>(x));
+        if (!warm) Hflf = ex + ev;
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            x[j][e] = x0[j][e];
+            v[j][e] = v0[j][e];
+          }
+      }
+      // forward proposal L
+      trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
+      const T EVL = kinetic_rows<T, E, G>(v);
+      const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
+      const T HL = EXL + EVL;
+      bool bad = false;
+      decide<T, false>(a, key, m1, H0, HL, Hflf, pc, pid, k, dwell, bad);
+      // successor state (markov_jump_hmc.py:399-410)
+      const bool isL = k == 0, isF = k == 1, isR = k == 2;
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          x[j][e] = isL ? x[j][e] : x0[j][e];
+          v[j][e] = isL ? v[j][e] : (isF ? -v0[j][e] : v0[j][e]);
+        }
+      EXn = isL ? EXL : EX0;
+      EVn = isL ? EVL : EV0;
+      Hc = isL ? H0 : (T)__builtin_nan("");   // L: the pre-move state becomes the cached inverse-L state; F, R: clear_flf_cache
+      const unsigned long long bR = __ballot(isR && alive);
+      if (bR != 0ull) {   // HMCState.R (hmc_state.py:121-129) of the wave's R-movers, a chunk per lane
+        const int nR = (int)__popcll(bR);
+        if (isR && alive) {
+          rtab[(int)__popcll(bR & ((1ull << lane) - 1ull))] = lane;
+          rt.write_own(v);
+        }
+        wave_lds_fence();
+        const int l = RT::fresh_lane();
+        for (int w = l; w < nR * RC; w += 64) {
+          const int q = w / RC, c = w % RC;
+          if (FULL || c < rt.CH) {
+            const int r = rtab[q];
+            const int slot = r * 16 + (c ^ (r & 15));
+            const V vc = tile[slot];
+            const int d = c * 2;
+            double z0, z1;
+            normal_pair(key, (uint32_t)(a.first_pid + base + r), (uint32_t)c, z0, z1);
+            const T zy = (d + 1 < a.D) ? (T)z1 : T(0);
+            V res;
+            res.x = vc.x * a.r_keep + (T)z0 * a.r_mix;
+            res.y = vc.y * a.r_keep + zy * a.r_mix;
+            tile[slot] = res;
+          }
+        }
+        wave_lds_fence();
+        if (isR && alive) {
+          rt.read_own(v);
+          EVn = kinetic_rows<T, E, G>(v);
+        }
+        wave_lds_fence();
+      }
+      // bookkeeping of iteration `it`; the successor state becomes the next iteration's pre-move state
+      if (bad && alive) first_bad = min(first_bad, it);
+      const unsigned long long b0 = __ballot(alive && isL), b1 = __ballot(alive && isF), b3 = __ballot(alive && !warm);
+      if (lane == 0) {
+        tally[it][0] += (unsigned)__popcll(b0);
+        tally[it][1] += (unsigned)__popcll(b1);
+        tally[it][2] += (unsigned)__popcll(bR);
+        tally[it][3] += (unsigned)__popcll(b3);
+      }
+      if (a.xiter) {  // sample ring: X and the dwelling times after every iteration
+        Stage tx;
+        rt.from_rows(x, tx);
+        rt.store(a.xiter + (size_t)it * a.xiter_stride, base, tx);
+        a.dwell_ring[(size_t)it * a.Npad + p] = dwell;
+      }
+      EX0 = EXn;
+      EV0 = EVn;
+      Hcached = Hc;
+      key.tick_hi += (key.tick_lo == 0xFFFFFFFFu) ? 1u : 0u;
+      key.tick_lo += 1u;
+    }  // fused iterations
+    {
+      Stage tx, tv;
+      if (!a.xiter) rt.from_rows(x, tx);
+      rt.from_rows(v, tv);
+      if (!a.xiter) rt.store(a.X_out, base, tx);
+      rt.store(a.V_out, base, tv);
+    }
+    if (alive) {
+      a.EX_out[p] = EXn;
+      a.EV_out[p] = EVn;
+      a.Hflf_out[p] = Hc;
+      a.dwell[p] = dwell;
+      a.trans[p] = (uint8_t)k;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, o));
+  if (first_bad != 0x7fffffff && lane == 0) {
+    a.ctl->failed = 1;
+    atomicMax(&a.ctl->inv_iter, 0x7fffffff - (a.iter + first_bad));
+  }
+  wave_lds_fence();
+  for (int i = lane; i < n_it * 4; i += 64) {
+    const unsigned t = (&tally[0][0])[i];
+    if (t) atomicAdd(&a.stats[i], (unsigned long long)t);
   }
 }
 
@@ -2119,8 +2337,9 @@ __device__ __forceinline__ void decide_block(const JumpDecideArgs<T>& a, DecideS
   const int nr = n_r, nf = n_f, nm = nr + nf;
   if (threadIdx.x == 0) {
     if (any_bad) {  // draw_from's ValueError (utils.py:43-48): the host rolls this attempt back
-      a.ctl->failed = 1;
       a.ctl->failed_iter = a.iter;
+      __threadfence();
+      a.ctl->failed = 1;
     }
     list_base = nm ? atomicAdd(a.next_count, nm) : 0;
   }
@@ -2345,6 +2564,26 @@ inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   hipLaunchKernelGGL((mjhmc_jump_kernel<En, T, E, MODE, REPLAY, FULLROW, WPP, FUSED>), dim3(grid), dim3(256), 0, st, a, en);
 }
 
+// fused MarkovJumpHMC launches of the energies with a row form run a lane per particle for rows held by 2 or 4 lanes elsewhere
+inline bool fused_rows_shape(int mode, int logG, int ab) {
+  return mode == kModeMJHMC && (logG == 1 || logG == 2) && !(ab & kAbNoRows);
+}
+// persistent: as many one-wave workgroups as the device keeps resident (one per SIMD), never more than there are tiles
+template <class En, typename T, int E, int LOGG, bool FULL>
+inline void launch_fused_rows(const JumpArgs<T>& a, const En& en, hipStream_t st) {
+  static int resident_blocks = 0;
+  if (resident_blocks == 0) {
+    int dev = 0, per_cu = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_fused_rows_kernel<En, T, E, LOGG, FULL>, 64, 0);
+    resident_blocks = std::max(1, per_cu) * std::max(1, cus);
+  }
+  const int64_t tiles = a.Npad >> 6;
+  const unsigned grid = (unsigned)std::min<int64_t>(tiles, resident_blocks);
+  hipLaunchKernelGGL((mjhmc_fused_rows_kernel<En, T, E, LOGG, FULL>), dim3(grid), dim3(64), 0, st, a, en);
+}
+
 // Replay needs every recorded stream of the mode; it is a test path and exists only in the
 // predicated (non-FULLROW) form, as do the control-arm samplers.
 template <class En, typename T, int E>
@@ -2352,6 +2591,16 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   const bool full = a.CH == (E / VecOf<T>::n) << a.logG;
   const bool replay = a.noise != nullptr;
   if constexpr (En::kFuse) if (a.n_fuse > 0) {  // several iterations per launch (counter RNG only)
+    if constexpr (HasRowForm<En>::value && sizeof(T) == 8 && E == 8) {
+      if (fused_rows_shape(a.mode, a.logG, a.ab)) {   // a lane per particle (mjhmc_fused_rows_kernel)
+        const bool full_row = a.CH == 4 << a.logG;
+        if (a.logG == 2 && full_row) launch_fused_rows<En, T, E, 2, true>(a, en, st);
+        else if (a.logG == 2) launch_fused_rows<En, T, E, 2, false>(a, en, st);
+        else if (full_row) launch_fused_rows<En, T, E, 1, true>(a, en, st);
+        else launch_fused_rows<En, T, E, 1, false>(a, en, st);
+        return;
+      }
+    }
     if (a.mode == kModeMJHMC) {
       if (full && a.logG == 6 && !(a.ab & kAbNoBlockDecide)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 5, true>(a, en, st);
       else if (full && a.logG == 5 && !(a.ab & kAbNoBlockDecide)) launch_jump_r<En, T, E, kModeMJHMC, false, true, 6, true>(a, en, st);

@@ -44,7 +44,11 @@ def _stats_tuple(st):
     ('E_ISO_GAUSS', 40, 129, 'MODE_MJHMC', 5),       # ragged rows (predicated chunks)
     ('E_ISO_GAUSS', 2, 100, 'MODE_MJHMC', 9),
     ('E_DIAG_GAUSS', 32, 300, 'MODE_MJHMC', 6),
-    ('E_FUNNEL_NEAL', 32, 300, 'MODE_MJHMC', 6),      # fused while the batch is small
+    ('E_FUNNEL_NEAL', 32, 300, 'MODE_MJHMC', 6),      # the funnels fuse in row form (a lane per particle, mjhmc_fused_rows_kernel):
+    ('E_FUNNEL_NEAL', 31, 20011, 'MODE_MJHMC', 5),    #   full rows of four-lane groups, a persistent grid with a ragged last tile
+    ('E_FUNNEL_NEAL', 21, 131, 'MODE_MJHMC', 70),     #   short rows; across the 64-iteration launch boundary
+    ('E_FUNNEL_NEAL', 16, 700, 'MODE_MJHMC', 9),      #   two-lane groups, full rows
+    ('E_FUNNEL_NEAL', 11, 65, 'MODE_MJHMC', 7),       #   two-lane groups, short rows
     ('E_ROUGH_WELL', 4, 48, 'MODE_MJHMC', 8),
     ('E_MM_GAUSS', 3, 40, 'MODE_MJHMC', 8),
     ('E_ROUGH_WELL', 40, 200, 'MODE_CONTROL', 6),

@@ -38,19 +38,20 @@ def main():
         smp = engine.DeviceSampler(en, X0, seed=1)
         smp.set_hparams(0.05, 15, -np.log(0.9) * 0.5, 1.0)
         row = {}
-        for tag, env in (('compacted', '0'), ('groups', '0'), ('fused', '100000000')):
+        # compacted: trajectory launch (row form) + jump-process launch; groups: the same with a group of lanes per particle;
+        # fused: all iterations of a call in one launch, row form; fused_groups: the same with a group of lanes per particle
+        for tag, env in (('compacted', '0'), ('groups', '0'), ('fused', '100000000'), ('fused_groups', '100000000')):
             os.environ['MJHMC_FUSE_BELOW'] = env
-            if tag == 'groups':      # the trajectory launch with a group of lanes per particle (before the row form)
+            if tag.endswith('groups'):
                 os.environ['MJHMC_NO_ROWS'] = '1'
             else:
                 os.environ.pop('MJHMC_NO_ROWS', None)
             row[tag] = time_ms(smp, steps)
         if full is None:
-            full = min(row['compacted'][1], row['fused'][1])
+            full = min(r[1] for r in row.values())
         g = 1000000 // N
-        print('N=%8d steps=%d  compacted %.4f ms (wall %.4f)  [lane groups: %.4f (wall %.4f)]  fused %.4f ms (wall %.4f)   shard efficiency at G=%d: compacted %.2f fused %.2f'
-              % (N, steps, row['compacted'][0], row['compacted'][1], row['groups'][0], row['groups'][1], row['fused'][0], row['fused'][1], g,
-                 full / (g * row['compacted'][1]), full / (g * row['fused'][1])), flush=True)
+        print('N=%8d steps=%d  ' % (N, steps) + '  '.join('%s %.4f (wall %.4f)' % (t, row[t][0], row[t][1]) for t in row)
+              + '   shard efficiency at G=%d: ' % g + ' '.join('%s %.2f' % (t, full / (g * row[t][1])) for t in row), flush=True)
         smp.close()
 
 
