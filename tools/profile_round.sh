@@ -29,6 +29,13 @@ case " $WL " in *" c2 "*)
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_c2nofuse_$c" -o c2nofuse -- python3 "$ROOT/bench.py" --workload c2 --steps 1 --no-cpu-baseline --shard-of 1 > /dev/null 2> "$OUT/pmc_c2nofuse_$c.err"
   done;;
 esac
+# ... and of C4 (trajectory launch in row form + jump-process launch)
+case " $WL " in *" c4 "*)
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_c4nofuse" -o c4nofuse -- python3 "$ROOT/bench.py" --workload c4 --steps 1 --no-cpu-baseline --shard-of 1 > "$OUT/bench_c4nofuse.json" 2> "$OUT/kt_c4nofuse.err"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_c4nofuse_$c" -o c4nofuse -- python3 "$ROOT/bench.py" --workload c4 --steps 1 --no-cpu-baseline --shard-of 1 > /dev/null 2> "$OUT/pmc_c4nofuse_$c.err"
+  done;;
+esac
 # keep what is small: drop raw per-dispatch traces over 8 MB
 find "$OUT" -name "*.csv" -size +8M -delete
 du -sh "$OUT"

@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAIN = {'c2': 'mjhmc_jump_kernel', 'c2nofuse': 'mjhmc_jump_kernel', 'c3': 'pot_jump_kernel', 'c3f64': 'pot64_jump_kernel',
-        'c4': 'mjhmc_step_kernel', 'c5': 'sic_jump_kernel', 'c5f32': 'sic_jump_kernel'}
+        'c4': 'mjhmc_fused_rows_kernel', 'c4nofuse': 'mjhmc_traj_rows_kernel', 'c5': 'sic_jump_kernel', 'c5f32': 'sic_jump_kernel'}
 OURS = ('mjhmc', 'pot_', 'pot64_', 'sic_', 'compact_list', 'cold_list')
 
 
@@ -54,7 +54,7 @@ def main():
     traffic_path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
     notes = []
-    for w in ('c2', 'c2nofuse', 'c3', 'c3f64', 'c4', 'c5', 'c5f32'):
+    for w in ('c2', 'c2nofuse', 'c3', 'c3f64', 'c4', 'c4nofuse', 'c5', 'c5f32'):
         ks = find(os.path.join(src, 'kt_' + w), 'kernel_stats.csv')
         if ks:
             shutil.copy(ks, os.path.join(dst, w + '_kernel_stats.csv'))
@@ -76,6 +76,15 @@ def main():
                 big = [v for k, vals in cs.items() if MAIN[w] in k and k.rstrip().endswith('true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)') for v in vals]
                 n_units = max(len(big), 1) / float(launches_per_iteration(p, 'true>(mjhmc::JumpArgs<double>, mjhmc::IsoGaussF<double> const)'))
                 per[c] = sum(big) / n_units            # a fused launch runs as several parts on as many streams
+            elif w == 'c4':
+                # fused launches in row form (since round 5), one queue; the bench's few one-iteration launches (trajectory +
+                # jump-process kernels) are other kernels
+                per[c] = sum(main) / float(len(main))
+            elif w == 'c4nofuse':
+                # `bench.py --workload c4 --steps 1`: one trajectory launch (row form) + one jump-process launch per iteration;
+                # the warm-up's fused call is another kernel
+                single = [v for k, vals in cs.items() if ('mjhmc_traj_rows_kernel' in k or 'mjhmc_step_kernel' in k) for v in vals]
+                per[c] = sum(single) / float(len(main))
             elif w == 'c2nofuse':
                 # `bench.py --workload c2 --steps 1`: the timed calls are single iterations (never fused); its warm-up is one
                 # fused call (three parts on three streams) -- only the one-iteration launches count here
@@ -83,8 +92,7 @@ def main():
                 single = [v for k, vals in cs.items() if MAIN[w] in k and not k.rstrip().endswith(fused_tag) for v in vals]
                 per[c] = sum(single) / max(len(single), 1)
             else:
-                # (C4 since round 5: an iteration is two dispatches of mjhmc_step_kernel -- trajectories, jump process -- on one queue)
-                n_units = len(main) / float(launches_per_iteration(p, MAIN[w]) * (2 if w == 'c4' else 1))
+                n_units = len(main) / float(launches_per_iteration(p, MAIN[w]))
                 per[c] = sum(ours) / n_units            # every kernel of an iteration, per iteration
             # keep a trimmed copy of the pass: our kernels only
             with open(p) as f, open(os.path.join(dst, '%s_pmc_%s.csv' % (w, c.lower())), 'w') as g:
@@ -98,11 +106,11 @@ def main():
                                      row['VGPR_Count'], row['Scratch_Size'], row['LDS_Block_Size']])
                         kept += 1
         if len(per) == 2:
-            key = {'c2nofuse': 'c2_one_iteration_per_launch'}.get(w, w)
+            key = {'c2nofuse': 'c2_one_iteration_per_launch', 'c4nofuse': 'c4_one_iteration_per_launch'}.get(w, w)
             total = per['FETCH_SIZE'] * 1024 * 2.0 + per['WRITE_SIZE'] * 1024
-            traffic[key] = {'bytes_per_launch': total, 'iterations_per_launch': 1, 'fused': w == 'c2',
+            traffic[key] = {'bytes_per_launch': total, 'iterations_per_launch': 1, 'fused': w in ('c2', 'c4'),
                             'FETCH_SIZE_KiB': per['FETCH_SIZE'], 'WRITE_SIZE_KiB': per['WRITE_SIZE'], 'read_correction': 2.0,
-                            'what': 'one fused launch (any number of fused iterations: the state crosses HBM once)' if w == 'c2'
+                            'what': 'one fused launch (any number of fused iterations: the state crosses HBM once)' if w in ('c2', 'c4')
                                     else 'all kernels of one sampling iteration',
                             'sources': ['%s/%s_pmc_fetch_size.csv' % (os.path.basename(dst), w),
                                         '%s/%s_pmc_write_size.csv' % (os.path.basename(dst), w)]}
@@ -115,7 +123,7 @@ def main():
                 for cname, per_k in counters(p).items():
                     vals = [v for k, vs in per_k.items() if MAIN[w] in k and (w != 'c2' or 'true>(' in k) for v in vs]
                     if vals:
-                        parts = launches_per_iteration(p, 'true>(' if w == 'c2' else MAIN[w]) * (2 if w == 'c4' else 1)
+                        parts = launches_per_iteration(p, 'true>(' if w == 'c2' else MAIN[w])
                         sq[cname] = (sum(vals) / (len(vals) / float(parts)), int(len(vals) / parts))
         if sq:
             with open(os.path.join(dst, '%s_pmc_sq.txt' % w), 'w') as g:
