@@ -17,8 +17,11 @@ from tests.helpers import check_iteration, resync
 pytestmark = pytest.mark.gpu
 
 
-def test_full_size_c4_funnel():
-    """configs[3]: Neal funnel, ndims=32, nparticles=1000000, L=15, float64 (whole batch on one GPU)."""
+@pytest.mark.parametrize('calls', ['one iteration per call', 'one call'])
+def test_full_size_c4_funnel(calls):
+    """configs[3]: Neal funnel, ndims=32, nparticles=1000000, L=15, float64 (whole batch on one GPU) -- as single-iteration
+    calls (a trajectory launch in row form + a jump-process launch each) and as ONE call (all iterations fused in one launch
+    of mjhmc_fused_rows_kernel, what bench.py times): the same checks, the same oracle."""
     from mjhmc_amd import engine, _lib
     w = bench.WORKLOADS['c4']
     D, N, L, eps, beta = w['D'], w['N'], w['L'], w['eps'], w['beta']
@@ -30,10 +33,15 @@ def test_full_size_c4_funnel():
     s.set_hparams(eps, L, p_r, 1.0)
     T = 3
     stats = []
-    for _ in range(T):                       # single launches: the compacted inverse-L pass runs at this size
-        st, done = s.iterate(1)
-        assert done == 1
-        stats += st
+    if calls == 'one call':
+        stats, done = s.iterate(T)
+        assert done == T
+        stats = list(stats[:T])
+    else:
+        for _ in range(T):                   # single launches: the list's walkers integrate the cold caches' inverse-L proposals
+            st, done = s.iterate(1)
+            assert done == 1
+            stats += st
     n_cold_expected = N
     for st in stats:
         assert st.l + st.f + st.r == N and st.nonfinite == 0

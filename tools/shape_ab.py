@@ -3,7 +3,7 @@ import os as _os
 _os.environ.setdefault('MJHMC_HIP_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mjhmc_amd', 'lib', 'libmjhmc_hip_test.so'))
 import os, sys
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from mjhmc_amd import engine, _lib
 ctx = engine.context(0)
 for kind, params, name in ((_lib.E_ISO_GAUSS, [1.0], 'iso'), (_lib.E_FUNNEL_NEAL, [3.0], 'funnel')):

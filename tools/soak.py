@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from mjhmc_amd import engine, _lib
 ctx = engine.context(0)
 D, N = 512, 100000
