@@ -2082,7 +2082,12 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
   __shared__ V tile[64 * 16];
   __shared__ unsigned tally[kMaxFuse][4];
   __shared__ int rtab[64];
-  if (a.ctl->failed) return;   // an earlier attempt of this batch was rolled back: do nothing
+  if (a.ctl->failed) {   // an earlier launch of this call met a non-finite rate and was rolled back: do nothing ...
+    // ... unless the failure belongs to THIS launch (another wave met it first): this wave must still run, report an
+    // earlier first failure of its own particles if it has one, and flush its tallies (the failed attempt's evaluations count)
+    const int first = 0x7fffffff - __hip_atomic_load(&a.ctl->inv_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first < a.iter) return;
+  }
   const RT rt{tile, FULL ? RC : a.CH, a.pitch, a.N};
   const int lane = threadIdx.x;
   const int n_it = a.n_fuse;

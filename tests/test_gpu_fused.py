@@ -84,17 +84,20 @@ def test_fused_equals_single_iterations(kind, D, N, mode_name, n_iter):
     _same_state(a, b, _lib)
 
 
-@pytest.mark.parametrize('D,N', [(512, 70), (24, 301)])
-def test_fused_failure_in_the_middle_of_a_launch(D, N):
+@pytest.mark.parametrize('kind,D,N', [('E_ISO_GAUSS', 512, 70), ('E_ISO_GAUSS', 24, 301),
+                                      ('E_FUNNEL_NEAL', 32, 300), ('E_FUNNEL_NEAL', 14, 200)])   # the funnels: the fused row kernel
+def test_fused_failure_in_the_middle_of_a_launch(kind, D, N):
     """A few columns blow up after some iterations: the fused call must stop exactly where the sequence of
     single iterations stops, with the same state, counters and RNG position."""
     from mjhmc_amd import _lib
+    params = [3.0] if kind == 'E_FUNNEL_NEAL' else [1.0]
+    lo = 0.02 if kind == 'E_FUNNEL_NEAL' else 0.6    # (the funnel is stiff where x0 is negative: it fails at far smaller scales)
     # Far out in the Gaussian the leapfrog energy error (~ eps^2 |x|^2 / 8) reaches several hundred, so now
     # and then exp(H0 - H1) overflows: scan the initial scale for a first failure after a few good iterations
     found = None
     s_thr = np.sqrt(709.0 / (0.011 * D))     # scale at which the MEAN energy error of the L proposal overflows exp
-    for scale in np.linspace(0.6, 1.0, 161) * s_thr:
-        (p, _), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale))
+    for scale in np.linspace(lo, 1.0, 161) * s_thr:
+        (p, _), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, scale=float(scale))
         p.set_hparams(0.5, 5, 0.1, 1.0, 0.5)
         k = 0
         while k < 30:
@@ -109,7 +112,7 @@ def test_fused_failure_in_the_middle_of_a_launch(D, N):
         pytest.skip('no initial scale with a late first failure for this shape')
     scale, k = found
     eps = 0.5
-    (a, b), _lib = _pair('E_ISO_GAUSS', D, N, _lib.MODE_MJHMC, params=[1.0], scale=float(scale))
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, scale=float(scale))
     for s in (a, b):
         s.set_hparams(eps, 5, 0.1, 1.0, 0.5)
         s.ring_alloc(40)
