@@ -123,4 +123,56 @@ print('check_isa %s: %s' % (sys.argv[2], 'FAILED: %d kernel(s)' % bad if bad els
 sys.exit(1 if bad else 0)
 PY
 done
+# The row-form kernels of the funnels (elementwise.hpp): what their design promises --
+#   mjhmc_fused_rows_kernel: no scratch memory at all; the leapfrog-step loops are straight vector code (<= 150 instructions for
+#   the 32-coordinate row, nothing from memory);
+#   mjhmc_traj_rows_kernel (full rows): step loops the same; between the first row store and the end of the forward path no
+#   wait that drains the loads/stores counter (a vmcnt(0) there is a wait for the previous store's round trip to memory).
+[ -n "${SKIP_COMPILE:-}" ] || $HIPCC $FLAGS --cuda-device-only -S energy_funnel.hip -o /tmp/mjhmc_energy_funnel.s 2> /dev/null || { echo "compile of energy_funnel failed"; exit 2; }
+python3 - /tmp/mjhmc_energy_funnel.s <<'PY' || RC=1
+import re, sys
+txt = open(sys.argv[1]).read()
+bad = 0
+meta = {}
+for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)', txt, flags=re.S):
+    body = m.group(2)
+    g = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, body).group(1)) if re.search(r'\.%s:\s+(\d+)' % k, body) else None
+    meta[m.group(1)] = dict(vgpr=g('vgpr_count'), scratch=g('private_segment_fixed_size'), vgpr_spill=int(m.group(3)))
+for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel', txt, flags=re.S | re.M):
+    if 'rows_kernel' not in name or 'IdEE' not in name:
+        continue
+    lines = body.split('\n')
+    pos = {}
+    for k, l in enumerate(lines):
+        mm = re.match(r'^(\.LBB\w+):', l)
+        if mm:
+            pos[mm.group(1)] = k
+    instr = lambda l: bool(re.match(r'^\s+[a-z]', l)) and not l.strip().startswith(';')
+    steps = []                                   # innermost loops made of float64 multiply-adds: the leapfrog steps
+    for k, l in enumerate(lines):
+        mm = re.search(r's_cbranch_scc1\s+(\.LBB\w+)', l)
+        if mm and pos.get(mm.group(1), 1 << 30) < k:
+            seg = [x.strip() for x in lines[pos[mm.group(1)]:k + 1] if instr(x)]
+            if sum(x.startswith(('v_fma_f64', 'v_fmac_f64')) for x in seg) >= 40 and len(seg) < 400:
+                steps.append(seg)
+    n_mem = sum(sum(x.startswith(('scratch_', 'global_', 'buffer_', 'ds_', 'flat_')) for x in seg) for seg in steps)
+    longest = max([len(seg) for seg in steps] or [0])
+    m = meta.get(name, {})
+    fused = 'fused_rows' in name
+    full4 = 'Li8ELi2ELb1E' in name
+    drains = None
+    if not fused and 'Lb1E' in name:             # full rows: the forward path's stores
+        first = next((k for k, l in enumerate(lines) if 'global_store_dwordx4' in l), None)
+        end = next((k for k in range(first or 0, len(lines)) if 's_endpgm' in lines[k] or 's_branch' in lines[k]), len(lines))
+        drains = sum(bool(re.search(r's_waitcnt[^\n]*vmcnt\(0\)', l)) for l in lines[first:end]) if first is not None else None
+    tag = ''
+    if (not steps or n_mem or (full4 and longest > 150) or (fused and m.get('scratch')) or (drains not in (None, 0))):
+        bad += 1
+        tag = '   <-- VIOLATION'
+    print('%-92s vgpr %3s spilled %3s scratch %4s B | step loops %d (longest %d instructions, memory operations %d)%s%s'
+          % (name[9:101], m.get('vgpr'), m.get('vgpr_spill'), m.get('scratch'), len(steps), longest, n_mem,
+             '' if drains is None else ' | vmcnt(0) after the first row store: %d' % drains, tag))
+print('check_isa energy_funnel (row form): %s' % ('FAILED: %d kernel(s)' % bad if bad else 'ok'))
+sys.exit(1 if bad else 0)
+PY
 exit $RC
