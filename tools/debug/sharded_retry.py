@@ -1,3 +1,5 @@
+"""Repro of the late-workgroup tally race: two ranks share the GPU, rank 1 fails, E_count of the sharded run
+against the unsharded one, four times.  usage: python tools/debug/sharded_retry.py <rank> <port>   (both ranks, same port)"""
 import io, contextlib, sys, os
 import numpy as np
 import torch.distributed as dist
