@@ -286,7 +286,8 @@ def _sampler_for(what, seed=11):
                 self.Xinit = X0
         d = Fixed(ndims=D, nbatch=N, sigma=1.2)
         kw = dict(epsilon=0.2, num_leapfrog_steps=5)
-    elif what == 'funnel_compacted':        # several particles per wave, big batch: trajectory + jump-process launches
+    elif what == 'funnel_compacted':        # a funnel, big batch: the fused row kernel (two-lane groups, short rows) writes the ring
+                                            # (until the row form: a trajectory + a jump-process launch per iteration)
         D, N = 10, 170000
         X0 = rs.randn(D, N)
 
