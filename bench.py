@@ -578,12 +578,16 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
             roof['hbm_algorithmic'] = hbm
             if w['kind'] == 'funnel':
                 # a wave of 64 particles integrates the inverse-L trajectory in all its lanes whenever ONE of its caches is
-                # cold: what the pipe executes, beside what the chain needs (`achieved`)
+                # cold: what the pipe executes, beside what the chain needs
                 waves_inv = 1.0 - (1.0 - cold_frac) ** 64
                 ex_flops = (1.0 + waves_inv) * (fl_step * w['L'] + 6.0) * w['D'] * n_rank
-                roof['executed'] = {'achieved': ex_flops / (kern_it_ms * 1e-3) / 1e12, 'unit': 'TFLOP/s',
-                                    'frac': ex_flops / (kern_it_ms * 1e-3) / 1e12 / valu_peak,
-                                    'waves_integrating_inverse_L': waves_inv}
+                # as for the dense workloads the line's `achieved` is what the device RAN; `needed` = what the chain needs
+                roof['needed'] = {'achieved': roof['achieved'], 'unit': 'TFLOP/s', 'frac': roof['frac'],
+                                  'algorithmic_flops_per_launch': roof['algorithmic_flops_per_launch']}
+                roof['achieved'] = ex_flops / (kern_it_ms * 1e-3) / 1e12
+                roof['frac'] = roof['achieved'] / valu_peak
+                roof['executed_flops_per_launch'] = ex_flops * it_per_launch
+                roof['waves_integrating_inverse_L'] = waves_inv
             if unfused_ms:
                 roof['one_iteration_per_launch'] = {
                     'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,
