@@ -2254,10 +2254,19 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
   }
 }
 
+// particles per workgroup of the jump-process launch = 256 x kDecideSub.  A workgroup ends with FOUR global atomics on
+// addresses every workgroup of the launch uses -- its movers' place in the next iteration's list (returning), the l / f / r
+// tallies -- and same-address atomics are served one after another, ~12 ns each (tools/microbench/atomic_one_address.hip:
+// 3 906 workgroups, one counter + three tallies: 55 us per launch; 977 workgroups: 14 us): with 256 particles per
+// workgroup they, not the jump process, were most of C4's 0.074 ms launch.  Measured for C4 (10^6 particles), 1 / 2 / 4 / 8
+// sub-blocks per workgroup: 74 / 56 / 60 / 65 us (without R-movers 73 / 48 / 46 / 50: more particles per workgroup also
+// means their sub-blocks one after the other, and more movers for its lane groups).
+constexpr int kDecideSub = 2;
+
 template <typename T, int E>
 struct DecideShared {
   typename VecOf<T>::type stash[4][E / VecOf<T>::n][64];
-  int movers[256];       // this workgroup's movers: particle of the workgroup << 2 | move
+  int movers[256 * kDecideSub];   // this workgroup's movers: particle of the workgroup << 2 | move
   int n_f, n_r, list_base;
   unsigned tally[3];
   int any_bad;
@@ -2280,8 +2289,10 @@ __device__ __forceinline__ void decide_block(const JumpDecideArgs<T>& a, DecideS
   if (threadIdx.x < 3) tally[threadIdx.x] = 0;
   __syncthreads();
   // ---- the jump process, one lane per particle ------------------------------------------------------------------------
-  {
-    const int64_t p_raw = (int64_t)vblock * 256 + threadIdx.x;
+#pragma unroll 1
+  for (int sb = 0; sb < kDecideSub; ++sb) {
+    const int in_wg = sb * 256 + (int)threadIdx.x;
+    const int64_t p_raw = (int64_t)vblock * (256 * kDecideSub) + in_wg;
     const bool alive = p_raw < a.N;
     const int64_t p = alive ? p_raw : a.N - 1;
     const T EX0 = a.EX_in[p], EV0 = a.EV_in[p];
@@ -2329,13 +2340,13 @@ __device__ __forceinline__ void decide_block(const JumpDecideArgs<T>& a, DecideS
       int at = 0;
       if (lane == 0) at = atomicAdd(&n_r, (int)__popcll(b2));
       at = __shfl(at, 0);
-      if (alive && k == 2) movers[at + (int)__popcll(b2 & below)] = ((int)threadIdx.x << 2) | 2;
+      if (alive && k == 2) movers[at + (int)__popcll(b2 & below)] = (in_wg << 2) | 2;
     }
     if (b1) {
       int at = 0;
       if (lane == 0) at = atomicAdd(&n_f, (int)__popcll(b1));
       at = __shfl(at, 0);
-      if (alive && k == 1) movers[255 - (at + (int)__popcll(b1 & below))] = ((int)threadIdx.x << 2) | 1;
+      if (alive && k == 1) movers[256 * kDecideSub - 1 - (at + (int)__popcll(b1 & below))] = (in_wg << 2) | 1;
     }
   }
   __syncthreads();
@@ -2350,9 +2361,9 @@ __device__ __forceinline__ void decide_block(const JumpDecideArgs<T>& a, DecideS
   }
   if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
   __syncthreads();
-  auto mover = [&](int i) { return movers[i < nr ? i : 255 - (i - nr)]; };
+  auto mover = [&](int i) { return movers[i < nr ? i : 256 * kDecideSub - 1 - (i - nr)]; };
   // every move but L clears the cache (markov_jump_hmc.py:409-410): the movers are the next iteration's list
-  for (int i = threadIdx.x; i < nm; i += 256) a.next_list[list_base + i] = (int)((int64_t)vblock * 256 + (mover(i) >> 2));
+  for (int i = threadIdx.x; i < nm; i += 256) a.next_list[list_base + i] = (int)((int64_t)vblock * (256 * kDecideSub) + (mover(i) >> 2));
   // ---- the movers' successor states, a lane group per mover ------------------------------------------------------------
   const int G = 1 << a.logG;
   LaneMap m;
@@ -2367,7 +2378,7 @@ __device__ __forceinline__ void decide_block(const JumpDecideArgs<T>& a, DecideS
     const int idx = first + (threadIdx.x >> a.logG);
     const bool live = idx < nm;
     const int code = mover(live ? idx : 0);
-    const int64_t p = (int64_t)vblock * 256 + (code >> 2);
+    const int64_t p = (int64_t)vblock * (256 * kDecideSub) + (code >> 2);
     const int k = code & 3;
     if (__ballot(live) == 0ull) continue;   // (a wave without a mover has nothing to do)
     T x[E], v[E];
@@ -2635,7 +2646,7 @@ inline void launch_jump_t(const JumpArgs<T>& a, const En& en, hipStream_t st) {
   }
 }
 
-// trajectories: one workgroup per 256 >> logG particles + the list's walkers in front; jump process: one per 256 particles
+// trajectories: one workgroup per 256 >> logG particles + the list's walkers in front; jump process: one per 256 x kDecideSub particles
 template <class En, typename T, int E>
 inline void launch_step_t(const TrajArgs<T>* ta, const JumpDecideArgs<T>* da, const En& en, hipStream_t st) {
   int n_traj = 0, n_decide = 0;
@@ -2643,7 +2654,7 @@ inline void launch_step_t(const TrajArgs<T>* ta, const JumpDecideArgs<T>* da, co
     const int64_t ppb = 256 >> ta->logG;
     n_traj = (int)((ta->N + ppb - 1) / ppb) + ta->inv_blocks;
   }
-  if (da) n_decide = (int)((da->N + 255) / 256);
+  if (da) n_decide = (int)((da->N + 256 * kDecideSub - 1) / (256 * kDecideSub));
   if constexpr (HasRowForm<En>::value && sizeof(T) == 8 && E == 8) {
     if (ta && !da && ta->rows && (ta->logG == 1 || ta->logG == 2)) {   // a lane per particle, a wavefront per workgroup
       const int64_t fwd = (ta->N + 63) / 64;

@@ -1,5 +1,5 @@
 """C4 (Neal funnel 32 x N, L 15, float64): a few compacted iterations, for profiler runs.
-usage: python tools/c4_iter.py [N] [iterations] [L]      (test build when MJHMC_HIP_LIB names it: MJHMC_NO_ROWS, MJHMC_FUSE_BELOW)"""
+usage: python tools/c4_iter.py [N] [iterations] [L] [beta]      (test build when MJHMC_HIP_LIB names it: MJHMC_NO_ROWS, MJHMC_FUSE_BELOW)"""
 import os
 import sys
 
@@ -11,6 +11,7 @@ from mjhmc_amd import engine, _lib          # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 it = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+beta = float(sys.argv[4]) if len(sys.argv) > 4 else 0.1      # the refresh rate p_r = -log(1 - beta) / 2
 ctx = engine.context(0)
 rng = np.random.RandomState(0)
 X0 = rng.randn(32, N)
@@ -18,7 +19,7 @@ X0[0] *= 3.0
 X0[1:] *= np.exp(X0[0] / 2.)
 en = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, 32, [3.0])
 smp = engine.DeviceSampler(en, X0, seed=1)
-smp.set_hparams(0.05, L, -np.log(0.9) * 0.5, 1.0)
+smp.set_hparams(0.05, L, -np.log(1.0 - beta) * 0.5, 1.0)
 for _ in range(3):
     smp.iterate(it)
     smp.sync()
