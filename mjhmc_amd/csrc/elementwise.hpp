@@ -2064,14 +2064,17 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
 // particle.  Per iteration a wave runs the inverse-L trajectory (whenever one of its 64 caches is cold: nearly always),
 // the L trajectory, the jump process (decide() in its one-lane form, as the jump-process launch of the compacted path)
 // and the successor selection; HBM sees the state once per launch (+ the ring snapshots when samples are recorded).
-// With ~125 vector instructions per leapfrog step and 64 particles this is bound by the vector pipe at about half the
-// time the two launches of the compacted path need for their bytes (C4).
+// With ~129 vector instructions per leapfrog step and 64 particles this is bound by the vector pipe at 0.7 of the time the
+// two launches of the compacted path need for their bytes (C4: 0.19 against 0.27 ms per iteration).
+// (Every wave pays the inverse-L trajectory for its few cold lanes.  Letting each lane run at its OWN iteration -- rounds of
+// one trajectory: warm lanes take their L proposal and move on, cold lanes their inverse-L proposal -- removes that, was
+// written twice, is bit-identical, and is slower: a round then also pays the jump process.  DESIGN.md section 8c.)
 //
 // The momentum refresh of the wave's R-movers (a few per iteration) is spread over all lanes: the movers' rows go into
 // the tile, every lane redraws one CHUNK of one mover -- normal_pair(key, particle, chunk) and the two products and the
 // sum of refresh_stash, the same bits -- and the movers read their rows back.
-// One wavefront per SIMD (x, v, their pre-move copies and the inverse-L trajectory's working state: ~400 registers),
-// persistent: a wave strides over the tiles and adds its tallies up in LDS.
+// One wavefront per SIMD (x, v and their pre-move copies: 390 registers, the copies in the accumulation half), persistent:
+// a wave strides over the tiles and adds its tallies up in LDS.
 // ------------------------------------------------------------------------------------------
 template <class En, typename T, int E, int LOGG, bool FULL>
 __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<T> a, const En en) {
