@@ -1611,8 +1611,10 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   return 0;
 }
 
-// batches of the non-Gaussian elementwise energies below this many particles run fused (tools/sweep_shard_c4.py: the funnel at
-// 125 000 particles 0.047 ms per iteration fused, 0.051 as trajectory + jump-process launches; at 250 000 0.094 against 0.082)
+// batches of the non-Gaussian elementwise energies below this many particles run fused (measured on the funnel with a group
+// of lanes per particle, tools/sweep_shard_c4.py `fused_groups` / `groups`: at 125 000 particles 0.047 ms per iteration fused,
+// 0.051 as trajectory + jump-process launches; at 250 000 0.094 against 0.082).  The funnels themselves no longer come here:
+// their float64 rows of 9 ... 32 dims fuse in row form at every size (fused_rows).
 constexpr int64_t kFuseBelow = 160000;
 
 template <typename T>
