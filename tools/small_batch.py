@@ -31,3 +31,20 @@ for kind, params, name in ((_lib.E_ISO_GAUSS, [1.0], 'iso'), (_lib.E_FUNNEL_NEAL
             out.append(smp.last_timing()['total_ms'] / 1024 * 1e3)
         print('%-6s D=%3d N=%5d  default %.1f us/iter (device %.1f)   one launch per iteration %.1f us/iter (device %.1f)' % (name, D, N, out[0], out[1], out[2], out[3]), flush=True)
         smp.close()
+
+# single-iteration CALLS (what a loop of sampling_iteration() makes): call overhead included
+print('-- one mjhmc_iterate call per iteration (wall clock per call) --')
+for kind, params, name in ((_lib.E_ISO_GAUSS, [1.0], 'iso'), (_lib.E_FUNNEL_NEAL, [3.0], 'funnel')):
+    for D, N in ((2, 100), (2, 1000), (10, 1000), (32, 10000)):
+        X0 = np.random.RandomState(0).randn(D, N)
+        smp = engine.DeviceSampler(engine.DeviceEnergy(ctx, kind, D, params), X0, seed=1)
+        smp.set_hparams(0.05, 10, 0.05, 1.0, 0.5)
+        os.environ.pop('MJHMC_NO_FUSE', None)
+        for _ in range(200):
+            smp.iterate(1)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            smp.iterate(1)
+        smp.sync()
+        print('%-6s D=%3d N=%5d  %.1f us per call' % (name, D, N, (time.perf_counter() - t0) / 2000 * 1e6), flush=True)
+        smp.close()
