@@ -554,6 +554,9 @@ struct DlSession {
   int64_t n_total = 0, k0 = 0;
   std::atomic<int> downloaded{0};            // slots [0, downloaded) are in the host array
   std::vector<char> retiled;                 // [iteration] its slot already sits, in the host layout, in staging slot i (see dl_retile_in_stream)
+  std::atomic<bool> cancel{false};           // dl_restart: the worker leaves at its next look
+  std::atomic<bool> exited{false};           // the worker has left: nothing of the session is touched from its thread any more
+  bool off = false;                          // after dl_restart: the launch code marks nothing, the caller downloads when the call is over
   int rc = 0;
   std::string err;
 };
@@ -579,7 +582,7 @@ static int dl_retile(mjhmc_sampler* s, const void* rows0, int64_t start, int64_t
 // called by the launch code once the kernels completing iterations [i0, i0 + n) of the call are queued
 static int dl_mark(mjhmc_sampler* s, int i0, int n, const hipStream_t* streams, int n_streams) {
   DlSession* d = s->dl;
-  if (!d || i0 < d->marked.load(std::memory_order_acquire)) return 0;   // (a re-run after a failure rewrites marked slots with the same values)
+  if (!d || d->off || i0 < d->marked.load(std::memory_order_acquire)) return 0;   // (a re-run after a failure rewrites marked slots with the same values)
   for (int i = i0; i < i0 + n && i < d->n_iter; ++i) {
     for (int k = 0; k < n_streams; ++k) {
       hipEvent_t e = nullptr;
@@ -639,15 +642,17 @@ static int dl_download_slot(mjhmc_sampler* s, DlSession* d, int i) {
   return 0;
 }
 
-static void dl_worker(mjhmc_sampler* s, DlSession* d) {
+static void dl_worker_body(mjhmc_sampler* s, DlSession* d) {
   if (hipSetDevice(s->ctx->device) != hipSuccess) {
     d->rc = MJHMC_ERR_HIP;
     d->err = "hipSetDevice failed in the download thread";
     return;
   }
   for (int i = 0; i < d->n_iter; ++i) {
-    while (d->marked.load(std::memory_order_acquire) <= i && !d->launched.load(std::memory_order_acquire))
+    while (d->marked.load(std::memory_order_acquire) <= i && !d->launched.load(std::memory_order_acquire) &&
+           !d->cancel.load(std::memory_order_acquire))
       std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (d->cancel.load(std::memory_order_acquire)) return;
     if (d->marked.load(std::memory_order_acquire) <= i) break;   // a path that marks nothing: the caller downloads afterwards
     for (hipEvent_t e : d->ev[(size_t)i])
       if (hipStreamWaitEvent(s->dl_stream, e, 0) != hipSuccess) {
@@ -661,8 +666,46 @@ static void dl_worker(mjhmc_sampler* s, DlSession* d) {
       d->err = g_err;   // (thread-local: hand the message to the calling thread)
       return;
     }
+    if (d->cancel.load(std::memory_order_acquire)) return;   // (the slot it has just brought over is about to be rewritten)
     d->downloaded.store(i + 1, std::memory_order_release);
   }
+}
+
+static void dl_worker(mjhmc_sampler* s, DlSession* d) {
+  dl_worker_body(s, d);
+  d->exited.store(true, std::memory_order_release);
+}
+
+// the events of a session, each destroyed once (the iterations of a fused launch share theirs)
+static void dl_destroy_events(DlSession* d) {
+  for (size_t i = 0; i < d->ev.size(); ++i)
+    for (hipEvent_t e : d->ev[i]) {
+      bool first = true;
+      for (size_t j = 0; j < i && first; ++j)
+        for (hipEvent_t f : d->ev[j]) first = first && f != e;
+      if (first) (void)hipEventDestroy(e);
+    }
+  for (auto& v : d->ev) v.clear();
+}
+
+// A call that is about to be run AGAIN from its first iteration (iterate_t: a non-finite rate while the parts of a dense
+// batch ran freely -- the state is put back and the call re-run on one stream) while samples are being downloaded: what
+// the first run marked is void.  A lagging part returned early in the failing iteration and left its columns of the
+// ring slots and of the staging slots stale, and the re-run rewrites every slot: the worker must neither have copied nor
+// copy any of them.  The worker is told to leave and waited for, its stream drained, the session emptied and switched
+// off -- the re-run marks nothing, and mjhmc_iterate_download brings slots [0, done) over when the call has returned.
+static int dl_restart(mjhmc_sampler* s) {
+  DlSession* d = s->dl;
+  if (!d) return 0;
+  d->cancel.store(true, std::memory_order_release);
+  while (!d->exited.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  if (s->dl_stream) HIPCHK(hipStreamSynchronize(s->dl_stream));
+  dl_destroy_events(d);
+  d->marked.store(0, std::memory_order_release);
+  d->downloaded.store(0, std::memory_order_release);
+  std::fill(d->retiled.begin(), d->retiled.end(), 0);
+  d->off = true;
+  return 0;
 }
 
 template <typename T>
@@ -2044,7 +2087,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     // leave, so every slot crossed PCIe one iteration late and two of them after the run had ended.  The worker then only
     // moves bytes (copy engine + host).
     auto dl_done = [&](int j, const void* xj) -> int {
-      if (!(s->dl && ring_slot0 >= 0 && j >= s->dl->marked.load(std::memory_order_acquire))) return 0;
+      if (!(s->dl && !s->dl->off && ring_slot0 >= 0 && j >= s->dl->marked.load(std::memory_order_acquire))) return 0;
       hipStream_t sts[kMaxDenseParts];
       const size_t elems = (size_t)s->D * s->N;
       const bool room = s->dl_stage_elems >= (size_t)s->dl->n_iter * elems;
@@ -2070,6 +2113,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     // was never split (nothing of this attempt has been committed: parities, Xcur and the tick are still the call's)
     TRY(split_state_copy(s, true));
     HIPCHK(hipStreamSynchronize(s->stream));
+    TRY(dl_restart(s));   // (mjhmc_iterate_download: nothing the first run handed to the download survives it)
     return iterate_t<T>(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done, false);
   }
 
@@ -2216,13 +2260,7 @@ int mjhmc_iterate_download(mjhmc_sampler* s, int n_iter, int ring_slot0, double*
     HIPCHK(hipStreamSynchronize(s->dl_stream));
     for (int i = d.downloaded.load(); i < done && !rc2; ++i) rc2 = dl_download_slot(s, &d, i);
   }
-  for (size_t i = 0; i < d.ev.size(); ++i)      // (the iterations of a fused launch share their events: destroy each once)
-    for (hipEvent_t e : d.ev[i]) {
-      bool first = true;
-      for (size_t j = 0; j < i && first; ++j)
-        for (hipEvent_t f : d.ev[j]) first = first && f != e;
-      if (first) (void)hipEventDestroy(e);
-    }
+  dl_destroy_events(&d);
   if (n_done) *n_done = done;
   return rc ? rc : rc2;
 }

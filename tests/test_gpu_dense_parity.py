@@ -725,6 +725,55 @@ def test_split_launches_failure_in_the_middle_of_a_call(what, poison, monkeypatc
         s.close()
 
 
+@pytest.mark.parametrize('what,poison', [('pot36', '3:19000'), ('pot36', '5:7'), ('pot36f64', '4:19000'), ('sic_p1', '4:300')])
+def test_streamed_download_when_a_split_call_fails_in_the_middle(what, poison, monkeypatch):
+    """mjhmc_iterate_download while the two halves of a dense batch run freely and one of them meets a non-finite rate:
+    the call is put back and re-run on one stream (api.hip: iterate_t), and NOTHING the first run handed to the download
+    thread may survive -- a lagging half left its columns of the slots stale (dl_restart).  The host array of the
+    streamed call must hold, for the iterations that completed, exactly what a never-split call records in its ring."""
+    from mjhmc_amd import engine, _lib
+    ctx = hooks_context(0)
+    if what in ('pot36', 'pot36f64'):
+        D, N, dtype = 36, 20000, 'float64' if what == 'pot36f64' else 'float32'
+        W, lognu = ref_init_weights(D, D)
+        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)]))
+        X0 = np.random.RandomState(3).randn(D, N)
+        hp = (0.1, 6, 0.1)
+    else:
+        D, N, dtype = 1024, 17000, 'bfloat16'
+        B, imgs, a0 = sic_problem(0)
+        en = engine.DeviceEnergy(ctx, _lib.E_SPARSE_CODE, 1024,
+                                 np.concatenate([[1.0, 256.0, 1024.0, 0.01, 1.0], B.ravel(), imgs[:, :1].T.ravel()]))
+        X0 = a0[:, None] + 0.2 * np.random.RandomState(4).randn(1024, N)
+        hp = (0.0625, 3, 0.1)
+    it, n = int(poison.split(':')[0]), 8
+    pair = [engine.DeviceSampler(en, X0, seed=8, dtype=dtype) for _ in range(2)]
+    for s in pair:
+        s.set_hparams(hp[0], hp[1], hp[2], 1.0)
+        s.ring_alloc(n)
+    monkeypatch.setenv('MJHMC_DEBUG_POISON', poison)
+    monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+    out = np.full((D, n * N), -7.0)
+    st_a, done_a = pair[0].iterate_download(n, 0, out)
+    monkeypatch.setenv('MJHMC_NO_SPLIT', '1')
+    st_b, done_b = pair[1].iterate(n, ring_slot0=0)
+    monkeypatch.delenv('MJHMC_NO_SPLIT', raising=False)
+    monkeypatch.delenv('MJHMC_DEBUG_POISON', raising=False)
+    assert done_a == done_b == it
+    assert [(t.l, t.f, t.r, t.n_cold) for t in st_a[:it]] == [(t.l, t.f, t.r, t.n_cold) for t in st_b[:it]]
+    want = pair[1].ring_read(0, it)
+    got = out[:, :it * N]
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError(('streamed slots differ from the recorded ring', len(bad), 'time slots', sorted(set((bad[:, 1] // N).tolist())),
+                              'particles', sorted(set((bad[:, 1] % N).tolist()))[:8]))
+    assert np.array_equal(pair[0].ring_read(0, it), want)          # and the device ring of the streamed call itself
+    for f in ('X', 'V', 'EX', 'EV', 'HFLF'):
+        assert np.array_equal(pair[0].read(getattr(_lib, 'F_' + f)), pair[1].read(getattr(_lib, 'F_' + f)), equal_nan=True), f
+    for s in pair:
+        s.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # the REPLAY instances of the tile kernels (recorded random numbers fed from the host, the mode the golden replays of
 # the elementwise energies run in): every draw is the caller's, so device and oracle can be compared decision by decision
