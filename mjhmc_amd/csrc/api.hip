@@ -47,7 +47,8 @@ static const char* test_env(const char*) { return nullptr; }
 
 static int ab_flags() {
   return (test_env("MJHMC_NO_BLOCK_DECIDE") ? kAbNoBlockDecide : 0) | (test_env("MJHMC_NO_WPP") ? kAbNoWpp : 0) |
-         (test_env("MJHMC_NO_QUAD") ? kAbNoQuad : 0) | (test_env("MJHMC_NO_ROWS") ? kAbNoRows : 0);
+         (test_env("MJHMC_NO_QUAD") ? kAbNoQuad : 0) | (test_env("MJHMC_NO_ROWS") ? kAbNoRows : 0) |
+         (test_env("MJHMC_NO_RELAY") ? kAbNoRelay : 0);
 }
 
 static int ilog2(int v) {

@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "philox.hpp"
+#include "timing_variants.hpp"
 
 #ifndef MJHMC_NT
 #define MJHMC_NT 1  // streaming (nontemporal) row loads/stores: +1-2 % on C2, state rows are touched once per launch
@@ -424,6 +425,31 @@ __device__ __forceinline__ Ctx funnel_prep_rows(const T (&x)[G][E]) {
   return c;
 }
 
+// ... and on HALF a row: the two lanes of a pair hold x[j] for j in [h G/2, (h + 1) G/2), h = 0 (even lane), 1 (odd lane)
+// -- the relay of mjhmc_fused_rows_relay_kernel integrates a pooled particle on two lanes.  The partial sums are formed as
+// funnel_prep_rows forms them; a pair's sums meet as (p0 + p1) + (p2 + p3) in the even lane and (p2 + p3) + (p0 + p1) in
+// the odd one (G = 2: p0 + p1 / p1 + p0) -- the same bits, a floating-point sum does not depend on the order of its TWO terms.
+template <class Ctx, typename T, int E, int G>
+__device__ __forceinline__ Ctx funnel_prep_pair(const T (&xh)[G / 2][E], int h) {
+  constexpr int GH = G / 2;
+  static_assert(G == 2 || G == 4, "a row in two halves");
+  T part[GH];
+#pragma unroll
+  for (int jj = 0; jj < GH; ++jj) {
+    T s = xh[jj][0] * xh[jj][0];
+    if (jj == 0) s = (h == 0) ? T(0) : s;   // (dim 0 is not part of the sum)
+#pragma unroll
+    for (int e = 1; e < E; ++e) s = __builtin_fma(xh[jj][e], xh[jj][e], s);
+    part[jj] = s;
+  }
+  const T mine = (GH == 1) ? part[0] : part[0] + part[GH - 1];
+  Ctx c;
+  c.S = mine + dpp_mov<0xB1>(mine);          // quad_perm [1, 0, 3, 2]: the pair's other lane
+  c.x0 = dpp_mov<0xA0>(xh[0][0]);            // quad_perm [0, 0, 2, 2]: the even lane's x[0][0]
+  c.ex = exp_neg(c.x0);
+  return c;
+}
+
 // Neal's funnel, x0 ~ N(0, s^2), x_k ~ N(0, e^{x0}) (tf_distributions.py:143-147):
 // E = x0^2/(2 s^2) + e^{-x0} sum_k x_k^2 / 2 + (D-1) x0 / 2
 template <typename T>
@@ -483,6 +509,10 @@ struct FunnelNealF {
   __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E]) const {
     return funnel_prep_rows<Ctx, T, E, G>(x);
   }
+  template <int E, int G>
+  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h) const {
+    return funnel_prep_pair<Ctx, T, E, G>(xh, h);
+  }
 };
 
 // Funnel exactly as coded (tf_distributions.py:157-165): E = -(D-1) x0^2/s^2 - e^{-x0} sum_k x_k^2
@@ -538,6 +568,10 @@ struct FunnelRefF {
   __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E]) const {
     return funnel_prep_rows<Ctx, T, E, G>(x);
   }
+  template <int E, int G>
+  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h) const {
+    return funnel_prep_pair<Ctx, T, E, G>(xh, h);
+  }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -545,7 +579,7 @@ struct FunnelRefF {
 // ------------------------------------------------------------------------------------------
 
 // launch_jump_t's A/B flags (JumpArgs::ab): take the generic instance instead of a specialised lane mapping
-constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4, kAbNoRows = 8;
+constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4, kAbNoRows = 8, kAbNoRelay = 16;
 
 template <typename T>
 struct JumpArgs {
@@ -1788,10 +1822,14 @@ __device__ __forceinline__ constexpr int row_dim(int j, int e) {   // dim_of for
   return ((e / 2) * G + j) * 2 + (e % 2);
 }
 
+// leapfrog steps [s0, s1) of a trajectory of L steps, a row at a time (trajectory<.., EXACT = false>); the opening half kick
+// belongs to the FIRST part.  Parts that cover [0, L) in order are the whole trajectory, operation for operation: the relay
+// of the fused row kernel integrates a trajectory in four parts, on four waves.
 template <class En, typename T, int E, int G>
-__device__ __forceinline__ void trajectory_rows(const En& en, T (&x)[G][E], T (&v)[G][E], int L, T eps, T chalf) {
-  if (L <= 0) return;   // trajectory<.., EXACT = false>, a row at a time
-  {
+__device__ __forceinline__ void trajectory_rows_part(const En& en, T (&x)[G][E], T (&v)[G][E], bool first, int s0, int s1, int L,
+                                                     T eps, T chalf) {
+  if (L <= 0) return;
+  if (first) {
     const auto ctx = en.template prep_rows<E, G>(x);
 #pragma unroll
     for (int j = 0; j < G; ++j)
@@ -1799,7 +1837,7 @@ __device__ __forceinline__ void trajectory_rows(const En& en, T (&x)[G][E], T (&
       for (int e = 0; e < E; ++e) v[j][e] = en.template kick<E>(chalf, x[j][e], v[j][e], e, row_dim<G>(j, e), ctx);
   }
   const T cfull = chalf + chalf;
-  for (int s = 0; s < L; ++s) {
+  for (int s = s0; s < s1; ++s) {
 #pragma unroll
     for (int j = 0; j < G; ++j)
 #pragma unroll
@@ -1811,6 +1849,56 @@ __device__ __forceinline__ void trajectory_rows(const En& en, T (&x)[G][E], T (&
 #pragma unroll
       for (int e = 0; e < E; ++e) v[j][e] = en.template kick<E>(c, x[j][e], v[j][e], e, row_dim<G>(j, e), ctx);
   }
+}
+
+template <class En, typename T, int E, int G>
+__device__ __forceinline__ void trajectory_rows(const En& en, T (&x)[G][E], T (&v)[G][E], int L, T eps, T chalf) {
+  trajectory_rows_part<En, T, E, G>(en, x, v, true, 0, L, L, eps, chalf);
+}
+
+// the same part of the same trajectory with the row on TWO lanes: lane h of a pair holds x[h G/2 + jj] as xh[jj]
+// (prep_rows_pair: the pair's sums are the row's, bit for bit; everything else is per coordinate)
+template <class En, typename T, int E, int G>
+__device__ __forceinline__ void trajectory_pair_part(const En& en, T (&xh)[G / 2][E], T (&vh)[G / 2][E], int h, bool first, int s0,
+                                                     int s1, int L, T eps, T chalf) {
+  constexpr int GH = G / 2;
+  if (L <= 0) return;
+  if (first) {
+    const auto ctx = en.template prep_rows_pair<E, G>(xh, h);
+#pragma unroll
+    for (int jj = 0; jj < GH; ++jj)
+#pragma unroll
+      for (int e = 0; e < E; ++e) vh[jj][e] = en.template kick<E>(chalf, xh[jj][e], vh[jj][e], e, row_dim<G>(h * GH + jj, e), ctx);
+  }
+  const T cfull = chalf + chalf;
+  for (int s = s0; s < s1; ++s) {
+#pragma unroll
+    for (int jj = 0; jj < GH; ++jj)
+#pragma unroll
+      for (int e = 0; e < E; ++e) xh[jj][e] = __builtin_fma(eps, vh[jj][e], xh[jj][e]);
+    const auto ctx = en.template prep_rows_pair<E, G>(xh, h);
+    const T c = (s == L - 1) ? chalf : cfull;
+#pragma unroll
+    for (int jj = 0; jj < GH; ++jj)
+#pragma unroll
+      for (int e = 0; e < E; ++e) vh[jj][e] = en.template kick<E>(c, xh[jj][e], vh[jj][e], e, row_dim<G>(h * GH + jj, e), ctx);
+  }
+}
+
+// kinetic_rows() of a row on two lanes (valid in both lanes of the pair)
+template <typename T, int E, int G>
+__device__ __forceinline__ T kinetic_pair(const T (&vh)[G / 2][E]) {
+  constexpr int GH = G / 2;
+  T part[GH];
+#pragma unroll
+  for (int jj = 0; jj < GH; ++jj) {
+    T s = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s = __builtin_fma(vh[jj][e], vh[jj][e], s);
+    part[jj] = s;
+  }
+  const T mine = (GH == 1) ? part[0] : part[0] + part[GH - 1];
+  return (mine + dpp_mov<0xB1>(mine)) / T(2);
 }
 
 template <typename T, int E, int G>
@@ -1857,7 +1945,7 @@ struct RowTile {
   // and 2 x 16 global addresses across the trajectory loop in scratch memory -- and each reload in the store phase is a
   // vmcnt(0) wait, i.e. it waits for the previous STORE to reach memory (16 round trips per matrix).
   static __device__ __forceinline__ int fresh_lane() {
-    int l = threadIdx.x;
+    int l = threadIdx.x & 63;   // (the relay kernel's workgroups have four waves)
     asm volatile("" : "+v"(l));
     return l;
   }
@@ -2257,6 +2345,379 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The fused row kernel with the inverse-L trajectories of a WORKGROUP's cold caches pooled and relayed (round 6).
+//
+// mjhmc_fused_rows_kernel integrates the inverse-L proposal in all 64 lanes of a wave whenever one of its caches is cold --
+// at C4's 7 % movers that is 99 % of the wave-iterations, 1.86 trajectories executed per trajectory the chain needs.  Here a
+// workgroup is four such waves (one per SIMD, 256 particles).  Who is cold in iteration t + 1 is known when iteration t has
+// decided (every move but L clears the cache, markov_jump_hmc.py:404-410): those lanes put their (x, v) rows into an LDS pool
+// (a row per pool lane, lane-linear), ~18 of 256 at C4.  The pool's trajectories -- ONE wave's worth of work for the four
+// waves -- are integrated in four parts, one part per wave: wave p runs leapfrog steps [p L / 4, (p + 1) L / 4) of the pool
+// between parts p - 1 and p of its OWN L trajectory, takes the pool's state from LDS where wave p - 1 left it and leaves it
+// there for wave p + 1; the last part ends with the energies, H(F L F z) per pool lane, which the cold lanes pick up after
+// their own L trajectory, in front of decide().  Every wave then issues 1.25 trajectories per iteration and none waits:
+//
+//     wave 0:  [pool 0][own 0][own 1][own 2][own 3]        the pool's parts follow each other on four SIMDs while every
+//     wave 1:  [own 0][pool 1][own 1][own 2][own 3]        wave's own trajectory goes on beside them; hand-overs are LDS
+//     wave 2:  [own 0][own 1][pool 2][own 2][own 3]        flags a wave polls (no s_barrier: a barrier per part would make
+//     wave 3:  [own 0][own 1][own 2][pool 3][own 3]        everybody wait for the wave that has the pool)
+//
+// The same device functions on the same inputs in the same order (trajectory_rows_part: parts that cover [0, L) ARE the
+// trajectory), so the bits are those of mjhmc_fused_rows_kernel and of the single-iteration kernels (tests/test_gpu_fused.py,
+// tools/fuzz_rows.py).  A pooled particle takes TWO lanes of the relaying wave (half a row each: trajectory_pair_part), which
+// makes a part of the pool's trajectory shorter than the part of the wave's own it stands beside -- the next wave never
+// waits for it -- and leaves the wave's own state where it is (64 registers of pool state instead of 128: a first form with
+// a lane per pooled particle moved 256 registers in and out of the accumulation half per part and measured 0.231 ms against
+// the one-wave kernel's 0.210; its four hand-overs, each ~2 500 cycles, stood one after the other).  More than 32 cold caches
+// in a workgroup (a chain's first iteration, a high refresh rate): the lanes beyond the pool integrate in their own wave as before.
+// Order of LDS traffic between waves: a wave's LDS operations execute in order; a writer waits for its data (lgkmcnt(0))
+// before it raises the flag, a reader's data reads are issued after the flag's value has come back.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_wait_ge(const int* flag, int target) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+// the relay's flag: parts of the pool's trajectory done so far (low word) and, riding along, the pool's row count (high
+// word) -- the next wave gets both with the one LDS read it polls with
+__device__ __forceinline__ int lds_wait_seg(const unsigned long long* flag, int target) {
+  unsigned long long f;
+  while ((int)(unsigned)(f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+  return (int)(f >> 32);
+}
+__device__ __forceinline__ void lds_seg_set(unsigned long long* flag, int done, int rows) {   // (one lane)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __hip_atomic_store(flag, (unsigned long long)(unsigned)done | ((unsigned long long)(unsigned)rows << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+constexpr int kRelayWaves = 4;
+constexpr int kPoolRows = 32;   // pooled particles per workgroup and iteration: two lanes each
+
+template <class En, typename T, int E, int LOGG, bool FULL>
+__global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_kernel(const JumpArgs<T> a, const En en) {
+  using RT = RowTile<T, E, LOGG, FULL>;
+  using Stage = typename RT::Stage;
+  using V = typename RT::V;
+  constexpr int G = RT::G, GH = G / 2, RC = RT::RC, W = kRelayWaves, PR = kPoolRows;
+  __shared__ V tiles[W][64 * 16];
+  __shared__ V pool[2 * RC * PR];      // chunk c of pool row r at [c * PR + r]: the x chunks, then the v chunks
+  __shared__ T pool_H[PR];
+  __shared__ unsigned long long relay_flag;   // lds_wait_seg / lds_seg_set
+  __shared__ unsigned long long tally[kMaxFuse][2];   // per iteration (#L | #F << 32), (#R | #cold << 32)
+  __shared__ int pool_n[2];            // rows asked for, by parity of the epoch
+  __shared__ int arrived, go;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) {
+    int g = 1;
+    if (a.ctl->failed) {   // as mjhmc_fused_rows_kernel; decided once for the workgroup (its waves must agree)
+      const int first = 0x7fffffff - __hip_atomic_load(&a.ctl->inv_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (first < a.iter) g = 0;
+    }
+    go = g;
+    arrived = 0;
+    relay_flag = 0ull;
+    pool_n[0] = 0;
+    pool_n[1] = 0;
+  }
+  for (int i = threadIdx.x; i < kMaxFuse * 2; i += 64 * W) (&tally[0][0])[i] = 0ull;
+  __syncthreads();
+  if (!go) return;
+  V* const tile = tiles[wave];
+  const RT rt{tile, FULL ? RC : a.CH, a.pitch, a.N};
+  const int n_it = a.n_fuse;
+  int first_bad = 0x7fffffff;
+  LaneMap m1;   // decide() with the three clocks in one lane
+  m1.j = 0;
+  m1.G = 1;
+  m1.D = 1;
+  m1.CH = 1;
+  m1.lane0 = 0;
+  m1.wpp = 0;
+  const int L = a.L;
+  // where a wave's own trajectory stops for its part of the pool's.  Part p of the pool's trajectory (L / 4 steps on two
+  // lanes per particle + the hand-over through LDS: ~0.19 L + 1.7 own steps' worth of time, tools/rows_stamps.py) can start
+  // when part p - 1 is done: wave p turns to it after own_stop(p) steps of its own, when that is about to be the case --
+  // standing at L p / 4 it waited ~1 700 cycles per iteration at C4
+  auto own_stop = [&](int p) { return p >= W ? L : min(L, (p * (19 * L + 170) + 50) / 100); };
+  int epoch = 0;   // (tile, iteration) pairs this workgroup has started: the same sequence in its four waves
+  [[maybe_unused]] bool stamp_on = false;   // (timing build only: ROWS_STAMP)
+  [[maybe_unused]] int stamp_it = 0;
+  // A wave's rows asked of the pool, in three steps that leave their LDS round trips behind other work: pool_alloc (the rows'
+  // numbers: one returning atomic per wave, issued when decide() is through), pool_write (the rows, when the movers have
+  // their new momenta; returns the lane's pool row -- >= PR: the pool is full, the lane integrates in its wave) and
+  // pool_arrive (at the top of the next iteration, behind its register copies).
+  unsigned long long dep_mask = 0ull;
+  int dep_base = 0;
+  auto pool_alloc = [&](bool cold, int par) {
+    dep_mask = __ballot(cold);
+    dep_base = 0;
+    if (dep_mask != 0ull && lane == __ffsll((long long)dep_mask) - 1) dep_base = atomicAdd(&pool_n[par], (int)__popcll(dep_mask));
+  };
+  auto pool_write = [&](bool cold, const T (&x)[G][E], const T (&v)[G][E]) -> int {
+    int sl = -1;
+    if (dep_mask != 0ull) {
+      const int b = __builtin_amdgcn_readlane(dep_base, __ffsll((long long)dep_mask) - 1);
+      if (cold) {
+        sl = b + (int)__popcll(dep_mask & ((1ull << lane) - 1ull));
+        if (sl < PR) {
+#pragma unroll
+          for (int c = 0; c < RC; ++c) {
+            pool[c * PR + sl] = V{x[c % G][(c / G) * 2], x[c % G][(c / G) * 2 + 1]};
+            pool[(RC + c) * PR + sl] = V{v[c % G][(c / G) * 2], v[c % G][(c / G) * 2 + 1]};
+          }
+        }
+      }
+    }
+    return sl;
+  };
+  auto pool_arrive = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(&arrived, 1);
+  };
+  // part `ph` of the pool's inverse-L trajectories F L F (only H() of them is ever read: markov_jump_hmc.py:360,367), a
+  // pooled particle on the lanes 2 r, 2 r + 1: ~115 vector instructions per leapfrog step instead of the ~155 of a whole row
+  // per lane, and 64 registers of state beside the wave's own -- nothing of the wave's has to be moved out of the way
+  auto relay = [&](int ph) {
+    ROWS_STAMP(2);
+    const int par = epoch & 1;
+    int n;
+    if (ph == 0) {
+      lds_wait_ge(&arrived, W * (epoch + 1));
+      n = min(__hip_atomic_load(&pool_n[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), PR);
+      if (lane == 0) pool_n[par ^ 1] = 0;   // the next epoch's requests start when this epoch's energies are out
+    } else {
+      n = lds_wait_seg(&relay_flag, W * epoch + ph);
+    }
+    n = __builtin_amdgcn_readfirstlane(n);
+    ROWS_STAMP(3);
+    if (n > 0) {
+      T px[GH][E], pv[GH][E];
+      const int l = RT::fresh_lane();
+      const int h = l & 1, r = min(l >> 1, n - 1);   // (the lanes beyond the pool repeat its last row; they store nothing)
+      const bool mine = (l >> 1) < n;
+      const V* src = pool + h * GH * PR + r;
+#pragma unroll
+      for (int k = 0; k < E / 2; ++k)
+#pragma unroll
+        for (int jj = 0; jj < GH; ++jj) {
+          const V qx = src[(k * G + jj) * PR], qv = src[(RC + k * G + jj) * PR];
+          px[jj][2 * k] = qx.x;
+          px[jj][2 * k + 1] = qx.y;
+          pv[jj][2 * k] = (ph == 0) ? -qv.x : qv.x;
+          pv[jj][2 * k + 1] = (ph == 0) ? -qv.y : qv.y;
+        }
+      trajectory_pair_part<En, T, E, G>(en, px, pv, h, ph == 0, ph * L / W, (ph + 1) * L / W, L, a.eps, a.chalf);
+      if (ph == W - 1) {
+        const T ev = kinetic_pair<T, E, G>(pv);
+        const T ex = en.energy_of(en.template prep_rows_pair<E, G>(px, h));
+        if (mine && h == 0) pool_H[r] = ex + ev;
+      } else if (mine) {
+        V* dst = pool + h * GH * PR + r;
+#pragma unroll
+        for (int k = 0; k < E / 2; ++k)
+#pragma unroll
+          for (int jj = 0; jj < GH; ++jj) {
+            dst[(k * G + jj) * PR] = V{px[jj][2 * k], px[jj][2 * k + 1]};
+            dst[(RC + k * G + jj) * PR] = V{pv[jj][2 * k], pv[jj][2 * k + 1]};
+          }
+      }
+    }
+    if (lane == 0) lds_seg_set(&relay_flag, W * epoch + ph + 1, n);
+    ROWS_STAMP(4);
+  };
+  const int64_t n_wtiles = a.Npad >> 6, n_gtiles = (n_wtiles + W - 1) / W;
+#pragma unroll 1
+  for (int64_t gt = blockIdx.x; gt < n_gtiles; gt += gridDim.x) {
+    const int64_t wt = gt * W + wave;
+    const bool wave_live = wt < n_wtiles;   // (the batch's last workgroup tile may hold fewer than four wave tiles: the
+                                            // others walk through the protocol with nothing alive)
+    const int64_t base = wt * 64, p = base + lane;
+    const bool alive = wave_live && p < a.N;
+    const int64_t pc = alive ? p : a.N - 1;   // padding rows: somebody's scalars, nothing of theirs is stored
+    T x[G][E], v[G][E];
+    if (wave_live) {
+      Stage tx, tv;
+      rt.fetch(a.X_in, base, tx);
+      rt.fetch(a.V_in, base, tv);
+      rt.to_rows(tx, x);
+      rt.to_rows(tv, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          x[j][e] = T(0);
+          v[j][e] = T(0);
+        }
+    }
+    T EX0 = a.EX_in[pc], EV0 = a.EV_in[pc], Hcached = a.Hflf_in[pc];
+    const uint32_t pid = (uint32_t)(a.first_pid + p);
+    RngKey key = a.key;
+    int k = 0;
+    double dwell = 0.0;
+    T EXn = EX0, EVn = EV0, Hc = Hcached;
+    pool_alloc(alive && !(Hcached == Hcached), epoch & 1);
+    int slot = pool_write(alive && !(Hcached == Hcached), x, v);
+#pragma unroll 1
+    for (int it = 0; it < n_it; ++it) {
+      stamp_on = gt == (int64_t)blockIdx.x;
+      stamp_it = it;
+      ROWS_STAMP(0);
+      T x0[G][E], v0[G][E];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          x0[j][e] = x[j][e];
+          v0[j][e] = v[j][e];
+        }
+      pool_arrive();   // (this iteration's cold rows were written before the copies above)
+      const bool warm = Hcached == Hcached;   // cache_active (hmc_state.py:43-44) is carried as "H_flf is not NaN"
+      const T H0 = EX0 + EV0;                 // HMCState.H (hmc_state.py:80-84)
+      const bool pooled = !warm && slot >= 0 && slot < PR;
+      const bool in_wave = !warm && alive && !pooled;
+      T Hflf = Hcached;
+      if (__ballot(in_wave) != 0ull) {   // the pool was full: as mjhmc_fused_rows_kernel
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[j][e] = -v[j][e];
+        trajectory_rows<En, T, E, G>(en, x, v, L, a.eps, a.chalf);
+        const T ev = kinetic_rows<T, E, G>(v);
+        const T ex = en.energy_of(en.template prep_rows<E, G>(x));
+        if (in_wave) Hflf = ex + ev;
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            x[j][e] = x0[j][e];
+            v[j][e] = v0[j][e];
+          }
+      }
+      ROWS_STAMP(1);
+      // forward proposal L in four parts, this wave's part of the pool's trajectories between two of them
+#pragma unroll 1
+      for (int ph = 0; ph < W; ++ph) {
+        if (wave == ph) relay(ph);
+        trajectory_rows_part<En, T, E, G>(en, x, v, ph == 0, own_stop(ph), own_stop(ph + 1), L, a.eps, a.chalf);
+      }
+      ROWS_STAMP(5);
+      const T EVL = kinetic_rows<T, E, G>(v);
+      const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
+      const T HL = EXL + EVL;
+      ROWS_STAMP(6);
+      (void)lds_wait_seg(&relay_flag, W * (epoch + 1));
+      if (pooled) Hflf = pool_H[slot];
+      ROWS_STAMP(7);
+      bool bad = false;
+      decide<T, false>(a, key, m1, H0, HL, Hflf, pc, pid, k, dwell, bad);
+      ROWS_STAMP(8);
+      // successor state (markov_jump_hmc.py:399-410)
+      const bool isL = k == 0, isF = k == 1, isR = k == 2;
+      const bool more = it + 1 < n_it;
+      if (more) pool_alloc(alive && !isL, (epoch + 1) & 1);   // the next iteration's cold caches: every move but L
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          x[j][e] = isL ? x[j][e] : x0[j][e];
+          v[j][e] = isL ? v[j][e] : (isF ? -v0[j][e] : v0[j][e]);
+        }
+      EXn = isL ? EXL : EX0;
+      EVn = isL ? EVL : EV0;
+      Hc = isL ? H0 : (T)__builtin_nan("");   // L: the pre-move state becomes the cached inverse-L state; F, R: clear_flf_cache
+      const unsigned long long bR = __ballot(isR && alive);
+      ROWS_STAMP(9);
+      if (bR != 0ull) {   // HMCState.R (hmc_state.py:121-129) of the wave's R-movers, a chunk per lane
+        const int nR = (int)__popcll(bR);
+        if (isR && alive) rt.write_own(v);
+        wave_lds_fence();
+        const int l = RT::fresh_lane();
+        constexpr int RPI = 64 / RC;       // movers per pass: lanes [g RC, (g + 1) RC) redraw the pass's g-th mover
+        const int c = l % RC, g_l = l / RC;
+        unsigned long long left = bR;      // (wave-uniform: the movers' lanes are picked off the ballot on the scalar unit)
+        for (int q0 = 0; q0 < nR; q0 += RPI) {
+          int r = 0;
+#pragma unroll
+          for (int g = 0; g < RPI; ++g) {
+            const int rg = __ffsll((long long)left) - 1;
+            left &= left - 1ull;
+            r = (g_l == g) ? rg : r;
+          }
+          if (q0 + g_l < nR && (FULL || c < rt.CH)) {
+            const int sl = r * 16 + (c ^ (r & 15));
+            const V vc = tile[sl];
+            const int d = c * 2;
+            double z0, z1;
+            normal_pair(key, (uint32_t)(a.first_pid + base + r), (uint32_t)c, z0, z1);
+            const T zy = (d + 1 < a.D) ? (T)z1 : T(0);
+            V res;
+            res.x = vc.x * a.r_keep + (T)z0 * a.r_mix;
+            res.y = vc.y * a.r_keep + zy * a.r_mix;
+            tile[sl] = res;
+          }
+        }
+        wave_lds_fence();
+        if (isR && alive) {
+          rt.read_own(v);
+          EVn = kinetic_rows<T, E, G>(v);
+        }
+        wave_lds_fence();
+      }
+      ROWS_STAMP(10);
+      // bookkeeping of iteration `it`; the successor state becomes the next iteration's pre-move state
+      if (bad && alive) first_bad = min(first_bad, it);
+      const unsigned long long b0 = __ballot(alive && isL), b1 = __ballot(alive && isF), b3 = __ballot(alive && !warm);
+      if (lane == 0) {
+        atomicAdd(&tally[it][0], (unsigned long long)__popcll(b0) | ((unsigned long long)__popcll(b1) << 32));
+        atomicAdd(&tally[it][1], (unsigned long long)__popcll(bR) | ((unsigned long long)__popcll(b3) << 32));
+      }
+      if (a.xiter && wave_live) {  // sample ring: X and the dwelling times after every iteration
+        Stage tx;
+        rt.from_rows(x, tx);
+        rt.store(a.xiter + (size_t)it * a.xiter_stride, base, tx);
+        a.dwell_ring[(size_t)it * a.Npad + p] = dwell;
+      }
+      EX0 = EXn;
+      EV0 = EVn;
+      Hcached = Hc;
+      key.tick_hi += (key.tick_lo == 0xFFFFFFFFu) ? 1u : 0u;
+      key.tick_lo += 1u;
+      ++epoch;
+      ROWS_STAMP(11);
+      if (more) slot = pool_write(alive && !isL, x, v);
+      ROWS_STAMP(12);
+    }  // fused iterations
+    if (wave_live) {
+      Stage tx, tv;
+      if (!a.xiter) rt.from_rows(x, tx);
+      rt.from_rows(v, tv);
+      if (!a.xiter) rt.store(a.X_out, base, tx);
+      rt.store(a.V_out, base, tv);
+    }
+    if (alive) {
+      a.EX_out[p] = EXn;
+      a.EV_out[p] = EVn;
+      a.Hflf_out[p] = Hc;
+      a.dwell[p] = dwell;
+      a.trans[p] = (uint8_t)k;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, o));
+  if (first_bad != 0x7fffffff && lane == 0) {
+    a.ctl->failed = 1;
+    atomicMax(&a.ctl->inv_iter, 0x7fffffff - (a.iter + first_bad));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_it * 4; i += 64 * W) {
+    const unsigned t = (unsigned)(tally[i >> 2][(i >> 1) & 1] >> (32 * (i & 1)));
+    if (t) atomicAdd(&a.stats[i], (unsigned long long)t);
+  }
+}
+
 // particles per workgroup of the jump-process launch = 256 x kDecideSub.  A workgroup ends with FOUR global atomics on
 // addresses every workgroup of the launch uses -- its movers' place in the next iteration's list (returning), the l / f / r
 // tallies -- and same-address atomics are served one after another, ~12 ns each (tools/microbench/atomic_one_address.hip:
@@ -2587,18 +3048,28 @@ inline void launch_jump_r(const JumpArgs<T>& a, const En& en, hipStream_t st) {
 inline bool fused_rows_shape(int mode, int logG, int ab) {
   return mode == kModeMJHMC && (logG == 1 || logG == 2) && !(ab & kAbNoRows);
 }
-// persistent: as many one-wave workgroups as the device keeps resident (one per SIMD), never more than there are tiles
+// persistent: as many one-wave workgroups as the device keeps resident (one per SIMD), never more than there are tiles.
+// The product's form is the relay kernel (four-wave workgroups, one per CU, the workgroup's cold caches pooled); the
+// one-wave form stays as the test build's A/B partner (kAbNoRelay) -- the two must agree bit for bit.
 template <class En, typename T, int E, int LOGG, bool FULL>
 inline void launch_fused_rows(const JumpArgs<T>& a, const En& en, hipStream_t st) {
-  static int resident_blocks = 0;
+  static int resident_blocks = 0, resident_relay = 0;
   if (resident_blocks == 0) {
-    int dev = 0, per_cu = 0, cus = 0;
+    int dev = 0, per_cu = 0, per_cu_relay = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mjhmc_fused_rows_kernel<En, T, E, LOGG, FULL>, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_relay, mjhmc_fused_rows_relay_kernel<En, T, E, LOGG, FULL>,
+                                                       64 * kRelayWaves, 0);
     resident_blocks = std::max(1, per_cu) * std::max(1, cus);
+    resident_relay = std::max(1, per_cu_relay) * std::max(1, cus);
   }
   const int64_t tiles = a.Npad >> 6;
+  if (!(a.ab & kAbNoRelay)) {
+    const unsigned grid = (unsigned)std::min<int64_t>((tiles + kRelayWaves - 1) / kRelayWaves, resident_relay);
+    hipLaunchKernelGGL((mjhmc_fused_rows_relay_kernel<En, T, E, LOGG, FULL>), dim3(grid), dim3(64 * kRelayWaves), 0, st, a, en);
+    return;
+  }
   const unsigned grid = (unsigned)std::min<int64_t>(tiles, resident_blocks);
   hipLaunchKernelGGL((mjhmc_fused_rows_kernel<En, T, E, LOGG, FULL>), dim3(grid), dim3(64), 0, st, a, en);
 }

@@ -17,3 +17,10 @@ static inline FunnelRefF<float> make_fr32(const EnergyParams& ep) {
 MJHMC_DEFINE_ENERGY_LAUNCHERS(funnel_neal, make_fn64, make_fn32)
 MJHMC_DEFINE_ENERGY_LAUNCHERS(funnel_ref, make_fr64, make_fr32)
 }  // namespace mjhmc
+
+#ifdef ROWS_STAMPS
+// timing build (tools/rows_stamps.sh): the cycle stamps of timing_variants.hpp
+extern "C" int mjhmc_rows_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mjhmc::g_rows_stamp), sizeof(mjhmc::g_rows_stamp));
+}
+#endif

@@ -36,3 +36,18 @@ static __device__ unsigned g_sic_stamp[4][8][8];
 #else
 #define SIC_STAMP(RD, I) do { } while (0)
 #endif
+
+// -DROWS_STAMPS (tools/rows_stamps.sh): cycle stamps of workgroup 0's four waves at the phase boundaries of the relay kernel's
+// sampling iterations (elementwise.hpp: mjhmc_fused_rows_relay_kernel), first workgroup tile only, [wave][iteration][point].
+// Twelve stamps per ~25 000-cycle iteration; tools/rows_stamps.py reads them (mjhmc_rows_stamps in energy_funnel.hip).
+#ifdef ROWS_STAMPS
+namespace mjhmc {
+static __device__ unsigned long long g_rows_stamp[4][64][16];
+}
+#define ROWS_STAMP(I)                                                                                                    \
+  do {                                                                                                                   \
+    if (blockIdx.x == 0 && stamp_on && (threadIdx.x & 63) == 0) g_rows_stamp[threadIdx.x >> 6][stamp_it & 63][I] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define ROWS_STAMP(I) do { } while (0)
+#endif
