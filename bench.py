@@ -62,15 +62,20 @@ WORKLOADS = {
     'c4': dict(name='C4 Neal funnel ndims=32 nparticles=1000000 L=15 fp64', kind='funnel', D=32, N=1000000,
                L=15, eps=0.05, beta=0.1, dtype='float64', params=[3.0]),
     # BASELINE.json configs[4]: all 200000 particles fit one GPU; synthetic dictionary (the reference's
-    # distr_data/dump_1024.pkl is not in its checkout)
-    'c5': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25 bf16 state / fp32 accumulate',
-               kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1, dtype='bfloat16', params=None),
-    # the same workload with the state rows kept as the reference keeps them (TensorFlow float32, tf_distributions.py:89); the
-    # matrix-core operands are bf16 either way.  With bf16 STATE the MarkovJumpHMC chain does not keep the law (it runs
-    # hot: tests/test_gpu_stationary.py::test_sic_stationary_law); with float32 state it does
-    'c5f32': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25, float32 state (the reference\'s) / bf16 '
-                       'matrix-core operands / fp32 accumulate', kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1,
-                  dtype='float32', params=None),
+    # distr_data/dump_1024.pkl is not in its checkout).  The C5 OF RECORD keeps the state rows as the reference keeps them
+    # (TensorFlow float32 placeholders, tf_distributions.py:89) with bf16 matrix-core operands and fp32 accumulation: under
+    # MarkovJumpHMC this form keeps the target law (tests/test_gpu_stationary.py::test_sic_stationary_law, within the 1-3 %
+    # the bf16 OPERANDS leave in the temperature) -- it is the class's default state_dtype
+    'c5': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25, float32 state (the reference\'s) / bf16 '
+                    'matrix-core operands / fp32 accumulate', kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1,
+               dtype='float32', params=None),
+    # BASELINE.json's wording of configs[4], "bf16 state / fp32 accumulate": parity-green against the oracle with the same
+    # rounding, and statistically HOT under MarkovJumpHMC -- rounding the state at every commit makes L irreversible and the
+    # jump process balances its rates on H(FLF(Lz)) = H(z) (test_sic_stationary_law asserts the drift).  Kept
+    # as a labelled variant (`c5bf16_law` = "hot" in the line); same kernel, 2 % less time (HBM is at 0.28 TB/s either way)
+    'c5bf16': dict(name='C5 SparseImageCode n_coeffs=1024 img=256 nparticles=200000 L=25 bf16 state / fp32 accumulate '
+                        '(BASELINE.json\'s wording; the MarkovJumpHMC chain runs hot in this form)',
+                   kind='sic', D=1024, N=200000, L=25, eps=0.05, beta=0.1, dtype='bfloat16', params=None),
     # BASELINE.json configs[0] (README shape; plumbing)
     'c1': dict(name='C1 README isotropic Gaussian ndims=2 nparticles=100 L=5', kind='iso', D=2, N=100, L=5,
                eps=0.1, beta=0.1, dtype='float64', params=[1.0]),
@@ -444,49 +449,66 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
         unfused_ms = t_sum / 32
     # The C-ABI boundary hands over HOST buffers in the reference's (ndims, nparticles) layout; the device keeps rows
     # per particle.  What that costs (re-tile kernel + PCIe, pageable host memory), outside `value`: a state read,
-    # and a batch of 10 stacked samples = 10 iterations into the device ring + one download of the ring.
+    # and a batch of stacked samples = n iterations into the device ring + the download of the ring (sample()'s own form:
+    # every slot crosses PCIe while the following iterations run, mjhmc_iterate_download).  n = 10 where ten float64 host
+    # copies of the state stay under ~4.4 GB, fewer for the bigger states (C5: 1.6 GB per sample).
     boundary = None
-    if world == 1 and key == rig.head and scaling == 'weak' and shard_of == 1:
+    want_boundary = world == 1 and scaling == 'weak' and shard_of == 1 and key in (rig.head, 'c2', 'c4', 'c5')
+    if want_boundary:
         esz = {'float64': 8, 'float32': 4, 'bfloat16': 2}[w['dtype']]
-        t_b = time.perf_counter()
-        Xh = smp.read(_lib.F_X)
-        t_read = time.perf_counter() - t_b
-        nbytes_host = Xh.nbytes
-        del Xh
-        n_s = 10
+        host_bytes = 8 * int(w['D']) * n_rank
+        n_s = int(max(2, min(10, 4.4e9 // host_bytes)))
         smp.ring_alloc(n_s)
+        ring = np.empty((w['D'], n_s * n_rank))
+        ring[:] = 0.0                                              # (pages faulted in before anything is timed)
         t_b = time.perf_counter()
         smp.iterate(n_s, ring_slot0=0)
         smp.sync()
         t_it = time.perf_counter() - t_b
-        t_b = time.perf_counter()
-        ring = smp.ring_read(0, n_s, stacked=False)                # into a fresh array: its pages are faulted in on the way
-        t_dl = time.perf_counter() - t_b
-        t_b = time.perf_counter()
-        smp.ring_read(0, n_s, stacked=False, out=ring)             # sample(..., out=preallocated)
-        t_dl2 = time.perf_counter() - t_b
-        # what sample() does: every slot crosses PCIe while the following iterations run (mjhmc_iterate_download)
         smp.iterate_download(n_s, 0, ring)                         # (first call: staging, pinned buffers, stream, thread)
         t_b = time.perf_counter()
         smp.iterate_download(n_s, 0, ring)
         t_str = time.perf_counter() - t_b
-        t_b = time.perf_counter()
-        Xh = smp.read(_lib.F_X)
-        smp.read(_lib.F_X, out=Xh)
-        t_read2 = (time.perf_counter() - t_b) / 2
-        del Xh
         psteps = float(w['D']) * n_rank * w['L'] * n_s
-        boundary = {'state_read_ms': t_read * 1e3, 'state_read_GBps': nbytes_host / t_read / 1e9,
-                    'state_bytes_device': int(w['D']) * n_rank * esz, 'state_bytes_host_f64': int(nbytes_host),
-                    'state_read_warm_GBps': nbytes_host / t_read2 / 1e9,
-                    'sample10': {'iterate_ms': t_it * 1e3, 'download_ms': t_dl * 1e3, 'host_bytes': int(ring.nbytes),
-                                 'download_GBps': ring.nbytes / t_dl / 1e9,
-                                 'download_into_preallocated_GBps': ring.nbytes / t_dl2 / 1e9,
-                                 'iterate_then_download_particle_steps_per_s': psteps / (t_it + t_dl2),
-                                 'streamed_ms': t_str * 1e3,
-                                 'particle_steps_per_s_incl_download': psteps / t_str,
-                                 'incl_download_over_resident': t_it / t_str}}
+        boundary = {'samples': n_s, 'host_bytes': int(ring.nbytes), 'iterate_ms': t_it * 1e3, 'streamed_ms': t_str * 1e3,
+                    'particle_steps_per_s_incl_download': psteps / t_str, 'incl_download_over_resident': t_it / t_str,
+                    'state_bytes_device': int(w['D']) * n_rank * esz}
+        if key == rig.head:
+            t_b = time.perf_counter()
+            Xh = smp.read(_lib.F_X)
+            t_read = time.perf_counter() - t_b
+            t_b = time.perf_counter()
+            smp.read(_lib.F_X, out=Xh)
+            t_read2 = time.perf_counter() - t_b
+            t_b = time.perf_counter()
+            smp.ring_read(0, n_s, stacked=False, out=ring)         # sample(..., out=preallocated) of a recorded ring
+            t_dl2 = time.perf_counter() - t_b
+            boundary.update({'state_read_GBps': Xh.nbytes / t_read / 1e9, 'state_read_warm_GBps': Xh.nbytes / t_read2 / 1e9,
+                             'download_into_preallocated_GBps': ring.nbytes / t_dl2 / 1e9,
+                             'iterate_then_download_particle_steps_per_s': psteps / (t_it + t_dl2)})
+            del Xh
         del ring
+    # ... and the consumer that needs no download: the reference's main caller records samples to autocorrelate them
+    # (misc/autocor.py:213-261 generate_samples, :37-49 fft_autocor).  T iterations recorded into the device ring
+    # (sample(n, preserve_order=True)'s form) + the lag sums over the ring on the device (mjhmc_ring_autocor): the samples
+    # never leave HBM; particle-steps/s over BOTH.
+    acor = None
+    if world == 1 and scaling == 'weak' and shard_of == 1 and key in ('c2', 'c4'):
+        T_ac = 16
+        smp.ring_alloc(T_ac)
+        smp.iterate(T_ac, ring_slot0=0)
+        smp.ring_autocor(0, T_ac)                                  # (first call: plans, work buffers)
+        smp.sync()
+        t_b = time.perf_counter()
+        smp.iterate(T_ac, ring_slot0=0)
+        smp.sync()
+        t_rec = time.perf_counter() - t_b
+        t_b = time.perf_counter()
+        lag = smp.ring_autocor(0, T_ac)
+        t_ac = time.perf_counter() - t_b
+        acor = {'samples': T_ac, 'record_ms': t_rec * 1e3, 'autocor_ms': t_ac * 1e3, 'ring_bytes': int(w['D']) * n_rank * T_ac * 8,
+                'particle_steps_per_s_incl_autocor': float(w['D']) * n_rank * w['L'] * T_ac / (t_rec + t_ac),
+                'finite': bool(np.isfinite(lag).all())}
     smp.close()
     if rank != 0:
         return None
@@ -500,43 +522,48 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
     full_shape = shard_of == 1 and not (scaling == 'strong' and world > 1)   # the PMC passes were taken on the single-GPU shapes
     # What every field below means (kernels, byte and flop models, why each bound) is DESIGN.md section 7 ("the line's
     # fields"); the line itself carries numbers only, so that it stays under the 8 kB the driver keeps.
+    # ONE definition of `frac` for every workload: the flops (or bytes) the CHAIN NEEDS / time / peak.  Beside it
+    # `executed` (what the device ran: more than needed where lanes integrate trajectories nobody reads, less where a
+    # term is not evaluated separately) and, for the dense energies, `counted` (the reference's evaluation count).
     if w['kind'] in ('pot', 'sic'):
         # dense energy: the bound is the matrix pipe (fp32 for ProductOfT, bf16 for SparseImageCode).
-        # Algorithmic flops from the exact counters: dEdX_evals * 4*D*K + E_evals * 2*D*K
         DK = float(w['D']) * (w['D'] if w['kind'] == 'pot' else 256)
         # ProductOfT keeps dE/dX as part of the state (read + written with X, V); SparseImageCode recomputes it
         dense_bytes = (6.0 if w['kind'] == 'pot' else 4.0) * w['D'] * esize + 6 * (8 if w['dtype'] == 'float64' else 4) + 17
         peak = 157.3 if w['kind'] == 'pot' else 2500.0
-        # ... of the trajectories the device RAN.  The reference integrates the inverse-L proposal of every cold particle; the
-        # kernels skip the F-movers' (it is the L proposal of the iteration before, bit for bit: csrc/dense_pot.hip), so the
-        # counters (which follow the reference) count more evaluations than were executed.  `achieved` / `frac` = executed
-        # flops / time -- what the matrix pipe did; `counted` = the reference's evaluation count / time.
+        # needed: the trajectories whose end point the chain reads -- every particle's L proposal and the inverse-L proposal
+        # of every cold cache EXCEPT the F-movers' (it is the L proposal of the iteration before, bit for bit:
+        # csrc/dense_pot.hip) -- at L gradients (4 D K flop) + one energy (2 D K) each.
+        # executed: the same trajectories without the 2 D K energy term -- the kernels take the energy from the last
+        # gradient's intermediate (dense_pot_tile.hpp), no separate product runs.
+        # counted: the reference's own counters (it integrates the F-movers' proposals too): dEdX_evals 4DK + E_evals 2DK.
         run = float(n_rank * iters + agg[6])                                  # trajectories integrated (forward + inverse-L)
         flops = run * (w['L'] * 4 * DK + 2 * DK) / iters
+        flops_exec = run * (w['L'] * 4 * DK) / iters
         flops_counted = (agg[3] * 4 * DK + agg[2] * 2 * DK) / iters
-        tf = flops / (kern_it_ms * 1e-3) / 1e12
+        sec = kern_it_ms * 1e-3
+        tf = flops / sec / 1e12
         roof = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
-                'counted': {'achieved': flops_counted / (kern_it_ms * 1e-3) / 1e12, 'frac': flops_counted / (kern_it_ms * 1e-3) / 1e12 / peak,
+                'executed': {'achieved': flops_exec / sec / 1e12, 'frac': flops_exec / sec / 1e12 / peak, 'flops_per_launch': flops_exec},
+                'counted': {'achieved': flops_counted / sec / 1e12, 'frac': flops_counted / sec / 1e12 / peak,
                             'flops_per_launch': flops_counted},
                 'traffic': measured_traffic(key, 1) if full_shape else None,
                 'kernel': ('pot64_jump_kernel+pot64_decide_kernel' if (w['kind'] == 'pot' and w['dtype'] == 'float64') else
                            'pot_jump_kernel+pot_fix_kernel' if w['kind'] == 'pot' else 'sic_jump_kernel+sic_fix_kernel'),
                 'avg_launch_ms': kern_it_ms, 'launches_timed': launches, 'algorithmic_flops_per_launch': flops,
                 'hbm': {'algorithmic_bytes_per_launch': dense_bytes * n_rank,
-                        'achieved': dense_bytes * n_rank / (kern_it_ms * 1e-3) / 1e9, 'unit': 'GB/s'}}
+                        'achieved': dense_bytes * n_rank / sec / 1e9, 'unit': 'GB/s'}}
         if w['kind'] == 'pot' and w['dtype'] == 'float64':
             # the float64-state kernel streams the position through a working copy once per leapfrog step:
-            # 8 B read + 8 B written per element and gradient evaluation, by design -- part of what this kernel has to move
-            wc = 16.0 * w['D'] * run * w['L'] / iters
-            roof['hbm']['working_copy_bytes_per_launch'] = wc
-            roof['hbm']['algorithmic_bytes_per_launch'] += wc
-            roof['hbm']['achieved'] = roof['hbm']['algorithmic_bytes_per_launch'] / (kern_it_ms * 1e-3) / 1e9
+            # 8 B read + 8 B written per element and gradient evaluation -- the kernel's own traffic, NOT part of the
+            # algorithmic bytes of SURVEY 8d (PMC traffic / algorithmic = 8.6: that copy)
+            roof['hbm']['working_copy_bytes_per_launch'] = 16.0 * w['D'] * run * w['L'] / iters
         if w['kind'] == 'sic':
             # one pass over the 512 KB dictionary per leapfrog step of a 32-particle tile, plus two per trajectory (the
             # residual at its head, the closing half kick): L + 2 passes per L gradient evaluations, out of L2 (the
             # dictionary cannot stay in a CU).
             tile_grads = run * w['L'] / 32.0 / iters
-            l2 = tile_grads * (w['L'] + 2.0) / w['L'] * 512 * 1024 / (kern_it_ms * 1e-3) / 1e9
+            l2 = tile_grads * (w['L'] + 2.0) / w['L'] * 512 * 1024 / sec / 1e9
             roof['l2'] = {'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS}
             # The bound the 32-column tile sets: every leapfrog step streams the whole dictionary out of L2 for
             # 4*D*K*32 flop = 64 flop per dictionary byte; ceiling = min(MFMA peak, L2 peak x 64 flop/B)
@@ -549,21 +576,22 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
             # fragments (80 KiB), against 256 B/clk/CU at 2.4 GHz
             lds_bytes = tile_grads * (2.0 + 0.578) * 1024 * 1024
             lds_peak = 256.0 * 256 * 2.4                                  # B/clk/CU x CUs x GHz = GB/s
-            roof['lds'] = {'achieved': lds_bytes / (kern_it_ms * 1e-3) / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
-                           'frac': lds_bytes / (kern_it_ms * 1e-3) / 1e9 / lds_peak}
+            roof['lds'] = {'achieved': lds_bytes / sec / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
+                           'frac': lds_bytes / sec / 1e9 / lds_peak}
     else:
         abytes = algorithmic_bytes_per_particle(w['D'], esize) * n_rank          # per sampling iteration
         hbm = {'achieved': abytes / (kern_it_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'algorithmic_bytes_per_launch': abytes * it_per_launch}
         hbm['frac_of_algorithmic'] = hbm['achieved'] / HBM_PEAK_GBS
-        # Vector work executed per iteration: one fused multiply-add per element for the opening half kick, two per
+        # Vector work the chain needs per iteration: one fused multiply-add per element for the opening half kick, two per
         # element and leapfrog step (drift, merged kick), on the forward trajectory of every particle and the
         # inverse one of the cold-cache particles, plus 4 flop per element for the two energy sums (rates, draws,
         # reductions and bookkeeping are vector instructions too, not flops).
         # (the funnel's force needs sum_k x_k^2 at every step: one more multiply-add per element and step; its exp(-x0),
         # once per particle and step, is not counted)
         fl_step = 6.0 if w['kind'] == 'funnel' else 4.0
-        vflops = (1.0 + cold_frac) * (fl_step * w['L'] + 6.0) * w['D'] * n_rank
+        per_traj = (fl_step * w['L'] + 6.0) * w['D']
+        vflops = (1.0 + cold_frac) * per_traj * n_rank
         valu_tf = vflops / (kern_it_ms * 1e-3) / 1e12
         valu_peak = 78.6 if w['dtype'] == 'float64' else 157.3
         valu = {'achieved': valu_tf, 'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': valu_tf / valu_peak}
@@ -572,22 +600,22 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
             # the state crosses HBM once per LAUNCH, not once per iteration: HBM does not bound the launch (the
             # algorithmic byte rate of SURVEY 8d exceeds the HBM peak); the fp64 vector pipe does
             roof = dict(valu, bound='fp64_valu', traffic=traffic,
-                        kernel='mjhmc_fused_rows_kernel' if w['kind'] == 'funnel' else 'mjhmc_jump_kernel<FUSED>',
+                        kernel='mjhmc_fused_rows_relay_kernel' if w['kind'] == 'funnel' else 'mjhmc_jump_kernel<FUSED>',
                         avg_launch_ms=kern_it_ms * it_per_launch, launches_timed=launches / it_per_launch,
                         iterations_per_launch=it_per_launch, algorithmic_flops_per_launch=vflops * it_per_launch)
             roof['hbm_algorithmic'] = hbm
+            ex_flops = vflops       # a wavefront per particle (C2): the inverse-L trajectory runs for the cold particles only
             if w['kind'] == 'funnel':
-                # a wave of 64 particles integrates the inverse-L trajectory in all its lanes whenever ONE of its caches is
-                # cold: what the pipe executes, beside what the chain needs
-                waves_inv = 1.0 - (1.0 - cold_frac) ** 64
-                ex_flops = (1.0 + waves_inv) * (fl_step * w['L'] + 6.0) * w['D'] * n_rank
-                # as for the dense workloads the line's `achieved` is what the device RAN; `needed` = what the chain needs
-                roof['needed'] = {'achieved': roof['achieved'], 'unit': 'TFLOP/s', 'frac': roof['frac'],
-                                  'algorithmic_flops_per_launch': roof['algorithmic_flops_per_launch']}
-                roof['achieved'] = ex_flops / (kern_it_ms * 1e-3) / 1e12
-                roof['frac'] = roof['achieved'] / valu_peak
-                roof['executed_flops_per_launch'] = ex_flops * it_per_launch
-                roof['waves_integrating_inverse_L'] = waves_inv
+                # the relay kernel (elementwise.hpp): a workgroup of 256 particles integrates its own 256 L proposals and, on
+                # one wave's worth of lanes (two per pooled particle), the inverse-L proposals of its cold caches -- one
+                # quarter of a wave-trajectory per wave and iteration whenever the pool is not empty: 1.125 executed per
+                # 1 + cold_fraction needed (the one-wave kernel of round 5: 1 + 0.99)
+                pool_busy = 1.0 - (1.0 - cold_frac) ** 256
+                ex_flops = (1.0 + 0.125 * pool_busy) * per_traj * n_rank
+                roof['pool_busy_fraction'] = pool_busy
+            roof['executed'] = {'achieved': ex_flops / (kern_it_ms * 1e-3) / 1e12, 'unit': 'TFLOP/s',
+                                'frac': ex_flops / (kern_it_ms * 1e-3) / 1e12 / valu_peak,
+                                'flops_per_launch': ex_flops * it_per_launch, 'over_needed': ex_flops / vflops}
             if unfused_ms:
                 roof['one_iteration_per_launch'] = {
                     'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,
@@ -630,6 +658,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
             roof['lds']['frac_at_held_clock'] = roof['lds']['frac'] * 2400.0 / max(device['sclk_mhz'][1], 1.0)
     if boundary is not None:
         out['boundary'] = boundary
+    if acor is not None:
+        out['autocor_on_device'] = acor
     if world == 1 and cpu_seconds > 0:
         out['cpu_baseline'] = cpu_baseline(w, cpu_seconds)
         out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
@@ -652,27 +682,20 @@ def rnd(x, sig=5):
 
 
 def compact(rec):
-    """One workload's record as the printed line carries it (numbers only; the full record goes to --detail)."""
+    """One workload's record as the printed line carries it beside the flat keys of `config` (numbers only; the full record
+    goes to --detail)."""
     r = rec['roofline']
-    roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms') if k in r}
-    for sub in ('l2_stream', 'l2', 'lds', 'one_iteration_per_launch', 'counted'):
-        if sub in r:
-            roof[sub + '_frac'] = r[sub]['frac']
-    if 'frac_at_held_clock' in r:
-        roof['frac_at_held_clock'] = r['frac_at_held_clock']
     c = rec['config']
-    out = {'value': rec['value'], 'ms_per_step': rec['ms_per_step'], 'steps': rec.get('steps'), 'roofline': roof,
-           'lfr': [c['L_move_fraction'], c['F_move_fraction'], c['R_move_fraction']], 'cold': c['cold_fraction'],
-           'inv_run': c['inverse_L_run_fraction'],
-           'n': c['nparticles_per_gpu']}
+    out = {'value': rec['value'], 'steps': rec.get('steps'), 'n': c['nparticles_per_gpu'], 'achieved': r['achieved'], 'peak': r['peak'],
+           'traffic': r.get('traffic'), 'cold': c['cold_fraction'], 'inv_run': c['inverse_L_run_fraction']}
+    if 'frac_at_held_clock' in r:
+        out['frac_at_held_clock'] = r['frac_at_held_clock']
     d = rec.get('device') or {}
     if d.get('sclk_mhz'):
         out['sclk_w'] = [d['sclk_mhz'][1], d['power_w'][1] if d.get('power_w') else None]
     if 'cpu_baseline' in rec:
         b = rec['cpu_baseline']
-        out['cpu_baseline'] = {'value': b['value'], 'cores': b['cores'], 'kind': b['kind'], 'n': b['nparticles'],
-                               'iters': b['iterations'], 's': b['seconds']}
-        out['gpu_over_cpu'] = c.get('gpu_over_cpu')
+        out['cpu'] = [b['value'], b['cores'], b['nparticles'], b['iterations']]
     return out
 
 
@@ -949,15 +972,16 @@ def main(argv=None):
     ap.add_argument('--steps', type=int, default=64)     # iterations per mjhmc_iterate call (one fused launch of the elementwise kernels)
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--workload', default='all', choices=sorted(WORKLOADS) + ['all'])      # c3f64: C3 in the reference's arithmetic
-    ap.add_argument('--head', default='c3f64', choices=['c2', 'c3', 'c3f64', 'c4', 'c5', 'c5f32'],
+    ap.add_argument('--head', default='c3f64', choices=['c2', 'c3', 'c3f64', 'c4', 'c5', 'c5bf16'],
                     help='top-level workload of the line (default: C3 in the reference\'s arithmetic -- float64 state around '
                          'the float32 force --, the workload of BASELINE.json\'s numeric target; c3: its float32-state form)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--shard-of', default='8',
+    ap.add_argument('--shard-of', default='auto',
                     help='comma list of G: after every workload, the same workload at N/G particles on this ONE GPU (what a rank '
-                         'of a G-GPU strong-scaled run executes); shard_efficiency = t(N) / (G t(N/G)).  Default 8; "1" = none; '
-                         '"2,4,8" = the whole curve.  Ignored at --gpus > 1')
+                         'of a G-GPU strong-scaled run executes); shard_efficiency = t(N) / (G t(N/G)).  Default "auto": 2,4,8 '
+                         'for the head, C4 and C5 (BASELINE.json words those as sharded; north_star: "fraction reported at '
+                         '1/2/4/8"), 8 for the others; "1" = none.  Ignored at --gpus > 1')
     ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
                     help='file that receives the complete per-workload records (the printed line carries numbers only)')
     ap.add_argument('--spawn-check', action='store_true',
@@ -975,12 +999,17 @@ def main(argv=None):
     # spawning parent watches for the marker below), not after five workloads
     gather_info = sample_gather_check(rig) if rig.comm is not None else None
     progress('gather_done')
-    keys = ['c2', 'c3', 'c3f64', 'c4', 'c5', 'c5f32'] if args.workload == 'all' else [args.workload]
+    keys = ['c2', 'c3', 'c3f64', 'c4', 'c5', 'c5bf16'] if args.workload == 'all' else [args.workload]
     head = args.head if args.head in keys else keys[0]
     keys = [head] + [k for k in keys if k != head]
     rig.head = head
     results, strong, shards = {}, {}, {}
-    shard_gs = sorted({int(g) for g in args.shard_of.split(',') if g.strip() and int(g) > 1}) if rig.world == 1 else []
+    def shard_gs(key):
+        if rig.world != 1 or key == 'c1':
+            return []
+        if args.shard_of == 'auto':
+            return [2, 4, 8] if key in (head, 'c4', 'c5') else [8]
+        return sorted({int(g) for g in args.shard_of.split(',') if g.strip() and int(g) > 1})
 
     def budget(key):
         # the head workload runs exactly --steps / --warmup; the other dense workloads (10-20 ms per iteration: a batch
@@ -992,10 +1021,10 @@ def main(argv=None):
     # ONE CPU baseline serves both forms of C3: the NumPy port integrates float64 state around a float32 force, which is
     # c3f64's arithmetic exactly; it is timed with whichever of the two runs as the head (else with c3f64)
     cpu_key = {'c3': head if head in ('c3', 'c3f64') else 'c3f64', 'c3f64': head if head in ('c3', 'c3f64') else 'c3f64',
-               'c5': head if head in ('c5', 'c5f32') else 'c5', 'c5f32': head if head in ('c5', 'c5f32') else 'c5'}
+               'c5': head if head in ('c5', 'c5bf16') else 'c5', 'c5bf16': head if head in ('c5', 'c5bf16') else 'c5'}
     # run order: the two vector-pipe / HBM workloads first, then the matrix-core ones -- whichever is the head.  (Measured:
     # C2 right after the ProductOfT run reads 7 % slower than on a chip that has not just run 20 s of dense MFMA work.)
-    for key in [k for k in ('c1', 'c2', 'c4', 'c3', 'c3f64', 'c5', 'c5f32') if k in keys]:
+    for key in [k for k in ('c1', 'c2', 'c4', 'c3', 'c3f64', 'c5', 'c5bf16') if k in keys]:
         steps, warm = budget(key)
         cpu_s = 0 if (args.no_cpu_baseline or cpu_key.get(key, key) != key) else (12.0 if key == head else 6.0)
         results[key] = run_workload(rig, key, steps, warm, cpu_s, args.scaling)
@@ -1005,9 +1034,7 @@ def main(argv=None):
             results[key]['warmup'] = warm
         # what a rank of a G-GPU strong-scaled run executes: the same workload at N/G particles on this one GPU, right
         # after the full-size run (same box, same clocks): shard_efficiency = t(N) / (G * t(N/G))
-        for g in shard_gs:
-            if key == 'c1':
-                continue
+        for g in shard_gs(key):
             rec = run_workload(rig, key, steps, warm, 0, args.scaling, shard_of=g)
             progress('shard_done %s/%d' % (key, g))
             if rec is not None:
@@ -1024,7 +1051,7 @@ def main(argv=None):
                 strong[key].update(steps=steps, warmup=warm, scaling='strong')
     if rig.rank == 0:
         # the two forms of C3 share the CPU baseline (which IS the float64-state arithmetic)
-        for pair in ([results.get('c3'), results.get('c3f64')], [results.get('c5'), results.get('c5f32')]):
+        for pair in ([results.get('c3'), results.get('c3f64')], [results.get('c5'), results.get('c5bf16')]):
             src = next((r for r in pair if r and 'cpu_baseline' in r), None)
             for r in pair:
                 if r and src and 'cpu_baseline' not in r:
@@ -1042,20 +1069,30 @@ def main(argv=None):
                 continue
             r, c = v['roofline'], v['config']
             flat['%s_ms' % k] = v['ms_per_step']
-            flat['%s_frac' % k] = r['frac']
+            flat['%s_frac' % k] = r['frac']                       # needed flops (bytes) / time / peak: one meaning everywhere
             flat['%s_bound' % k] = r['bound']
+            if 'executed' in r:
+                flat['%s_frac_executed' % k] = r['executed']['frac']
             if 'counted' in r:
                 flat['%s_frac_counted' % k] = r['counted']['frac']
             if 'l2_stream' in r:
                 flat['%s_l2stream_frac' % k] = r['l2_stream']['frac']
-                flat['%s_l2_frac' % k] = r['l2']['frac']
+            if 'one_iteration_per_launch' in r:               # the sampling_iteration() path: one iteration per call (HBM-bound)
+                flat['%s_one_iter_ms' % k] = r['one_iteration_per_launch']['avg_launch_ms']
+                flat['%s_one_iter_frac' % k] = r['one_iteration_per_launch']['frac']
             flat['%s_lfr' % k] = '%.3f/%.3f/%.3f' % (c['L_move_fraction'], c['F_move_fraction'], c['R_move_fraction'])
             if c.get('gpu_over_cpu'):
                 flat['%s_gpu_over_cpu' % k] = c['gpu_over_cpu']
+            if 'boundary' in v:                                   # particle-steps/s of sample(n): iterations + streamed download
+                flat['%s_sample%d_incl_download' % (k, v['boundary']['samples'])] = v['boundary']['particle_steps_per_s_incl_download']
+            if 'autocor_on_device' in v:
+                flat['%s_autocor_on_device' % k] = v['autocor_on_device']['particle_steps_per_s_incl_autocor']
             for g, rec in sorted(shards.get(k, {}).items()):
                 flat['%s_shard%d_ms' % (k, g)] = rec['ms_per_step']
                 flat['%s_shard%d_frac' % (k, g)] = rec['roofline']['frac']
                 flat['%s_shard%d_eff' % (k, g)] = rec['shard_efficiency']
+        if 'c5bf16' in results and results['c5bf16']:
+            flat['c5bf16_law'] = 'hot'         # the bf16-state MarkovJumpHMC chain does not keep its law; c5 does
         cfg.update(flat)
         if gather_info is not None:
             cfg['sample_gather_ok'] = bool(gather_info.get('ok'))
@@ -1072,6 +1109,8 @@ def main(argv=None):
                                             'traffic_over_algorithmic', 'frac_at_held_clock') if k in hr},
             'timing': {k: h[k] for k in ('ms_per_step_median', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'timed_s')},
         }
+        if 'executed' in hr:    # what the device ran / time (the line's `frac`: what the chain needs)
+            out['roofline']['frac_executed'] = hr['executed']['frac']
         if 'counted' in hr:     # the reference's evaluation count / time (it integrates the F-movers' inverse-L proposals too)
             out['roofline']['frac_counted'] = hr['counted']['frac']
         if 'cpu_baseline' in h:
@@ -1088,22 +1127,21 @@ def main(argv=None):
             out['target'] = {'workload': 'c3f64' if results.get('c3f64') else 'c3', 'min_gpu_over_cpu': 50, 'gpu_over_cpu': ratio,
                              'met': bool(ratio >= 50)}
         if 'boundary' in h:
-            bd = h['boundary']
-            out['boundary'] = {'state_read_GBps': bd['state_read_GBps'], 'state_read_warm_GBps': bd['state_read_warm_GBps'],
-                               'sample10': bd['sample10']}
+            out['boundary'] = h['boundary']
+        ac = {k: v['autocor_on_device'] for k, v in results.items() if v and 'autocor_on_device' in v}
+        if ac:
+            out['autocor_on_device'] = ac
         if gather_info is not None:
             out['sample_gather'] = {k: v for k, v in gather_info.items() if k not in ('compared_with',)}
         if len(keys) > 1:
             out['workloads'] = {k: compact(v) for k, v in results.items() if v}
-        if shards:
-            out['shards'] = {k: {str(g): {'n': rec['config']['nparticles_per_gpu'], 'ms': rec['ms_per_step'],
-                                          'frac': rec['roofline']['frac'], 'eff': rec['shard_efficiency']}
-                                 for g, rec in sorted(v.items())} for k, v in shards.items()}
         if strong:
             out['strong'] = {k: compact(v) for k, v in strong.items() if v}
         # LAST key (the tail of the line is what a truncating reader keeps): [ms, frac, bound, shard-8 efficiency] per workload
         out['summary'] = {k: [v['ms_per_step'], v['roofline']['frac'], v['roofline']['bound'],
                               (shards.get(k, {}).get(8) or {}).get('shard_efficiency')] for k, v in results.items() if v}
+        out['line_note'] = 'frac = needed flops (bytes) / time / peak; *_frac_executed, *_frac_counted beside it; c5 = float32 state, c5bf16_law = hot'
+
         line = json.dumps(rnd(out))
         print(line)
         sys.stdout.flush()

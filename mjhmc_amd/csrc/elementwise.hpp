@@ -1614,6 +1614,14 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
       // bookkeeping of iteration `it`; the successor state becomes the next iteration's pre-move state
       if (bad && alive) first_bad = min(first_bad, it);
       const bool lead = alive && m.j == 0;
+      if constexpr (BD && kBdPpw == 1) {
+        // a wavefront per particle: the move is wave-uniform, the tallies are two LDS atomics of lane 0 (the ballots of the
+        // general form below cost ~25 vector instructions per iteration to say "one" -- 6 % of C2's iteration)
+        if (lead) {
+          atomicAdd(&fused_tally[it][k], 1u);
+          if (tally_cold) atomicAdd(&fused_tally[it][3], 1u);
+        }
+      } else {
       unsigned long long b0, b1, b2;
       if constexpr (MODE == kModeControl) {
         b0 = __ballot(lead && k == 3);
@@ -1630,6 +1638,7 @@ __global__ __launch_bounds__(256, (JumpWaves<En, T, E>::value)) void mjhmc_jump_
         if (b1) atomicAdd(&fused_tally[it][1], (unsigned)__popcll(b1));
         if (b2) atomicAdd(&fused_tally[it][2], (unsigned)__popcll(b2));
         if (b3) atomicAdd(&fused_tally[it][3], (unsigned)__popcll(b3));
+      }
       }
       if (a.xiter && have) {  // sample ring: X and the dwelling times after every iteration
         slot_store<T, E, FULLROW>((char*)(a.xiter + (size_t)it * a.xiter_stride) + slot * slot_bytes, lane_off,

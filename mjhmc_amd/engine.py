@@ -232,12 +232,14 @@ class DeviceSampler(object):
         attempts = n_done + 1 if n_done < n_iter else n_iter
         return [stats[i] for i in range(attempts)], n_done
 
-    def ring_budget_slots(self, n_wanted, share=0.6):
+    def ring_budget_slots(self, n_wanted, share=0.6, staging=True):
         """How many whole-state ring slots (of n_wanted) the device can take: those it already has, or `share` of the free
-        memory -- at least 2 (an iteration reads one slot and writes the next)."""
+        memory -- at least 2 (an iteration reads one slot and writes the next).  ``staging``: every slot also gets a staging
+        copy in the host layout (mjhmc_iterate_download: the streamed sample()); a ring that is recorded and then read or
+        gathered from needs none."""
         b = ctypes.c_uint64()
         check(self.lib.mjhmc_ring_slot_bytes(self.handle, ctypes.byref(b)), self.lib)
-        per = int(b.value) + 8 * self.ndims * self.nparticles    # + the slot's staging copy in the host layout (iterate_download)
+        per = int(b.value) + (8 * self.ndims * self.nparticles if staging else 0)
         free, _ = self.ctx.mem_info()
         fit = max(int(share * free // per) + self.ring_slots, 2)
         return min(int(n_wanted), fit)

@@ -191,11 +191,12 @@ class HMCBase(object):
         self._account(stats[0])
         self._commit(stats[0])
 
-    def _run(self, n_iter, ring_slot0=-1, replay=None, download=None):
+    def _run(self, n_iter, ring_slot0=-1, replay=None, download=None, keep_trace=False):
         """n_iter iterations launched back to back; the host only steps in on a non-finite rate.  ``download = (out, k0)``:
         ring slot ring_slot0 + i also goes to out[:, (k0 + i) * N : ...] while the following iterations run
-        (mjhmc_iterate_download)."""
-        if not self._in_retry:
+        (mjhmc_iterate_download).  ``keep_trace``: this call continues a batch call that walks the device ring in chunks --
+        eval_trace() describes the whole batch call, not its last chunk."""
+        if not self._in_retry and not keep_trace:
             self._iter_evals = []                         # the trace describes one batch call, it does not grow for ever
         if replay is not None:                            # recorded random numbers: one attempt at a time
             for i in range(n_iter):
@@ -315,7 +316,7 @@ class HMCBase(object):
         done = 0
         while done < n_iter:
             chunk = min(slots, n_iter - done)
-            self._run(chunk, ring_slot0=0, download=(out, done))
+            self._run(chunk, ring_slot0=0, download=(out, done), keep_trace=done > 0)
             done += chunk
         self._publish()
         return out
@@ -416,7 +417,8 @@ class ContinuousTimeHMC(HMCBase):
         if num_steps is not None:
             n_samples = num_steps
         if self.resample:
-            if self._streams(False, replay) and self._dev.ring_budget_slots(n_samples + 1) < n_samples + 1:
+            # (this path records into the ring and gathers columns from it: no staging copy per slot is charged)
+            if self._streams(False, replay) and self._dev.ring_budget_slots(n_samples + 1, staging=False) < n_samples + 1:
                 return self._resample_on_host(n_samples)
             self._dev.ring_alloc(n_samples + 1)
             self._run(n_samples + 1, ring_slot0=0, replay=replay)
@@ -455,7 +457,7 @@ class ContinuousTimeHMC(HMCBase):
         dwell, done = [], 0
         while done < n_iter:
             chunk = min(slots, n_iter - done)
-            self._run(chunk, ring_slot0=0, download=(states, done))
+            self._run(chunk, ring_slot0=0, download=(states, done), keep_trace=done > 0)
             dwell.append(self._dev.ring_read_dwell(0, chunk))
             done += chunk
         self._publish()

@@ -322,8 +322,9 @@ def test_streamed_sample_equals_the_recorded_ring(what, cls_name, monkeypatch):
         if variant == 'recorded, then read':
             monkeypatch.setattr(type(s), '_streams', lambda self, po, rp: False)
         elif variant == 'ring of 3 slots':
-            monkeypatch.setattr(type(s._dev), 'ring_budget_slots', lambda self, n_wanted, share=0.6: min(n_wanted, 3))
-        outs.append((s.sample(n), s.state.X, s.l_count, s.f_count, s.r_count, d.E_count, d.dEdX_count))
+            monkeypatch.setattr(type(s._dev), 'ring_budget_slots', lambda self, n_wanted, share=0.6, staging=True: min(n_wanted, 3))
+        outs.append((s.sample(n), s.state.X, s.l_count, s.f_count, s.r_count, d.E_count, d.dEdX_count, s.eval_trace(n).tolist()))
+        assert len(outs[-1][-1]) == n, 'eval_trace() describes the whole batch call, chunked or not'
         monkeypatch.undo()
     for o in outs[1:]:
         if not bits_equal(outs[0][0], o[0]):
@@ -345,7 +346,7 @@ def test_resampling_on_the_host_when_the_ring_does_not_fit(monkeypatch):
         d, kw = _sampler_for('pot32')
         s = M.MarkovJumpHMC(distribution=d, seed=21, beta=0.2, **kw)
         if small:
-            monkeypatch.setattr(type(s._dev), 'ring_budget_slots', lambda self, n_wanted, share=0.6: min(n_wanted, 4))
+            monkeypatch.setattr(type(s._dev), 'ring_budget_slots', lambda self, n_wanted, share=0.6, staging=True: min(n_wanted, 4))
         np.random.seed(3)
         outs.append((s.sample(9), s._last_resample_idx.copy(), s.dwelling_times.copy()))
         monkeypatch.undo()

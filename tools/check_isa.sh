@@ -87,6 +87,9 @@ for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)', txt, 
 for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel', txt, flags=re.S | re.M):
     if 'pot' not in name:
         continue
+    if ('pot_fix_kernel' in name or 'pot64_decide_kernel' in name) and meta.get(name, {}).get('scratch'):
+        print('%-84s scratch %s B   <-- VIOLATION (the fix / decide kernels hold no spills)' % (name[9:93], meta[name]['scratch']))
+        bad += 1
     blocks, cur = [], []
     for l in body.split('\n'):
         if re.match(r'^\.LBB\w+:', l):
@@ -112,7 +115,11 @@ for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel'
     tag = ''
     # (one or two folded reloads of a lane constant in a pass are tolerated: the allocator moves them around with every
     # change to the kernel; momentum elements reloaded inside the pass -- a handful of them, each behind a vmcnt(0) -- are not)
-    if hot and (n_scr or p_scr > 2 or len(gemm) < 2 or ('pot64' in name and not passes)):
+    # scratch reloads tolerated in the streamed per-step pass, per instance (what each one has TODAY: a regression of a
+    # clean instance fails; the allocator's one or two folded lane-constant reloads of the others are pinned at their count)
+    allow = {'pot64_jump_kernelILi4ELb0ELi0EE': 1, 'pot64_jump_kernelILi4ELb1ELi0EE': 1}.get(re.sub(r'^_ZN5mjhmc\d+', '', name).split('Ev')[0], 0)
+    new_kernels = any(t in name for t in ('pot_fix_kernel', 'pot64_decide_kernel'))
+    if (hot and (n_scr or p_scr > allow or len(gemm) < 2 or ('pot64' in name and not passes))) or (new_kernels and m.get('scratch')):
         bad += 1
         tag = '   <-- VIOLATION'
     if gemm:
@@ -124,8 +131,10 @@ sys.exit(1 if bad else 0)
 PY
 done
 # The row-form kernels of the funnels (elementwise.hpp): what their design promises --
-#   mjhmc_fused_rows_kernel: no scratch memory at all; the leapfrog-step loops are straight vector code (<= 150 instructions for
-#   the 32-coordinate row, nothing from memory);
+#   mjhmc_fused_rows_kernel / mjhmc_fused_rows_relay_kernel (the product's form since round 6: four-wave workgroups, the cold
+#   caches' inverse-L trajectories pooled): no scratch memory at all; the leapfrog-step loops -- the wave's own and the
+#   pool's two-lanes-per-particle one -- are straight vector code (<= 150 / 170 instructions for the 32-coordinate row,
+#   nothing from memory);
 #   mjhmc_traj_rows_kernel (full rows): step loops the same; between the first row store and the end of the forward path no
 #   wait that drains the loads/stores counter (a vmcnt(0) there is a wait for the previous store's round trip to memory).
 [ -n "${SKIP_COMPILE:-}" ] || $HIPCC $FLAGS --cuda-device-only -S energy_funnel.hip -o /tmp/mjhmc_energy_funnel.s 2> /dev/null || { echo "compile of energy_funnel failed"; exit 2; }
@@ -139,7 +148,7 @@ for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)', txt, 
     g = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, body).group(1)) if re.search(r'\.%s:\s+(\d+)' % k, body) else None
     meta[m.group(1)] = dict(vgpr=g('vgpr_count'), scratch=g('private_segment_fixed_size'), vgpr_spill=int(m.group(3)))
 for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel', txt, flags=re.S | re.M):
-    if 'rows_kernel' not in name or 'IdEE' not in name:
+    if ('rows_kernel' not in name and 'rows_relay_kernel' not in name) or 'IdEE' not in name:
         continue
     lines = body.split('\n')
     pos = {}
@@ -159,6 +168,7 @@ for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel'
     longest = max([len(seg) for seg in steps] or [0])
     m = meta.get(name, {})
     fused = 'fused_rows' in name
+    relay = 'rows_relay_kernel' in name      # (its own-trajectory step carries the pool's bookkeeping registers: <= 170)
     full4 = 'Li8ELi2ELb1E' in name
     drains = None
     if not fused and 'Lb1E' in name:             # full rows: the forward path's stores
@@ -166,7 +176,7 @@ for name, body in re.findall(r'^(_ZN5mjhmc\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel'
         end = next((k for k in range(first or 0, len(lines)) if 's_endpgm' in lines[k] or 's_branch' in lines[k]), len(lines))
         drains = sum(bool(re.search(r's_waitcnt[^\n]*vmcnt\(0\)', l)) for l in lines[first:end]) if first is not None else None
     tag = ''
-    if (not steps or n_mem or (full4 and longest > 150) or (fused and m.get('scratch')) or (drains not in (None, 0))):
+    if (not steps or n_mem or (full4 and longest > (170 if relay else 150)) or (fused and m.get('scratch')) or (drains not in (None, 0))):
         bad += 1
         tag = '   <-- VIOLATION'
     print('%-92s vgpr %3s spilled %3s scratch %4s B | step loops %d (longest %d instructions, memory operations %d)%s%s'

@@ -6,7 +6,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/$1; shift
-WL=${*:-c2 c3 c3f64 c4 c5 c5f32}
+WL=${*:-c2 c3 c3f64 c4 c5 c5bf16}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
@@ -16,7 +16,7 @@ for w in $WL; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${w}_$c" -o $w -- python3 "$ROOT/bench.py" $args > /dev/null 2> "$OUT/pmc_${w}_$c.err"
   done
 done
-for w in c2 c3f64 c4 c5 c5f32; do
+for w in c2 c3f64 c4 c5 c5bf16; do
   case " $WL " in *" $w "*) ;; *) continue;; esac
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d "$OUT/sq1_$w" -o $w -- python3 "$ROOT/bench.py" --workload $w --no-cpu-baseline --shard-of 1 > /dev/null 2> "$OUT/sq1_$w.err"
   rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq2_$w" -o $w -- python3 "$ROOT/bench.py" --workload $w --no-cpu-baseline --shard-of 1 > /dev/null 2> "$OUT/sq2_$w.err"

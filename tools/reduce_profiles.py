@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAIN = {'c2': 'mjhmc_jump_kernel', 'c2nofuse': 'mjhmc_jump_kernel', 'c3': 'pot_jump_kernel', 'c3f64': 'pot64_jump_kernel',
-        'c4': 'mjhmc_fused_rows_kernel', 'c4nofuse': 'mjhmc_traj_rows_kernel', 'c5': 'sic_jump_kernel', 'c5f32': 'sic_jump_kernel'}
+        'c4': 'mjhmc_fused_rows_relay_kernel', 'c4nofuse': 'mjhmc_traj_rows_kernel', 'c5': 'sic_jump_kernel', 'c5bf16': 'sic_jump_kernel'}
 OURS = ('mjhmc', 'pot_', 'pot64_', 'sic_', 'compact_list', 'cold_list')
 
 
@@ -54,7 +54,7 @@ def main():
     traffic_path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
     notes = []
-    for w in ('c2', 'c2nofuse', 'c3', 'c3f64', 'c4', 'c4nofuse', 'c5', 'c5f32'):
+    for w in ('c2', 'c2nofuse', 'c3', 'c3f64', 'c4', 'c4nofuse', 'c5', 'c5bf16'):
         ks = find(os.path.join(src, 'kt_' + w), 'kernel_stats.csv')
         if ks:
             shutil.copy(ks, os.path.join(dst, w + '_kernel_stats.csv'))

@@ -1,5 +1,5 @@
 """Dense workloads: free-running parts of a batch (api.hip: iterate_t) -- 1 ... 4 parts at full size and at N/8.
-usage: python tools/sweep_parts.py [c3f64|c3|c5|c5f32 ...]      (test build: MJHMC_SPLIT_PARTS / MJHMC_NO_SPLIT)"""
+usage: python tools/sweep_parts.py [c3f64|c3|c5|c5bf16 ...]      (test build: MJHMC_SPLIT_PARTS / MJHMC_NO_SPLIT)"""
 import os as _os
 _os.environ.setdefault('MJHMC_HIP_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mjhmc_amd', 'lib', 'libmjhmc_hip_test.so'))
 import os
