@@ -228,6 +228,17 @@ __device__ __forceinline__ double exp_any(double h);
 __device__ __forceinline__ float exp_any(float h);
 __device__ __forceinline__ double exp_neg(double x);
 __device__ __forceinline__ float exp_neg(float x);
+// exp_neg()'s fifteen constants held in VECTOR registers by the caller for the length of a kernel (exp_neg_k: the same
+// operations on the same constants, the same bits).  The relay kernel's step loops re-materialised them in scalar registers
+// at every leapfrog step -- 30 s_mov_b32 per step: its 106 scalar registers are taken (70 spilled) and the loop's constants
+// lost -- where it has vector registers to spare.
+struct ExpNegK {
+  double k[15];
+};
+struct NoExpK {};
+__device__ __forceinline__ ExpNegK exp_neg_pinned();
+__device__ __forceinline__ double exp_neg_k(double x, const ExpNegK& K);
+__device__ __forceinline__ double exp_neg_k(double x, const NoExpK&) { return exp_neg(x); }
 
 struct NoCtx {};
 template <int E>
@@ -408,8 +419,8 @@ __device__ __forceinline__ T rows_sum(const T (&p)[G]) {
 }
 // prep() of the two funnels on a whole row: lane j's partial sum exactly as prep() forms it, the partials paired as
 // group_sum pairs them, exp(-x0) once per particle (prep() spends the instructions in all G lanes of the group)
-template <class Ctx, typename T, int E, int G>
-__device__ __forceinline__ Ctx funnel_prep_rows(const T (&x)[G][E]) {
+template <class Ctx, typename T, int E, int G, class XK = NoExpK>
+__device__ __forceinline__ Ctx funnel_prep_rows(const T (&x)[G][E], const XK& xk = XK{}) {
   T part[G];
 #pragma unroll
   for (int j = 0; j < G; ++j) {
@@ -421,7 +432,8 @@ __device__ __forceinline__ Ctx funnel_prep_rows(const T (&x)[G][E]) {
   Ctx c;
   c.S = rows_sum<T, G>(part);
   c.x0 = x[0][0];
-  c.ex = exp_neg(x[0][0]);
+  if constexpr (sizeof(T) == 8) c.ex = exp_neg_k(x[0][0], xk);
+  else c.ex = exp_neg(x[0][0]);
   return c;
 }
 
@@ -429,8 +441,8 @@ __device__ __forceinline__ Ctx funnel_prep_rows(const T (&x)[G][E]) {
 // -- the relay of mjhmc_fused_rows_relay_kernel integrates a pooled particle on two lanes.  The partial sums are formed as
 // funnel_prep_rows forms them; a pair's sums meet as (p0 + p1) + (p2 + p3) in the even lane and (p2 + p3) + (p0 + p1) in
 // the odd one (G = 2: p0 + p1 / p1 + p0) -- the same bits, a floating-point sum does not depend on the order of its TWO terms.
-template <class Ctx, typename T, int E, int G>
-__device__ __forceinline__ Ctx funnel_prep_pair(const T (&xh)[G / 2][E], int h) {
+template <class Ctx, typename T, int E, int G, class XK = NoExpK>
+__device__ __forceinline__ Ctx funnel_prep_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) {
   constexpr int GH = G / 2;
   static_assert(G == 2 || G == 4, "a row in two halves");
   T part[GH];
@@ -446,7 +458,8 @@ __device__ __forceinline__ Ctx funnel_prep_pair(const T (&xh)[G / 2][E], int h) 
   Ctx c;
   c.S = mine + dpp_mov<0xB1>(mine);          // quad_perm [1, 0, 3, 2]: the pair's other lane
   c.x0 = dpp_mov<0xA0>(xh[0][0]);            // quad_perm [0, 0, 2, 2]: the even lane's x[0][0]
-  c.ex = exp_neg(c.x0);
+  if constexpr (sizeof(T) == 8) c.ex = exp_neg_k(c.x0, xk);
+  else c.ex = exp_neg(c.x0);
   return c;
 }
 
@@ -505,13 +518,13 @@ struct FunnelNealF {
   }
   // the row form (mjhmc_traj_rows_kernel): the whole particle in one lane, x[j] = what lane j of its group would hold
   static constexpr bool kRowForm = true;
-  template <int E, int G>
-  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E]) const {
-    return funnel_prep_rows<Ctx, T, E, G>(x);
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E], const XK& xk = XK{}) const {
+    return funnel_prep_rows<Ctx, T, E, G, XK>(x, xk);
   }
-  template <int E, int G>
-  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h) const {
-    return funnel_prep_pair<Ctx, T, E, G>(xh, h);
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) const {
+    return funnel_prep_pair<Ctx, T, E, G, XK>(xh, h, xk);
   }
 };
 
@@ -564,13 +577,13 @@ struct FunnelRefF {
     return energy_of(prep(x, m));
   }
   static constexpr bool kRowForm = true;   // as FunnelNealF
-  template <int E, int G>
-  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E]) const {
-    return funnel_prep_rows<Ctx, T, E, G>(x);
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E], const XK& xk = XK{}) const {
+    return funnel_prep_rows<Ctx, T, E, G, XK>(x, xk);
   }
-  template <int E, int G>
-  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h) const {
-    return funnel_prep_pair<Ctx, T, E, G>(xh, h);
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) const {
+    return funnel_prep_pair<Ctx, T, E, G, XK>(xh, h, xk);
   }
 };
 
@@ -1036,6 +1049,33 @@ __device__ __forceinline__ double exp_neg(double x) {
   return __builtin_amdgcn_ldexp(q, (int)n);
 }
 __device__ __forceinline__ float exp_neg(float x) { return expf(-x); }
+__device__ __forceinline__ ExpNegK exp_neg_pinned() {
+  ExpNegK K;
+  const unsigned long long bits[15] = {0xc091300000000000ULL /* -1100 */, 0x4091300000000000ULL /* 1100 */,
+                                       0xbff71547652b82feULL, 0xbfe62e42fefa39efULL, 0xbc7abc9e3b39803fULL,
+                                       0x3e5ade156a5dcb37ULL, 0x3e928af3fca7ab0cULL, 0x3ec71dee623fde64ULL,
+                                       0x3efa01997c89e6b0ULL, 0x3f2a01a014761f6eULL, 0x3f56c16c1852b7b0ULL,
+                                       0x3f81111111122322ULL, 0x3fa55555555502a1ULL, 0x3fc5555555555511ULL,
+                                       0x3fe000000000000bULL};
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    K.k[i] = __longlong_as_double((long long)bits[i]);
+    asm volatile("" : "+v"(K.k[i]));   // opaque: a value in a vector register, not a literal to be re-created at its uses
+  }
+  return K;
+}
+__device__ __forceinline__ double exp_neg_k(double x, const ExpNegK& K) {   // exp_neg(), operation for operation
+  const double xc = __builtin_fmin(__builtin_fmax(x, K.k[0]), K.k[1]);
+  const double n = __builtin_rint(xc * K.k[2]);
+  double r = __builtin_fma(n, K.k[3], -xc);
+  r = __builtin_fma(n, K.k[4], r);
+  double q = r * K.k[5] + K.k[6];
+#pragma unroll
+  for (int i = 7; i < 15; ++i) q = __builtin_fma(r, q, K.k[i]);
+  q = __builtin_fma(r, q, 1.0);
+  q = __builtin_fma(r, q, 1.0);
+  return __builtin_amdgcn_ldexp(q, (int)n);
+}
 
 // Transition rate exp(dH) ** .5 (markov_jump_hmc.py:341-347).  Where exp(dH) is a normal number the rate is
 // evaluated as exp(dH / 2) in one polynomial pass (within 1 ulp of the two-step value).  Where exp(dH)
@@ -1834,12 +1874,12 @@ __device__ __forceinline__ constexpr int row_dim(int j, int e) {   // dim_of for
 // leapfrog steps [s0, s1) of a trajectory of L steps, a row at a time (trajectory<.., EXACT = false>); the opening half kick
 // belongs to the FIRST part.  Parts that cover [0, L) in order are the whole trajectory, operation for operation: the relay
 // of the fused row kernel integrates a trajectory in four parts, on four waves.
-template <class En, typename T, int E, int G>
+template <class En, typename T, int E, int G, class XK = NoExpK>
 __device__ __forceinline__ void trajectory_rows_part(const En& en, T (&x)[G][E], T (&v)[G][E], bool first, int s0, int s1, int L,
-                                                     T eps, T chalf) {
+                                                     T eps, T chalf, const XK& xk = XK{}) {
   if (L <= 0) return;
   if (first) {
-    const auto ctx = en.template prep_rows<E, G>(x);
+    const auto ctx = en.template prep_rows<E, G>(x, xk);
 #pragma unroll
     for (int j = 0; j < G; ++j)
 #pragma unroll
@@ -1851,7 +1891,7 @@ __device__ __forceinline__ void trajectory_rows_part(const En& en, T (&x)[G][E],
     for (int j = 0; j < G; ++j)
 #pragma unroll
       for (int e = 0; e < E; ++e) x[j][e] = __builtin_fma(eps, v[j][e], x[j][e]);
-    const auto ctx = en.template prep_rows<E, G>(x);
+    const auto ctx = en.template prep_rows<E, G>(x, xk);
     const T c = (s == L - 1) ? chalf : cfull;
 #pragma unroll
     for (int j = 0; j < G; ++j)
@@ -1867,13 +1907,13 @@ __device__ __forceinline__ void trajectory_rows(const En& en, T (&x)[G][E], T (&
 
 // the same part of the same trajectory with the row on TWO lanes: lane h of a pair holds x[h G/2 + jj] as xh[jj]
 // (prep_rows_pair: the pair's sums are the row's, bit for bit; everything else is per coordinate)
-template <class En, typename T, int E, int G>
+template <class En, typename T, int E, int G, class XK = NoExpK>
 __device__ __forceinline__ void trajectory_pair_part(const En& en, T (&xh)[G / 2][E], T (&vh)[G / 2][E], int h, bool first, int s0,
-                                                     int s1, int L, T eps, T chalf) {
+                                                     int s1, int L, T eps, T chalf, const XK& xk = XK{}) {
   constexpr int GH = G / 2;
   if (L <= 0) return;
   if (first) {
-    const auto ctx = en.template prep_rows_pair<E, G>(xh, h);
+    const auto ctx = en.template prep_rows_pair<E, G>(xh, h, xk);
 #pragma unroll
     for (int jj = 0; jj < GH; ++jj)
 #pragma unroll
@@ -1885,7 +1925,7 @@ __device__ __forceinline__ void trajectory_pair_part(const En& en, T (&xh)[G / 2
     for (int jj = 0; jj < GH; ++jj)
 #pragma unroll
       for (int e = 0; e < E; ++e) xh[jj][e] = __builtin_fma(eps, vh[jj][e], xh[jj][e]);
-    const auto ctx = en.template prep_rows_pair<E, G>(xh, h);
+    const auto ctx = en.template prep_rows_pair<E, G>(xh, h, xk);
     const T c = (s == L - 1) ? chalf : cfull;
 #pragma unroll
     for (int jj = 0; jj < GH; ++jj)
@@ -2489,7 +2529,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
   // part `ph` of the pool's inverse-L trajectories F L F (only H() of them is ever read: markov_jump_hmc.py:360,367), a
   // pooled particle on the lanes 2 r, 2 r + 1: ~115 vector instructions per leapfrog step instead of the ~155 of a whole row
   // per lane, and 64 registers of state beside the wave's own -- nothing of the wave's has to be moved out of the way
-  auto relay = [&](int ph) {
+  auto relay = [&](int ph, const ExpNegK& xk) {
     ROWS_STAMP(2);
     const int par = epoch & 1;
     int n;
@@ -2518,7 +2558,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
           pv[jj][2 * k] = (ph == 0) ? -qv.x : qv.x;
           pv[jj][2 * k + 1] = (ph == 0) ? -qv.y : qv.y;
         }
-      trajectory_pair_part<En, T, E, G>(en, px, pv, h, ph == 0, ph * L / W, (ph + 1) * L / W, L, a.eps, a.chalf);
+      trajectory_pair_part<En, T, E, G>(en, px, pv, h, ph == 0, ph * L / W, (ph + 1) * L / W, L, a.eps, a.chalf, xk);
       if (ph == W - 1) {
         const T ev = kinetic_pair<T, E, G>(pv);
         const T ex = en.energy_of(en.template prep_rows_pair<E, G>(px, h));
@@ -2608,10 +2648,11 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       }
       ROWS_STAMP(1);
       // forward proposal L in four parts, this wave's part of the pool's trajectories between two of them
+      const ExpNegK xk = exp_neg_pinned();   // (the force's exp(-x0) constants: vector registers for the length of the trajectories)
 #pragma unroll 1
       for (int ph = 0; ph < W; ++ph) {
-        if (wave == ph) relay(ph);
-        trajectory_rows_part<En, T, E, G>(en, x, v, ph == 0, own_stop(ph), own_stop(ph + 1), L, a.eps, a.chalf);
+        if (wave == ph) relay(ph, xk);
+        trajectory_rows_part<En, T, E, G>(en, x, v, ph == 0, own_stop(ph), own_stop(ph + 1), L, a.eps, a.chalf, xk);
       }
       ROWS_STAMP(5);
       const T EVL = kinetic_rows<T, E, G>(v);
