@@ -347,7 +347,10 @@ int mjhmc_comm_allgatherv(mjhmc_comm* c, const void* send, const int64_t* nbytes
 /* THE data-path collective, device to device: ring slots [slot0, slot0 + n) of every rank's sampler are all-gathered
  * and re-tiled on the receiving GPU; host_out is the sample block of the UNSHARDED run, columns in global particle
  * order: (D, n * N_total) time-major if stacked == 0 (np.concatenate(axis=1), markov_jump_hmc.py:170-173,336-338),
- * (D, N_total, n) if stacked != 0 (np.stack(axis=-1)).  particles_per_rank[world]: the column shard sizes. */
+ * (D, N_total, n) if stacked != 0 (np.stack(axis=-1)).  particles_per_rank[world]: the column shard sizes.
+ * host_out == NULL: this rank takes part in the collective and keeps nothing -- no re-tile, no download (a caller that
+ * wants the block on ONE rank passes NULL on the others: at C4 / n = 10 every rank's copy is 2.56 GB over its PCIe link);
+ * the same holds for mjhmc_comm_allgather_columns. */
 int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n, int stacked,
                               const int64_t* particles_per_rank, double* host_out);
 /* resampled columns (markov_jump_hmc.py:322-328): every rank gathers the n_local ring columns IT owns (local pool indices

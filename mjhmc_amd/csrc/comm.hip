@@ -238,11 +238,70 @@ static int ring_pack(mjhmc_sampler* s, int slot0, int n, int64_t mx, void* dst) 
 // unpack: `world` received blocks -> the unsharded sample block in the reference's layout, on the host.
 //   stacked == 0: (D, n * total) time-major like np.concatenate(axis=1) of the per-iteration states
 //   stacked != 0: (D, total, n) like np.stack(axis=-1)
+// ONE launch for all world x n (rank, slot) blocks (until round 5: a re-tile launch per block -- 80 launches of a few
+// microseconds each for the eight shards of a ten-sample gather); the ranks' column counts and offsets ride in the kernel
+// argument (up to kMaxUnpackRanks ranks; beyond that the launch-per-block form).
+}  // extern "C"
+constexpr int kMaxUnpackRanks = 64;
+struct UnpackShards {
+  int64_t cnt[kMaxUnpackRanks], off[kMaxUnpackRanks];
+};
+template <typename T>
+__global__ void ring_unpack_kernel(const char* __restrict__ recv, size_t blk, size_t slot_bytes, UnpackShards sh, int n,
+                                   double* __restrict__ dst, int D, int pitch, int64_t total, int stacked) {
+  __shared__ double tile[32][33];
+  const int r = blockIdx.z / n, t = blockIdx.z % n;
+  const int64_t cnt = sh.cnt[r], k0 = (int64_t)blockIdx.x * 32;
+  if (k0 >= cnt) return;   // (the grid is sized for the largest shard)
+  const T* src = reinterpret_cast<const T*>(recv + (size_t)r * blk + (size_t)t * slot_bytes);
+  // element (d, column k of rank r, slot t) -> time-major: d * (n total) + t total + off + k; stacked: d * (total n) + (off + k) n + t
+  const int64_t rs = (int64_t)n * total, cs = stacked ? n : 1, off = stacked ? sh.off[r] * n + t : (int64_t)t * total + sh.off[r];
+  const int d0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kk = threadIdx.y + 8 * i;
+    const int64_t k = k0 + kk;
+    const int d = d0 + threadIdx.x;
+    if (d < D && k < cnt) tile[kk][threadIdx.x] = (double)src[(size_t)k * pitch + d];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int dd = threadIdx.y + 8 * i;
+    const int d = d0 + dd;
+    const int64_t k = k0 + threadIdx.x;
+    if (d < D && k < cnt) dst[(size_t)d * rs + (size_t)k * cs + off] = tile[threadIdx.x][dd];
+  }
+}
+
+extern "C" {
+
 static int ring_unpack(mjhmc_sampler* s, const char* recv, size_t blk, int world, const int64_t* counts, int64_t total,
                        int64_t mx, int n, int stacked, double* host_out) {
   const size_t rb = row_bytes(s);
   const size_t elems = (size_t)s->D * total * n;
   TRY(ensure_stage(s, elems));
+  if (world <= kMaxUnpackRanks && (int64_t)world * n <= 65535) {
+    UnpackShards sh;
+    int64_t off = 0;
+    for (int r = 0; r < world; ++r) {
+      sh.cnt[r] = counts[r];
+      sh.off[r] = off;
+      off += counts[r];
+    }
+    const dim3 grid((unsigned)((mx + 31) / 32), (unsigned)((s->D + 31) / 32), (unsigned)(world * n)), block(32, 8);
+    if (s->dtype == MJHMC_F64)
+      hipLaunchKernelGGL(ring_unpack_kernel<double>, grid, block, 0, s->stream, recv, blk, (size_t)mx * rb, sh, n, s->stage, s->D,
+                         s->sh.pitch, total, stacked);
+    else if (s->dtype == MJHMC_BF16)
+      hipLaunchKernelGGL(ring_unpack_kernel<__bf16>, grid, block, 0, s->stream, recv, blk, (size_t)mx * rb, sh, n, s->stage, s->D,
+                         s->sh.pitch, total, stacked);
+    else
+      hipLaunchKernelGGL(ring_unpack_kernel<float>, grid, block, 0, s->stream, recv, blk, (size_t)mx * rb, sh, n, s->stage, s->D,
+                         s->sh.pitch, total, stacked);
+    HIPCHK(hipGetLastError());
+    return copy_to_host(s, s->stage, host_out, elems * sizeof(double));
+  }
   int64_t off = 0;
   for (int r = 0; r < world; ++r) {
     const int64_t cnt = counts[r];
@@ -306,7 +365,7 @@ static int shard_totals(const int64_t* counts, int world, int64_t least, int64_t
 
 int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n, int stacked,
                               const int64_t* particles_per_rank, double* host_out) {
-  if (!c || !s || !particles_per_rank || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (!c || !s || !particles_per_rank) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
   if (slot0 < 0 || n < 1 || slot0 + n > s->ring_slots) return mjhmc_fail(MJHMC_ERR_INVALID, "slots out of range");
   if (particles_per_rank[c->rank] != s->N) return mjhmc_fail(MJHMC_ERR_INVALID, "particles_per_rank[rank] != nparticles");
   HIPCHK(hipSetDevice(c->ctx->device));
@@ -317,12 +376,16 @@ int mjhmc_comm_allgather_ring(mjhmc_comm* c, mjhmc_sampler* s, int slot0, int n,
   TRY(need(c, 1, blk * c->world));
   TRY(ring_pack(s, slot0, n, mx, c->buf[0]));
   NCCLCHK(rccl().AllGather(c->buf[0], c->buf[1], blk, ncclInt8, c->nccl, s->stream));
+  if (!host_out) {   // this rank takes part in the collective and keeps nothing (the caller wants the block on one rank)
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+  }
   return ring_unpack(s, (const char*)c->buf[1], blk, c->world, particles_per_rank, total, mx, n, stacked, host_out);
 }
 
 int mjhmc_comm_allgather_columns(mjhmc_comm* c, mjhmc_sampler* s, const int64_t* local_idx, int64_t n_local,
                                  const int64_t* columns_per_rank, double* host_out) {
-  if (!c || !s || !columns_per_rank || !host_out) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
+  if (!c || !s || !columns_per_rank) return mjhmc_fail(MJHMC_ERR_INVALID, "NULL argument");
   if (n_local < 0 || (n_local && !local_idx)) return mjhmc_fail(MJHMC_ERR_INVALID, "bad local index list");
   if (columns_per_rank[c->rank] != n_local) return mjhmc_fail(MJHMC_ERR_INVALID, "columns_per_rank[rank] != n_local");
   HIPCHK(hipSetDevice(c->ctx->device));
@@ -334,6 +397,10 @@ int mjhmc_comm_allgather_columns(mjhmc_comm* c, mjhmc_sampler* s, const int64_t*
   TRY(need(c, 1, blk * c->world));
   TRY(columns_pack(s, local_idx, n_local, c->buf[0], (int64_t*)((char*)c->buf[0] + blk)));
   NCCLCHK(rccl().AllGather(c->buf[0], c->buf[1], blk, ncclInt8, c->nccl, s->stream));
+  if (!host_out) {   // as mjhmc_comm_allgather_ring
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+  }
   return columns_unpack(s, (const char*)c->buf[1], blk, c->world, columns_per_rank, total, host_out);
 }
 

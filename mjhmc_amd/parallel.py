@@ -201,12 +201,14 @@ class RcclComm(_CommBase):
         self.allreduce_ints([1], 'sum')
 
     # -- the data-path collective: sample columns, device ring to device ring --------------------
-    def allgather_ring(self, dev, slot0, n, stacked, counts):
+    def allgather_ring(self, dev, slot0, n, stacked, counts, root=None):
         """ring slots [slot0, slot0 + n) of every rank's DeviceSampler -> the unsharded sample block,
-        (D, n * N_total) time-major or (D, N_total, n) when ``stacked``."""
+        (D, n * N_total) time-major or (D, N_total, n) when ``stacked``.  ``root``: only that rank re-tiles and downloads
+        the block (the others take part in the collective and return None)."""
         counts = np.ascontiguousarray(counts, dtype=np.int64)
         total = int(counts.sum())
-        out = np.empty((dev.ndims, total, n) if stacked else (dev.ndims, n * total))
+        keep = root is None or int(root) == self.rank
+        out = np.empty((dev.ndims, total, n) if stacked else (dev.ndims, n * total)) if keep else None
         self._lib_mod.check(self.lib.mjhmc_comm_allgather_ring(self.handle, dev.handle, int(slot0), int(n), 1 if stacked else 0,
                                                                self._lib_mod.ptr(counts), self._lib_mod.ptr(out)))
         return out

@@ -225,6 +225,14 @@ def test_rccl_communicator_entry_points(tmp_path):
         s = MarkovJumpHMC(distribution=d, epsilon=0.05, beta=0.2, num_leapfrog_steps=4, seed=6, comm=c, resample=False)
         outs.append(s.sample(3))
     assert np.array_equal(outs[0], outs[1])
+    # the root-only form of the data-path collective (mjhmc_comm_allgather_ring with host_out = NULL): a rank that is not
+    # the root runs the pack and the collective and keeps nothing; the root's block is the all-ranks form's
+    dev = s._dev
+    counts = np.array([40], dtype=np.int64)
+    full = comm.allgather_ring(dev, 0, 3, False, counts)
+    assert np.array_equal(comm.allgather_ring(dev, 0, 3, False, counts, root=0), full)
+    assert comm.allgather_ring(dev, 0, 3, False, counts, root=1) is None          # (this rank is 0: not the root)
+    assert np.array_equal(comm.allgather_ring(dev, 0, 3, True, counts, root=0), comm.allgather_ring(dev, 0, 3, True, counts))
     comm.close()
 
 
