@@ -295,3 +295,42 @@ def test_split_fused_launch_equals_single_launch(kind, D, N, monkeypatch, mode_n
 @pytest.mark.parametrize('mode_name', ['MODE_CONTROL', 'MODE_CTHMC'])
 def test_split_fused_launch_other_sampler_families(mode_name, monkeypatch):
     test_split_fused_launch_equals_single_launch('E_ISO_GAUSS', 64, 263000, monkeypatch, mode_name=mode_name)
+
+
+@pytest.mark.parametrize('kind,D,N,n_iter,p_r,ring', [
+    ('E_FUNNEL_NEAL', 32, 1000, 9, 0.05, False),      # four-wave workgroup tiles, the last one with three live waves and a ragged row count
+    ('E_FUNNEL_NEAL', 32, 255, 6, 0.05, True),        # one workgroup tile, ragged; ring snapshots
+    ('E_FUNNEL_NEAL', 32, 20011, 5, 0.05, False),     # a persistent grid walking several workgroup tiles
+    ('E_FUNNEL_NEAL', 32, 700, 8, 2.0, False),        # refresh rate 2: more than 32 cold caches per workgroup -- the pool overflows
+    ('E_FUNNEL_NEAL', 31, 513, 7, 0.3, True),         #   every iteration, the lanes beyond it integrate in their own wave
+    ('E_FUNNEL_NEAL', 21, 300, 70, 0.05, False),      # short rows; across the 64-iteration launch boundary
+    ('E_FUNNEL_NEAL', 16, 1500, 9, 0.1, True),        # two-lane groups (a pooled particle on two lanes of ONE chunk column each)
+    ('E_FUNNEL_NEAL', 11, 65, 7, 0.1, False),         # two-lane groups, short rows
+    ('E_FUNNEL_NEAL', 32, 300, 5, 0.0, False),        # no refresh at all: the pool is empty after the first iteration
+])
+def test_relay_kernel_equals_the_one_wave_kernel(kind, D, N, n_iter, p_r, ring, monkeypatch):
+    """mjhmc_fused_rows_relay_kernel (the product's fused row form since round 6: four-wave workgroups pool their cold caches,
+    the pool's inverse-L trajectories relayed in four parts on two lanes per particle) against mjhmc_fused_rows_kernel (round
+    5's one-wave workgroups, every wave integrating the inverse-L proposal in all its lanes; the test build with
+    MJHMC_NO_RELAY=1): state, scalars, ring and tallies bit for bit, from a chain's first iteration (every cache cold: the
+    pool holds 32 of a workgroup's 256) through warm ones, over several calls."""
+    (a, b), _lib = _pair(kind, D, N, 0, params=[3.0] if kind == 'E_FUNNEL_NEAL' else [1.0], scale=0.7, libs='ph')
+    L = 5
+    for s in (a, b):
+        s.set_hparams(0.05, L, p_r, 1.0, 0.5)
+        if ring:
+            s.ring_alloc(n_iter)
+    for call in range(3):
+        monkeypatch.delenv('MJHMC_NO_RELAY', raising=False)
+        sa, da = a.iterate(n_iter, ring_slot0=0) if ring else a.iterate(n_iter)
+        monkeypatch.setenv('MJHMC_NO_RELAY', '1')
+        sb, db = b.iterate(n_iter, ring_slot0=0) if ring else b.iterate(n_iter)
+        monkeypatch.delenv('MJHMC_NO_RELAY', raising=False)
+        assert da == db == n_iter
+        assert [_stats_tuple(t) for t in sa] == [_stats_tuple(t) for t in sb], call
+        _same_state(a, b, _lib)
+        if ring:
+            assert bits_equal(a.ring_read(0, n_iter), b.ring_read(0, n_iter))
+            assert bits_equal(a.ring_read_dwell(0, n_iter), b.ring_read_dwell(0, n_iter))
+    a.close()
+    b.close()

@@ -1,4 +1,4 @@
-"""Random shapes through the row-form kernels of the funnels: a fused call (mjhmc_fused_rows_kernel, ring snapshots included)
+"""Random shapes through the row-form kernels of the funnels: a fused call (mjhmc_fused_rows_relay_kernel, ring snapshots included)
 against the same iterations one call at a time (below 16 384 particles: the jump kernel, a group of lanes per particle;
 above: the trajectory launch in row form + the jump-process launch) -- state, scalars, ring and counters bit for bit.
 usage: python tools/fuzz_rows.py [seconds, default 60] [seed]"""
