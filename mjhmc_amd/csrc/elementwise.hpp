@@ -2669,13 +2669,15 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       const bool isL = k == 0, isF = k == 1, isR = k == 2;
       const bool more = it + 1 < n_it;
       if (more) pool_alloc(alive && !isL, (epoch + 1) & 1);   // the next iteration's cold caches: every move but L
+      if (!isL) {   // (the movers' lanes only: register moves under their execution mask instead of two selects per value in all lanes)
 #pragma unroll
-      for (int j = 0; j < G; ++j)
+        for (int j = 0; j < G; ++j)
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          x[j][e] = isL ? x[j][e] : x0[j][e];
-          v[j][e] = isL ? v[j][e] : (isF ? -v0[j][e] : v0[j][e]);
-        }
+          for (int e = 0; e < E; ++e) {
+            x[j][e] = x0[j][e];
+            v[j][e] = isF ? -v0[j][e] : v0[j][e];
+          }
+      }
       EXn = isL ? EXL : EX0;
       EVn = isL ? EVL : EV0;
       Hc = isL ? H0 : (T)__builtin_nan("");   // L: the pre-move state becomes the cached inverse-L state; F, R: clear_flf_cache
@@ -2718,6 +2720,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
         wave_lds_fence();
       }
       ROWS_STAMP(10);
+      if (more) slot = pool_write(alive && !isL, x, v);   // (in front of the bookkeeping: its LDS writes land behind it)
       // bookkeeping of iteration `it`; the successor state becomes the next iteration's pre-move state
       if (bad && alive) first_bad = min(first_bad, it);
       const unsigned long long b0 = __ballot(alive && isL), b1 = __ballot(alive && isF), b3 = __ballot(alive && !warm);
@@ -2738,7 +2741,6 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       key.tick_lo += 1u;
       ++epoch;
       ROWS_STAMP(11);
-      if (more) slot = pool_write(alive && !isL, x, v);
       ROWS_STAMP(12);
     }  // fused iterations
     if (wave_live) {
