@@ -61,7 +61,8 @@ static int ilog2(int v) {
 // fused MarkovJumpHMC launches of this sampler run in row form (elementwise.hpp: mjhmc_fused_rows_kernel)
 static bool fused_rows(const mjhmc_sampler* s) {
   const int kind = s->en->ep.kind;
-  return (kind == MJHMC_E_FUNNEL_NEAL || kind == MJHMC_E_FUNNEL_REF) && s->dtype == MJHMC_F64 && s->sh.E == 8 &&
+  return (kind == MJHMC_E_FUNNEL_NEAL || kind == MJHMC_E_FUNNEL_REF || kind == MJHMC_E_MM_GAUSS) && s->dtype == MJHMC_F64 &&
+         s->sh.E == 8 &&
          fused_rows_shape(s->mode, s->sh.logG, ab_flags());
 }
 

@@ -407,6 +407,64 @@ struct MMGaussF {
     b = group_sum(b, m.G);
     return -(T)log(exp(-a) + exp(-b));
   }
+  // the row form (round 6; the protocol of the funnels below): the whole particle in one lane -- exp(4 sep x_0), once per
+  // particle and leapfrog step, is paid once per particle instead of once per lane of its group -- and, for the relay of
+  // mjhmc_fused_rows_relay_kernel, half a row per lane of a pair.  The same operations in the same order as prep / grad /
+  // energy: the same bits (tests/test_gpu_fused.py, tools/fuzz_rows.py).
+  static constexpr bool kRowForm = true;
+  template <int E>
+  __device__ __forceinline__ T kick(T ck, T xe, T ve, int e, int d, const Ctx& c) const {
+    return __builtin_fma(ck, grad<E>(xe, e, d, c, Local<E>{}), ve);   // kick_fma's form for an energy without a scaled kick
+  }
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ Ctx prep_rows(const T (&x)[G][E], const XK& = XK{}) const {
+    return Ctx{(T)exp(T(4) * sep0 * x[0][0])};
+  }
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int, const XK& = XK{}) const {
+    return Ctx{(T)exp(T(4) * sep0 * dpp_mov<0xA0>(xh[0][0]))};   // quad_perm [0, 0, 2, 2]: the even lane's x[0][0]
+  }
+  template <int E, int G>
+  __device__ __forceinline__ T energy_rows(const T (&x)[G][E]) const {
+    T pa[G], pb[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      T a = 0, b = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const T s = (((e / 2) * G + j) * 2 + (e % 2) == 0) ? sep0 : T(0);   // row_dim<G>(j, e) == 0
+        a += (x[j][e] + s) * (x[j][e] + s);
+        b += (x[j][e] - s) * (x[j][e] - s);
+      }
+      pa[j] = a;
+      pb[j] = b;
+    }
+    T a, b;
+    if constexpr (G == 1) { a = pa[0]; b = pb[0]; }
+    else if constexpr (G == 2) { a = pa[0] + pa[1]; b = pb[0] + pb[1]; }
+    else { a = (pa[0] + pa[1]) + (pa[2] + pa[3]); b = (pb[0] + pb[1]) + (pb[2] + pb[3]); }   // rows_sum
+    return -(T)log(exp(-a) + exp(-b));
+  }
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ T energy_pair(const T (&xh)[G / 2][E], int h, const XK& = XK{}) const {
+    constexpr int GH = G / 2;
+    T pa[GH], pb[GH];
+#pragma unroll
+    for (int jj = 0; jj < GH; ++jj) {
+      T a = 0, b = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const T s = (e == 0 && jj == 0 && h == 0) ? sep0 : T(0);   // dim 0 is the even lane's first coordinate
+        a += (xh[jj][e] + s) * (xh[jj][e] + s);
+        b += (xh[jj][e] - s) * (xh[jj][e] - s);
+      }
+      pa[jj] = a;
+      pb[jj] = b;
+    }
+    const T ma = (GH == 1) ? pa[0] : pa[0] + pa[GH - 1], mb = (GH == 1) ? pb[0] : pb[0] + pb[GH - 1];
+    const T a = ma + dpp_mov<0xB1>(ma), b = mb + dpp_mov<0xB1>(mb);   // the pair's sums: (p0 + p1) + (p2 + p3), as rows_sum
+    return -(T)log(exp(-a) + exp(-b));
+  }
 };
 
 // group_sum()'s pairing on the G per-lane partial sums of a particle held by ONE lane (the row form): the same bits
@@ -526,6 +584,14 @@ struct FunnelNealF {
   __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) const {
     return funnel_prep_pair<Ctx, T, E, G, XK>(xh, h, xk);
   }
+  template <int E, int G>
+  __device__ __forceinline__ T energy_rows(const T (&x)[G][E]) const {
+    return energy_of(funnel_prep_rows<Ctx, T, E, G>(x));
+  }
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ T energy_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) const {
+    return energy_of(funnel_prep_pair<Ctx, T, E, G, XK>(xh, h, xk));
+  }
 };
 
 // Funnel exactly as coded (tf_distributions.py:157-165): E = -(D-1) x0^2/s^2 - e^{-x0} sum_k x_k^2
@@ -584,6 +650,14 @@ struct FunnelRefF {
   template <int E, int G, class XK = NoExpK>
   __device__ __forceinline__ Ctx prep_rows_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) const {
     return funnel_prep_pair<Ctx, T, E, G, XK>(xh, h, xk);
+  }
+  template <int E, int G>
+  __device__ __forceinline__ T energy_rows(const T (&x)[G][E]) const {
+    return energy_of(funnel_prep_rows<Ctx, T, E, G>(x));
+  }
+  template <int E, int G, class XK = NoExpK>
+  __device__ __forceinline__ T energy_pair(const T (&xh)[G / 2][E], int h, const XK& xk = XK{}) const {
+    return energy_of(funnel_prep_pair<Ctx, T, E, G, XK>(xh, h, xk));
   }
 };
 
@@ -2166,7 +2240,7 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
         for (int e = 0; e < E; ++e) v[j][e] = -v[j][e];
       trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
       const T ev = kinetic_rows<T, E, G>(v);
-      const T ex = en.energy_of(en.template prep_rows<E, G>(x));
+      const T ex = en.template energy_rows<E, G>(x);
       if (live) a.Hwork[p] = ex + ev;
     }
     return;
@@ -2181,7 +2255,7 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
   }
   trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
   const T EVL = kinetic_rows<T, E, G>(v);
-  const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
+  const T EXL = en.template energy_rows<E, G>(x);
   {
     Stage tx, tv;
     rt.from_rows(x, tx);
@@ -2285,7 +2359,7 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
           for (int e = 0; e < E; ++e) v[j][e] = -v[j][e];
         trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
         const T ev = kinetic_rows<T, E, G>(v);
-        const T ex = en.energy_of(en.template prep_rows<E, G>(x));
+        const T ex = en.template energy_rows<E, G>(x);
         if (!warm) Hflf = ex + ev;
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -2298,7 +2372,7 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
       // forward proposal L
       trajectory_rows<En, T, E, G>(en, x, v, a.L, a.eps, a.chalf);
       const T EVL = kinetic_rows<T, E, G>(v);
-      const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
+      const T EXL = en.template energy_rows<E, G>(x);
       const T HL = EXL + EVL;
       bool bad = false;
       decide<T, false>(a, key, m1, H0, HL, Hflf, pc, pid, k, dwell, bad);
@@ -2561,7 +2635,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       trajectory_pair_part<En, T, E, G>(en, px, pv, h, ph == 0, ph * L / W, (ph + 1) * L / W, L, a.eps, a.chalf, xk);
       if (ph == W - 1) {
         const T ev = kinetic_pair<T, E, G>(pv);
-        const T ex = en.energy_of(en.template prep_rows_pair<E, G>(px, h));
+        const T ex = en.template energy_pair<E, G>(px, h, xk);
         if (mine && h == 0) pool_H[r] = ex + ev;
       } else if (mine) {
         V* dst = pool + h * GH * PR + r;
@@ -2636,7 +2710,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
           for (int e = 0; e < E; ++e) v[j][e] = -v[j][e];
         trajectory_rows<En, T, E, G>(en, x, v, L, a.eps, a.chalf);
         const T ev = kinetic_rows<T, E, G>(v);
-        const T ex = en.energy_of(en.template prep_rows<E, G>(x));
+        const T ex = en.template energy_rows<E, G>(x);
         if (in_wave) Hflf = ex + ev;
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -2656,7 +2730,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       }
       ROWS_STAMP(5);
       const T EVL = kinetic_rows<T, E, G>(v);
-      const T EXL = en.energy_of(en.template prep_rows<E, G>(x));
+      const T EXL = en.template energy_rows<E, G>(x);
       const T HL = EXL + EVL;
       ROWS_STAMP(6);
       (void)lds_wait_seg(&relay_flag, W * (epoch + 1));

@@ -51,6 +51,9 @@ def _stats_tuple(st):
     ('E_FUNNEL_NEAL', 11, 65, 'MODE_MJHMC', 7),       #   two-lane groups, short rows
     ('E_ROUGH_WELL', 4, 48, 'MODE_MJHMC', 8),
     ('E_MM_GAUSS', 3, 40, 'MODE_MJHMC', 8),
+    ('E_MM_GAUSS', 32, 300, 'MODE_MJHMC', 6),         # the mixture in row form too (round 6): full rows of four-lane groups,
+    ('E_MM_GAUSS', 27, 20011, 'MODE_MJHMC', 5),       #   short rows + a persistent grid (trajectory launch in row form on the single-iteration side),
+    ('E_MM_GAUSS', 12, 700, 'MODE_MJHMC', 9),         #   two-lane groups
     ('E_ROUGH_WELL', 40, 200, 'MODE_CONTROL', 6),
     ('E_ISO_GAUSS', 16, 200, 'MODE_CONTROL', 12),
     ('E_ISO_GAUSS', 24, 77, 'MODE_CTHMC', 12),
@@ -307,6 +310,8 @@ def test_split_fused_launch_other_sampler_families(mode_name, monkeypatch):
     ('E_FUNNEL_NEAL', 16, 1500, 9, 0.1, True),        # two-lane groups (a pooled particle on two lanes of ONE chunk column each)
     ('E_FUNNEL_NEAL', 11, 65, 7, 0.1, False),         # two-lane groups, short rows
     ('E_FUNNEL_NEAL', 32, 300, 5, 0.0, False),        # no refresh at all: the pool is empty after the first iteration
+    ('E_MM_GAUSS', 32, 1000, 7, 0.1, True),           # the mixture's row form (exp(4 sep x_0) once per particle; a division per coordinate)
+    ('E_MM_GAUSS', 14, 513, 6, 0.5, False),           #   two-lane groups, the pool overflowing
 ])
 def test_relay_kernel_equals_the_one_wave_kernel(kind, D, N, n_iter, p_r, ring, monkeypatch):
     """mjhmc_fused_rows_relay_kernel (the product's fused row form since round 6: four-wave workgroups pool their cold caches,
@@ -314,7 +319,7 @@ def test_relay_kernel_equals_the_one_wave_kernel(kind, D, N, n_iter, p_r, ring, 
     5's one-wave workgroups, every wave integrating the inverse-L proposal in all its lanes; the test build with
     MJHMC_NO_RELAY=1): state, scalars, ring and tallies bit for bit, from a chain's first iteration (every cache cold: the
     pool holds 32 of a workgroup's 256) through warm ones, over several calls."""
-    (a, b), _lib = _pair(kind, D, N, 0, params=[3.0] if kind == 'E_FUNNEL_NEAL' else [1.0], scale=0.7, libs='ph')
+    (a, b), _lib = _pair(kind, D, N, 0, params=[1.0] if kind == 'E_FUNNEL_REF' else [3.0], scale=0.7, libs='ph')
     L = 5
     for s in (a, b):
         s.set_hparams(0.05, L, p_r, 1.0, 0.5)

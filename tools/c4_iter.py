@@ -1,5 +1,6 @@
 """C4 (Neal funnel 32 x N, L 15, float64): a few compacted iterations, for profiler runs.
-usage: python tools/c4_iter.py [N] [iterations] [L] [beta]      (test build when MJHMC_HIP_LIB names it: MJHMC_NO_ROWS, MJHMC_FUSE_BELOW)"""
+usage: python tools/c4_iter.py [N] [iterations] [L] [beta] [funnel|mm]      (test build when MJHMC_HIP_LIB names it: MJHMC_NO_ROWS,
+MJHMC_NO_RELAY, MJHMC_FUSE_BELOW; mm: MultimodalGaussian 32 x N instead of the funnel)"""
 import os
 import sys
 
@@ -17,7 +18,11 @@ rng = np.random.RandomState(0)
 X0 = rng.randn(32, N)
 X0[0] *= 3.0
 X0[1:] *= np.exp(X0[0] / 2.)
-en = engine.DeviceEnergy(ctx, _lib.E_FUNNEL_NEAL, 32, [3.0])
+kind = sys.argv[5] if len(sys.argv) > 5 else 'funnel'
+if kind == 'mm':
+    X0 = rng.randn(32, N)
+    X0[0] += 6.0 * (rng.rand(N) < 0.5) - 3.0
+en = engine.DeviceEnergy(ctx, _lib.E_MM_GAUSS if kind == 'mm' else _lib.E_FUNNEL_NEAL, 32, [3.0])
 smp = engine.DeviceSampler(en, X0, seed=1)
 smp.set_hparams(0.05, L, -np.log(1.0 - beta) * 0.5, 1.0)
 for _ in range(3):

@@ -27,7 +27,8 @@ def main():
     while time.time() - t0 < budget:
         D = int(rs.choice([9, 10, 15, 16, 17, 21, 31, 32, int(rs.randint(9, 33))]))
         N = int(rs.choice([1, 63, 64, 65, 127, 128, 1000, int(rs.randint(1, 5000)), int(rs.randint(16384, 40000))]))
-        kind = _lib.E_FUNNEL_NEAL if rs.rand() < 0.8 else _lib.E_FUNNEL_REF
+        u = rs.rand()
+        kind = _lib.E_FUNNEL_NEAL if u < 0.6 else (_lib.E_FUNNEL_REF if u < 0.75 else _lib.E_MM_GAUSS)   # the energies with a row form
         n_iter = int(rs.choice([2, 3, 7, 20, 64, 65, 70]))
         if N > 10000:
             n_iter = min(n_iter, 7)

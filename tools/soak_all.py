@@ -15,7 +15,7 @@ from mjhmc_amd import engine, _lib  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 ctx = engine.context(0)
-for key in ('c2', 'c4', 'c3', 'c3f64', 'c5'):
+for key in ('c2', 'c4', 'c3', 'c3f64', 'c5', 'c5bf16'):
     w = dict(bench.WORKLOADS[key])
     kind = {'iso': _lib.E_ISO_GAUSS, 'funnel': _lib.E_FUNNEL_NEAL, 'pot': _lib.E_PRODUCT_OF_T, 'sic': _lib.E_SPARSE_CODE}[w['kind']]
     params = w['params']
