@@ -1674,6 +1674,10 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // (the funnels in row form -- a lane per particle, mjhmc_fused_rows_kernel -- are bound by the vector pipe at any batch size)
   const bool rows = fused_rows(s) && !test_env("MJHMC_FUSE_BELOW");
   const bool fusable = !s->en->is_dense() && !s->en->is_user() && (gaussian || rows || s->N < fuse_below || s->D <= 4);
+  // (Measured in round 6 and dropped: a call of ONE iteration through the fused row kernel too -- the state read and written
+  // once with the jump process inside the launch, no second launch, no list scan: 0.346 ms per call against the 0.270 of
+  // trajectory launch + jump-process launch at C4's size, equal at N/8.  One wave per SIMD overlaps nothing of a tile's
+  // loads and stores with its compute, and a one-iteration launch is nothing but tiles' first and last iterations.)
   if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !test_env("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);

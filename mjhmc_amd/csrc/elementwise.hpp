@@ -2661,6 +2661,12 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
     const bool alive = wave_live && p < a.N;
     const int64_t pc = alive ? p : a.N - 1;   // padding rows: somebody's scalars, nothing of theirs is stored
     T x[G][E], v[G][E];
+    // the particle's scalars are asked for FIRST: behind the rows' way through the tile (whose fences the compiler does not
+    // move loads across) their round trip to memory stood alone at the head of every tile -- a lone wave hides nothing
+    stamp_on = gt == (int64_t)blockIdx.x;
+    stamp_it = 0;
+    ROWS_STAMP(13);
+    T EX0 = a.EX_in[pc], EV0 = a.EV_in[pc], Hcached = a.Hflf_in[pc];
     if (wave_live) {
       Stage tx, tv;
       rt.fetch(a.X_in, base, tx);
@@ -2676,12 +2682,12 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
           v[j][e] = T(0);
         }
     }
-    T EX0 = a.EX_in[pc], EV0 = a.EV_in[pc], Hcached = a.Hflf_in[pc];
     const uint32_t pid = (uint32_t)(a.first_pid + p);
     RngKey key = a.key;
     int k = 0;
     double dwell = 0.0;
     T EXn = EX0, EVn = EV0, Hc = Hcached;
+    ROWS_STAMP(14);
     pool_alloc(alive && !(Hcached == Hcached), epoch & 1);
     int slot = pool_write(alive && !(Hcached == Hcached), x, v);
 #pragma unroll 1
@@ -2831,6 +2837,8 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       a.dwell[p] = dwell;
       a.trans[p] = (uint8_t)k;
     }
+    stamp_it = 0;
+    ROWS_STAMP(15);
   }
   for (int o = 32; o > 0; o >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, o));
   if (first_bad != 0x7fffffff && lane == 0) {

@@ -25,7 +25,16 @@ if kind == 'mm':
 en = engine.DeviceEnergy(ctx, _lib.E_MM_GAUSS if kind == 'mm' else _lib.E_FUNNEL_NEAL, 32, [3.0])
 smp = engine.DeviceSampler(en, X0, seed=1)
 smp.set_hparams(0.05, L, -np.log(1.0 - beta) * 0.5, 1.0)
-for _ in range(3):
-    smp.iterate(it)
-    smp.sync()
-print('total_ms per iteration', smp.last_timing()['total_ms'] / it)
+if it == 1:      # the sampling_iteration() path: calls of ONE iteration; the mean over 20 warm calls
+    tot = 0.0
+    for k in range(30):
+        smp.iterate(1)
+        smp.sync()
+        if k >= 10:
+            tot += smp.last_timing()['total_ms']
+    print('total_ms per one-iteration call', tot / 20)
+else:
+    for _ in range(3):
+        smp.iterate(it)
+        smp.sync()
+    print('total_ms per iteration', smp.last_timing()['total_ms'] / it)

@@ -48,3 +48,11 @@ print('successor        ', ' '.join('%8.0f' % (st[w, :, 9] - st[w, :, 8]).mean()
 print('refresh          ', ' '.join('%8.0f' % (st[w, :, 10] - st[w, :, 9]).mean() for w in range(4)))
 print('tally            ', ' '.join('%8.0f' % (st[w, :, 11] - st[w, :, 10]).mean() for w in range(4)))
 print('deposit          ', ' '.join('%8.0f' % (st[w, :, 12] - st[w, :, 11]).mean() for w in range(4)))
+
+# the tile's fixed part (first workgroup tile): rows + scalars in (13 -> 14), first iteration top (14 -> it 0's stamp 0),
+# last iteration's end -> rows out and stored (stamp 12 of the last iteration -> 15)
+b = buf.astype(np.int64)
+print('tile: load      ', ' '.join('%8.0f' % (b[w, 0, 14] - b[w, 0, 13]) for w in range(4)))
+print('tile: to it 0   ', ' '.join('%8.0f' % (b[w, 0, 0] - b[w, 0, 14]) for w in range(4)))
+print('tile: store     ', ' '.join('%8.0f' % (b[w, 0, 15] - b[w, n_it - 1, 12]) for w in range(4)))
+print('tile: whole     ', ' '.join('%8.0f' % (b[w, 0, 15] - b[w, 0, 13]) for w in range(4)), ' = %d iterations + the fixed part' % n_it)
