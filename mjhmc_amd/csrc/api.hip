@@ -48,7 +48,7 @@ static const char* test_env(const char*) { return nullptr; }
 static int ab_flags() {
   return (test_env("MJHMC_NO_BLOCK_DECIDE") ? kAbNoBlockDecide : 0) | (test_env("MJHMC_NO_WPP") ? kAbNoWpp : 0) |
          (test_env("MJHMC_NO_QUAD") ? kAbNoQuad : 0) | (test_env("MJHMC_NO_ROWS") ? kAbNoRows : 0) |
-         (test_env("MJHMC_NO_RELAY") ? kAbNoRelay : 0);
+         (test_env("MJHMC_NO_RELAY") ? kAbNoRelay : 0) | (test_env("MJHMC_FORCE_RELAY") ? kAbForceRelay : 0);
 }
 
 static int ilog2(int v) {
@@ -61,6 +61,10 @@ static int ilog2(int v) {
 // fused MarkovJumpHMC launches of this sampler run in row form (elementwise.hpp: mjhmc_fused_rows_kernel)
 static bool fused_rows(const mjhmc_sampler* s) {
   const int kind = s->en->ep.kind;
+  // (the mixture's force is a division per coordinate: its row form pays through the relay kernel only -- 0.500 ms against
+  // the group form's 0.535 at 32 x 10^6, L = 15, and 0.734 in the one-wave row kernel -- so it takes the row form where the
+  // relay runs, launch_fused_rows: from MMGaussF::kRelayMinL leapfrog steps up)
+  if (kind == MJHMC_E_MM_GAUSS && s->L < MMGaussF<double>::kRelayMinL && !test_env("MJHMC_FORCE_RELAY")) return false;
   return (kind == MJHMC_E_FUNNEL_NEAL || kind == MJHMC_E_FUNNEL_REF || kind == MJHMC_E_MM_GAUSS) && s->dtype == MJHMC_F64 &&
          s->sh.E == 8 &&
          fused_rows_shape(s->mode, s->sh.logG, ab_flags());

@@ -412,6 +412,9 @@ struct MMGaussF {
   // mjhmc_fused_rows_relay_kernel, half a row per lane of a pair.  The same operations in the same order as prep / grad /
   // energy: the same bits (tests/test_gpu_fused.py, tools/fuzz_rows.py).
   static constexpr bool kRowForm = true;
+  // (a float64 division per coordinate and step: the relay's saved trajectory outweighs its hand-overs from ~4 steps up --
+  // 32 x 10^6, L = 5: 0.288 ms in the relay kernel, 0.308 in the group form; the funnels' break-even is 12 steps)
+  static constexpr int kRelayMinL = 4;
   template <int E>
   __device__ __forceinline__ T kick(T ck, T xe, T ve, int e, int d, const Ctx& c) const {
     return __builtin_fma(ck, grad<E>(xe, e, d, c, Local<E>{}), ve);   // kick_fma's form for an energy without a scaled kick
@@ -666,7 +669,7 @@ struct FunnelRefF {
 // ------------------------------------------------------------------------------------------
 
 // launch_jump_t's A/B flags (JumpArgs::ab): take the generic instance instead of a specialised lane mapping
-constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4, kAbNoRows = 8, kAbNoRelay = 16;
+constexpr int kAbNoBlockDecide = 1, kAbNoWpp = 2, kAbNoQuad = 4, kAbNoRows = 8, kAbNoRelay = 16, kAbForceRelay = 32;
 
 template <typename T>
 struct JumpArgs {
@@ -2517,6 +2520,16 @@ __device__ __forceinline__ void lds_seg_set(unsigned long long* flag, int done, 
 }
 
 constexpr int kRelayWaves = 4;
+constexpr int kRelayMinL = 12;   // leapfrog steps from which the relay kernel is the faster fused row form (launch_fused_rows);
+                                 // an energy may state its own (En::kRelayMinL)
+template <class En, typename = void>
+struct RelayMinL {
+  static constexpr int value = kRelayMinL;
+};
+template <class En>
+struct RelayMinL<En, decltype((void)En::kRelayMinL)> {
+  static constexpr int value = En::kRelayMinL;
+};
 constexpr int kPoolRows = 32;   // pooled particles per workgroup and iteration: two lanes each
 
 template <class En, typename T, int E, int LOGG, bool FULL>
@@ -3199,7 +3212,11 @@ inline void launch_fused_rows(const JumpArgs<T>& a, const En& en, hipStream_t st
     resident_relay = std::max(1, per_cu_relay) * std::max(1, cus);
   }
   const int64_t tiles = a.Npad >> 6;
-  if (!(a.ab & kAbNoRelay)) {
+  // The relay trades a trajectory per wave and iteration for a quarter of one + four hand-overs through LDS: it wins from
+  // ~12 leapfrog steps up (tools/sweep_L.py 32 1000000 funnel, profiles/r06/sweep_L_c4.txt: relay 0.110 + 0.0045 L ms per
+  // iteration, one-wave kernel 0.071 + 0.0078 L); shorter trajectories keep the one-wave kernel.  The same bits either way.
+  const bool relay = (a.ab & kAbForceRelay) || (!(a.ab & kAbNoRelay) && a.L >= RelayMinL<En>::value);
+  if (relay) {
     const unsigned grid = (unsigned)std::min<int64_t>((tiles + kRelayWaves - 1) / kRelayWaves, resident_relay);
     hipLaunchKernelGGL((mjhmc_fused_rows_relay_kernel<En, T, E, LOGG, FULL>), dim3(grid), dim3(64 * kRelayWaves), 0, st, a, en);
     return;

@@ -314,28 +314,32 @@ def test_split_fused_launch_other_sampler_families(mode_name, monkeypatch):
     ('E_MM_GAUSS', 14, 513, 6, 0.5, False),           #   two-lane groups, the pool overflowing
 ])
 def test_relay_kernel_equals_the_one_wave_kernel(kind, D, N, n_iter, p_r, ring, monkeypatch):
-    """mjhmc_fused_rows_relay_kernel (the product's fused row form since round 6: four-wave workgroups pool their cold caches,
-    the pool's inverse-L trajectories relayed in four parts on two lanes per particle) against mjhmc_fused_rows_kernel (round
-    5's one-wave workgroups, every wave integrating the inverse-L proposal in all its lanes; the test build with
-    MJHMC_NO_RELAY=1): state, scalars, ring and tallies bit for bit, from a chain's first iteration (every cache cold: the
-    pool holds 32 of a workgroup's 256) through warm ones, over several calls."""
-    (a, b), _lib = _pair(kind, D, N, 0, params=[1.0] if kind == 'E_FUNNEL_REF' else [3.0], scale=0.7, libs='ph')
-    L = 5
-    for s in (a, b):
-        s.set_hparams(0.05, L, p_r, 1.0, 0.5)
-        if ring:
-            s.ring_alloc(n_iter)
-    for call in range(3):
-        monkeypatch.delenv('MJHMC_NO_RELAY', raising=False)
-        sa, da = a.iterate(n_iter, ring_slot0=0) if ring else a.iterate(n_iter)
-        monkeypatch.setenv('MJHMC_NO_RELAY', '1')
-        sb, db = b.iterate(n_iter, ring_slot0=0) if ring else b.iterate(n_iter)
-        monkeypatch.delenv('MJHMC_NO_RELAY', raising=False)
-        assert da == db == n_iter
-        assert [_stats_tuple(t) for t in sa] == [_stats_tuple(t) for t in sb], call
-        _same_state(a, b, _lib)
-        if ring:
-            assert bits_equal(a.ring_read(0, n_iter), b.ring_read(0, n_iter))
-            assert bits_equal(a.ring_read_dwell(0, n_iter), b.ring_read_dwell(0, n_iter))
-    a.close()
-    b.close()
+    """mjhmc_fused_rows_relay_kernel (four-wave workgroups pool their cold caches, the pool's inverse-L trajectories relayed
+    in four parts on two lanes per particle: the product's fused row form from kRelayMinL = 12 leapfrog steps up) against
+    mjhmc_fused_rows_kernel (round 5's one-wave workgroups, every wave integrating the inverse-L proposal in all its lanes:
+    the form shorter trajectories keep): state, scalars, ring and tallies bit for bit, from a chain's first iteration (every
+    cache cold: the pool holds 32 of a workgroup's 256) through warm ones, over several calls.  L = 5 with both kernels
+    FORCED (test build: MJHMC_FORCE_RELAY / MJHMC_NO_RELAY; parts of one or two leapfrog steps, one of them empty), then
+    L = 13 with the product library's own choice -- the relay -- against the forced one-wave kernel."""
+    for L, libs in ((5, 'hh'), (13, 'ph')):
+        (a, b), _lib = _pair(kind, D, N, 0, params=[1.0] if kind == 'E_FUNNEL_REF' else [3.0], scale=0.7, libs=libs)
+        for s in (a, b):
+            s.set_hparams(0.05 if L == 5 else 0.02, L, p_r, 1.0, 0.5)
+            if ring:
+                s.ring_alloc(n_iter)
+        for call in range(3):
+            monkeypatch.delenv('MJHMC_NO_RELAY', raising=False)
+            monkeypatch.setenv('MJHMC_FORCE_RELAY', '1')
+            sa, da = a.iterate(n_iter, ring_slot0=0) if ring else a.iterate(n_iter)
+            monkeypatch.delenv('MJHMC_FORCE_RELAY', raising=False)
+            monkeypatch.setenv('MJHMC_NO_RELAY', '1')
+            sb, db = b.iterate(n_iter, ring_slot0=0) if ring else b.iterate(n_iter)
+            monkeypatch.delenv('MJHMC_NO_RELAY', raising=False)
+            assert da == db == n_iter
+            assert [_stats_tuple(t) for t in sa] == [_stats_tuple(t) for t in sb], (L, call)
+            _same_state(a, b, _lib)
+            if ring:
+                assert bits_equal(a.ring_read(0, n_iter), b.ring_read(0, n_iter))
+                assert bits_equal(a.ring_read_dwell(0, n_iter), b.ring_read_dwell(0, n_iter))
+        a.close()
+        b.close()

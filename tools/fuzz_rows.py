@@ -1,6 +1,8 @@
 """Random shapes through the row-form kernels of the funnels: a fused call (mjhmc_fused_rows_relay_kernel, ring snapshots included)
 against the same iterations one call at a time (below 16 384 particles: the jump kernel, a group of lanes per particle;
 above: the trajectory launch in row form + the jump-process launch) -- state, scalars, ring and counters bit for bit.
+With the test build (MJHMC_HIP_LIB=.../libmjhmc_hip_test.so) and MJHMC_FORCE_RELAY=1 the relay kernel takes the short
+trajectories too (parts of one leapfrog step, empty parts).
 usage: python tools/fuzz_rows.py [seconds, default 60] [seed]"""
 import os
 import sys
@@ -32,7 +34,7 @@ def main():
         n_iter = int(rs.choice([2, 3, 7, 20, 64, 65, 70]))
         if N > 10000:
             n_iter = min(n_iter, 7)
-        L = int(rs.choice([0, 1, 2, 5, 9]))
+        L = int(rs.choice([0, 1, 2, 5, 9, 12, 13, 16, 23]))     # (from 12 steps up the fused call is the relay kernel's)
         eps = float(rs.choice([0.01, 0.05, 0.1]))
         with_ring = rs.rand() < 0.5
         X0 = rs.randn(D, N) * 0.7
