@@ -110,6 +110,59 @@ __global__ __launch_bounds__(256) void power_accumulate(const double2* __restric
   atomicAdd(&P[f].x, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Short series straight from the ring (round 6).  At the batch sizes of BASELINE.json a ring holds tens of samples, not
+// thousands (C2: 410 MB per sample): for T <= 32 the transform pipeline above -- gather into [series][time], batched
+// transform, power sums: ~5 passes over a staging copy of the ring -- costs ten times the ONE read of the ring that the
+// lag products need (C2, 16 samples: 17.4 ms against 1.8 ms for recording them).  A thread owns a series (particle p,
+// coordinate d: consecutive threads, consecutive coordinates of a state row -- coalesced), reads its T values (zeros up
+// to the compile-time TT) and adds all LINEAR lag products x[t] x[t + k] into TT accumulators; a persistent grid, partial
+// sums per block, a second small kernel adds the blocks in a fixed order (no atomics: the result does not depend on the
+// schedule).  The circular sums of fft_autocor follow on the host: circ[k] = lin[k] + lin[T - k], circ[0] = lin[0].
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void lag_sums_direct(const T* __restrict__ ring, size_t slot_elems, int pitch, int D, int nT,
+                                                       int64_t n_series, double* __restrict__ partial) {
+  double acc[TT];
+#pragma unroll
+  for (int k = 0; k < TT; ++k) acc[k] = 0.0;
+  const uint32_t uD = (uint32_t)D;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n_series; g += (int64_t)gridDim.x * 256) {
+    // (n_series < 2^32 at every size a device holds: 32-bit division)
+    const uint32_t p = (uint32_t)((uint64_t)g / uD), d = (uint32_t)((uint64_t)g - (uint64_t)p * uD);
+    const size_t off = (size_t)p * pitch + d;
+    double x[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) x[t] = t < nT ? (double)ring[(size_t)t * slot_elems + off] : 0.0;
+#pragma unroll
+    for (int k = 0; k < TT; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int t = 0; t + k < TT; ++t) s = __builtin_fma(x[t], x[t + k], s);
+      acc[k] += s;
+    }
+  }
+  __shared__ double red[4][TT];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < TT; ++k) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < TT) partial[(size_t)blockIdx.x * TT + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int TT>
+__global__ void lag_sums_finish(const double* __restrict__ partial, int n_blocks, double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= TT) return;
+  double s = 0.0;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(size_t)b * TT + k];
+  out[k] = s;
+}
+
 // The most recent pair of plans is kept per thread: building them costs ~10 ms (and ~1 s the first time,
 // when rocFFT loads its kernels), a transform of a few GB of samples ~10 ms.
 struct PlanPair {
@@ -168,12 +221,67 @@ struct ChunkSource {
   const double* host = nullptr;
 };
 
+// test build: MJHMC_AUTOCOR_TRANSFORM=1 sends short rings through the transform pipeline too (the A/B partner of run_direct)
+bool force_transform() {
+#ifdef MJHMC_TEST_HOOKS
+  return std::getenv("MJHMC_AUTOCOR_TRANSFORM") != nullptr;
+#else
+  return false;
+#endif
+}
+
+template <int TT>
+int run_direct_t(hipStream_t st, const RingView& r, int64_t n_series, int T, double* lin, std::string& err) {
+  int device = 0, cus = 0;
+  ACHK(hipGetDevice(&device));
+  ACHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_series + 255) / 256, (int64_t)std::max(1, cus) * 8));
+  DevBuf partial, out;
+  ACHK(hipMalloc(&partial.p, (size_t)n_blocks * TT * sizeof(double)));
+  ACHK(hipMalloc(&out.p, TT * sizeof(double)));
+  const size_t slot_elems = (size_t)r.Npad * r.pitch;
+  if (r.dtype == MJHMC_F64)
+    hipLaunchKernelGGL((lag_sums_direct<double, TT>), dim3(n_blocks), dim3(256), 0, st, (const double*)r.base, slot_elems, r.pitch, r.D,
+                       T, n_series, (double*)partial.p);
+  else if (r.dtype == MJHMC_F32)
+    hipLaunchKernelGGL((lag_sums_direct<float, TT>), dim3(n_blocks), dim3(256), 0, st, (const float*)r.base, slot_elems, r.pitch, r.D, T,
+                       n_series, (double*)partial.p);
+  else
+    hipLaunchKernelGGL((lag_sums_direct<__bf16, TT>), dim3(n_blocks), dim3(256), 0, st, (const __bf16*)r.base, slot_elems, r.pitch, r.D,
+                       T, n_series, (double*)partial.p);
+  ACHK(hipGetLastError());
+  hipLaunchKernelGGL(lag_sums_finish<TT>, dim3(1), dim3(64), 0, st, (const double*)partial.p, n_blocks, (double*)out.p);
+  ACHK(hipGetLastError());
+  double h[TT];
+  ACHK(hipMemcpyAsync(h, out.p, TT * sizeof(double), hipMemcpyDeviceToHost, st));
+  ACHK(hipStreamSynchronize(st));
+  for (int k = 0; k < T; ++k) lin[k] = h[k];
+  return 0;
+}
+
+int run_direct(hipStream_t st, const RingView& r, int64_t n_series, int T, int linear, double* host_out, std::string& err) {
+  double lin[32];
+  int rc;
+  if (T <= 8) rc = run_direct_t<8>(st, r, n_series, T, lin, err);
+  else if (T <= 16) rc = run_direct_t<16>(st, r, n_series, T, lin, err);
+  else rc = run_direct_t<32>(st, r, n_series, T, lin, err);
+  if (rc) return rc;
+  if (linear) {
+    for (int k = 0; k < T; ++k) host_out[k] = lin[k];
+  } else {   // the time index wraps modulo T: the lag-k products that wrap are the lag-(T - k) products
+    host_out[0] = lin[0];
+    for (int k = 1; k < T; ++k) host_out[k] = lin[k] + lin[T - k];
+  }
+  return 0;
+}
+
 int run(hipStream_t st, const ChunkSource& src, int64_t n_series, int T, int linear, double* host_out,
         std::string& err) {
   if (T < 1 || T > (1 << 20) || n_series < 1) {
     err = "autocorrelation needs 1 <= n_samples <= 2^20 and at least one series";
     return MJHMC_ERR_INVALID;
   }
+  if (src.ring && T <= 32 && n_series < ((int64_t)1 << 32) && !force_transform()) return run_direct(st, *src.ring, n_series, T, linear, host_out, err);
   const FftApi* api = fft_api(err);
   if (!api) return MJHMC_ERR_UNSUPPORTED;
   const int M = (linear || T == 1) ? 2 * T : T;  // transform length (a length-1 series is its own zero-padded case)

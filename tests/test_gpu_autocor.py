@@ -57,7 +57,7 @@ def _gaussian(D, N, seed):
 
 
 @pytest.mark.parametrize('cls_name,D,N,T', [('MarkovJumpHMC', 10, 60, 32), ('ControlHMC', 7, 130, 32),
-                                            ('MarkovJumpHMC', 512, 70, 32)])
+                                            ('MarkovJumpHMC', 512, 70, 32), ('MarkovJumpHMC', 10, 60, 48)])   # T = 48: the transform pipeline from the ring
 def test_ring_resident_autocorrelation(cls_name, D, N, T, monkeypatch):
     """calculate_autocorrelation never downloads the samples; a twin sampler's downloaded samples through
     the oracle give the same curve, and the counter traces are those of generate_samples."""
@@ -76,6 +76,7 @@ def test_ring_resident_autocorrelation(cls_name, D, N, T, monkeypatch):
     from mjhmc_amd import engine, _lib
     from tests.helpers import hooks_context
     monkeypatch.setenv('MJHMC_AUTOCOR_STAGING_MB', '1')
+    monkeypatch.setenv('MJHMC_AUTOCOR_TRANSFORM', '1')      # (rings of <= 32 samples: the product sums the lag products directly)
     hctx = hooks_context(0)
     for linear in (False, True):
         want = engine.context(0).autocor(samples, linear=linear)
@@ -92,8 +93,9 @@ def test_ring_resident_autocorrelation(cls_name, D, N, T, monkeypatch):
         smp.iterate(T, ring_slot0=0)
         rings.append(smp.ring_autocor(0, T))
         smp.close()
-    np.testing.assert_allclose(rings[1], rings[0], rtol=1e-13, atol=1e-13 * abs(rings[0][0]))
+    np.testing.assert_allclose(rings[1], rings[0], rtol=1e-12, atol=1e-12 * abs(rings[0][0]))
     monkeypatch.delenv('MJHMC_AUTOCOR_STAGING_MB', raising=False)
+    monkeypatch.delenv('MJHMC_AUTOCOR_TRANSFORM', raising=False)
     # gradient-budget form: the curve of the truncated run
     ac3, e3, g3 = calculate_autocorrelation(cls, _gaussian(D, N, 3), num_grad_steps=60, **kw)
     k = int(np.nonzero(g2 >= 60)[0][0]) + 1 if np.any(g2 >= 60) else None
@@ -181,3 +183,31 @@ def test_g9_generate_samples_and_autocorrelation_match_the_reference(name):
                                                 replay=g9_replay_feed(g), **kw)
     np.testing.assert_allclose(auto, g['fft_autocor'], rtol=0, atol=ATOL)
     assert np.array_equal(e2, g['e_evals']) and np.array_equal(g2, g['grad_evals'])
+
+
+@pytest.mark.parametrize('T', [1, 2, 5, 8, 9, 16, 17, 31, 32])
+@pytest.mark.parametrize('dtype,D', [('float64', 24), ('float32', 36)])
+def test_short_rings_sum_the_lag_products_directly(T, dtype, D):
+    """Rings of up to 32 samples (what a BASELINE-size batch holds) are not transformed: lag_sums_direct reads the ring once
+    and adds the linear lag products per series (csrc/autocor.hip); circular sums = lin[k] + lin[T - k].  Against the
+    oracle's lag sums of the downloaded ring, linear and circular, ragged N and every T that meets a template boundary."""
+    from mjhmc_amd import engine, _lib
+    from tests.helpers import ref_init_weights
+    ctx = engine.context(0)
+    N = 333
+    rs = np.random.RandomState(T + D)
+    if dtype == 'float64':
+        en = engine.DeviceEnergy(ctx, _lib.E_ISO_GAUSS, D, [1.0])
+    else:
+        W, lognu = ref_init_weights(D, D)
+        en = engine.DeviceEnergy(ctx, _lib.E_PRODUCT_OF_T, D, np.concatenate([[float(D)], W.ravel(), np.exp(lognu), np.zeros(D)]))
+    smp = engine.DeviceSampler(en, rs.randn(D, N), seed=3, dtype=dtype)
+    smp.set_hparams(0.2, 4, 0.1, 1.0)
+    smp.ring_alloc(T + 2)
+    smp.iterate(T + 2, ring_slot0=0)
+    samples = smp.ring_read(1, T, stacked=True)                       # a sub-range of the ring's slots
+    lin = smp.ring_autocor(1, T, linear=True)
+    circ = smp.ring_autocor(1, T)
+    np.testing.assert_allclose(lin, aco.linear_lag_sums(samples), rtol=1e-12)
+    np.testing.assert_allclose(circ, aco.circular_lag_sums(samples), rtol=1e-12, atol=1e-12 * abs(circ[0]))
+    smp.close()
