@@ -2601,8 +2601,11 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
         if (sl < PR) {
 #pragma unroll
           for (int c = 0; c < RC; ++c) {
-            pool[c * PR + sl] = V{x[c % G][(c / G) * 2], x[c % G][(c / G) * 2 + 1]};
-            pool[(RC + c) * PR + sl] = V{v[c % G][(c / G) * 2], v[c % G][(c / G) * 2 + 1]};
+            // (the chunks of a row's second half stand 8 rows further round: the two lanes of a pair then read 128 bytes
+            // apart in a bank row instead of on the same banks -- SQ_LDS_BANK_CONFLICT was 1.9 % of the kernel's cycles)
+            const int at = c * PR + ((sl + 8 * ((c % G) / GH)) & (PR - 1));
+            pool[at] = V{x[c % G][(c / G) * 2], x[c % G][(c / G) * 2 + 1]};
+            pool[RC * PR + at] = V{v[c % G][(c / G) * 2], v[c % G][(c / G) * 2 + 1]};
           }
         }
       }
@@ -2634,7 +2637,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       const int l = RT::fresh_lane();
       const int h = l & 1, r = min(l >> 1, n - 1);   // (the lanes beyond the pool repeat its last row; they store nothing)
       const bool mine = (l >> 1) < n;
-      const V* src = pool + h * GH * PR + r;
+      const V* src = pool + h * GH * PR + ((r + 8 * h) & (PR - 1));
 #pragma unroll
       for (int k = 0; k < E / 2; ++k)
 #pragma unroll
@@ -2651,7 +2654,7 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
         const T ex = en.template energy_pair<E, G>(px, h, xk);
         if (mine && h == 0) pool_H[r] = ex + ev;
       } else if (mine) {
-        V* dst = pool + h * GH * PR + r;
+        V* dst = pool + h * GH * PR + ((r + 8 * h) & (PR - 1));
 #pragma unroll
         for (int k = 0; k < E / 2; ++k)
 #pragma unroll
