@@ -2780,9 +2780,10 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
       const unsigned long long bR = __ballot(isR && alive);
       ROWS_STAMP(9);
       if (bR != 0ull) {   // HMCState.R (hmc_state.py:121-129) of the wave's R-movers, a chunk per lane
+        // The lanes draw n sqrt(beta) chunk by chunk into the tile; a mover reads its row of them back and forms
+        // v sqrt(1 - beta) + n sqrt(beta) itself -- the two products and the sum of refresh_stash, the same bits --, so the
+        // old momenta never travel: two LDS round trips in a lone wave's stream instead of four.
         const int nR = (int)__popcll(bR);
-        if (isR && alive) rt.write_own(v);
-        wave_lds_fence();
         const int l = RT::fresh_lane();
         constexpr int RPI = 64 / RC;       // movers per pass: lanes [g RC, (g + 1) RC) redraw the pass's g-th mover
         const int c = l % RC, g_l = l / RC;
@@ -2797,20 +2798,21 @@ __global__ __launch_bounds__(64 * kRelayWaves, 1) void mjhmc_fused_rows_relay_ke
           }
           if (q0 + g_l < nR && (FULL || c < rt.CH)) {
             const int sl = r * 16 + (c ^ (r & 15));
-            const V vc = tile[sl];
             const int d = c * 2;
             double z0, z1;
             normal_pair(key, (uint32_t)(a.first_pid + base + r), (uint32_t)c, z0, z1);
             const T zy = (d + 1 < a.D) ? (T)z1 : T(0);
-            V res;
-            res.x = vc.x * a.r_keep + (T)z0 * a.r_mix;
-            res.y = vc.y * a.r_keep + zy * a.r_mix;
-            tile[sl] = res;
+            tile[sl] = V{(T)z0 * a.r_mix, zy * a.r_mix};
           }
         }
         wave_lds_fence();
         if (isR && alive) {
-          rt.read_own(v);
+          T zr[G][E];
+          rt.read_own(zr);
+#pragma unroll
+          for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[j][e] = v[j][e] * a.r_keep + zr[j][e];
           EVn = kinetic_rows<T, E, G>(v);
         }
         wave_lds_fence();
