@@ -2393,11 +2393,10 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
       Hc = isL ? H0 : (T)__builtin_nan("");   // L: the pre-move state becomes the cached inverse-L state; F, R: clear_flf_cache
       const unsigned long long bR = __ballot(isR && alive);
       if (bR != 0ull) {   // HMCState.R (hmc_state.py:121-129) of the wave's R-movers, a chunk per lane
+        // (round 6, as in the relay kernel: the lanes draw n sqrt(beta) into the tile, a mover reads its row back and forms
+        // v sqrt(1 - beta) + n sqrt(beta) itself -- the old momenta never travel through LDS; the same bits)
         const int nR = (int)__popcll(bR);
-        if (isR && alive) {
-          rtab[(int)__popcll(bR & ((1ull << lane) - 1ull))] = lane;
-          rt.write_own(v);
-        }
+        if (isR && alive) rtab[(int)__popcll(bR & ((1ull << lane) - 1ull))] = lane;
         wave_lds_fence();
         const int l = RT::fresh_lane();
         for (int w = l; w < nR * RC; w += 64) {
@@ -2405,20 +2404,21 @@ __global__ __launch_bounds__(64, 1) void mjhmc_fused_rows_kernel(const JumpArgs<
           if (FULL || c < rt.CH) {
             const int r = rtab[q];
             const int slot = r * 16 + (c ^ (r & 15));
-            const V vc = tile[slot];
             const int d = c * 2;
             double z0, z1;
             normal_pair(key, (uint32_t)(a.first_pid + base + r), (uint32_t)c, z0, z1);
             const T zy = (d + 1 < a.D) ? (T)z1 : T(0);
-            V res;
-            res.x = vc.x * a.r_keep + (T)z0 * a.r_mix;
-            res.y = vc.y * a.r_keep + zy * a.r_mix;
-            tile[slot] = res;
+            tile[slot] = V{(T)z0 * a.r_mix, zy * a.r_mix};
           }
         }
         wave_lds_fence();
         if (isR && alive) {
-          rt.read_own(v);
+          T zr[G][E];
+          rt.read_own(zr);
+#pragma unroll
+          for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[j][e] = v[j][e] * a.r_keep + zr[j][e];
           EVn = kinetic_rows<T, E, G>(v);
         }
         wave_lds_fence();
