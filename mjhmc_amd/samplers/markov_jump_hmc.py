@@ -263,16 +263,26 @@ class HMCBase(object):
             self._iter_evals = []
             self._one(-1, replay)
 
+    # Sharded runs (extension): ``sampler.gather_root = r`` makes sample() with resample=False return the gathered block on
+    # rank r only -- the other ranks take part in the collective, skip the re-tile and the download of a block they do not
+    # want (mjhmc_comm_allgather_ring with host_out = NULL) and get None.  Default None: every rank gets the block, as a
+    # single-process caller of the reference does.
+    gather_root = None
+
     def _stack(self, n_samples, preserve_order, out=None):
         if self._comm is not None and self._comm.on_device:
             # the one data-path collective: device rings all-gathered over RCCL, re-tiled on the receiving GPU
-            res = self._comm.allgather_ring(self._dev, 0, n_samples, bool(preserve_order), self._plan.counts)
+            res = self._comm.allgather_ring(self._dev, 0, n_samples, bool(preserve_order), self._plan.counts, root=self.gather_root)
         else:
             local = self._dev.ring_read(0, n_samples, stacked=bool(preserve_order), out=out if self._comm is None else None)
             if self._comm is None:
                 return local
             from ..parallel import assemble_stacked
             res = assemble_stacked(self._comm, self._plan, local, n_samples, bool(preserve_order))
+            if self.gather_root is not None and int(self.gather_root) != self._comm.rank:
+                res = None
+        if res is None:
+            return None
         if out is None:
             return res
         if out.shape != res.shape or out.dtype != np.float64:      # sharded run: the gathered block lands in the caller's array

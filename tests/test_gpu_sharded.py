@@ -232,6 +232,14 @@ def test_rccl_communicator_entry_points(tmp_path):
     full = comm.allgather_ring(dev, 0, 3, False, counts)
     assert np.array_equal(comm.allgather_ring(dev, 0, 3, False, counts, root=0), full)
     assert comm.allgather_ring(dev, 0, 3, False, counts, root=1) is None          # (this rank is 0: not the root)
+    # ... and through the sampler: gather_root = this rank -> sample() returns the block, another rank -> None
+    d2 = TestGaussian(ndims=24, nbatch=301, sigma=1.3)
+    s2 = MarkovJumpHMC(distribution=d2, epsilon=0.3, beta=0.3, num_leapfrog_steps=5, seed=4242, comm=comm, resample=False)
+    s2.gather_root = 0
+    blk = s2.sample(4, preserve_order=True)
+    assert blk.shape == (24, 301, 4)
+    s2.gather_root = 1
+    assert s2.sample(4, preserve_order=True) is None
     assert np.array_equal(comm.allgather_ring(dev, 0, 3, True, counts, root=0), comm.allgather_ring(dev, 0, 3, True, counts))
     comm.close()
 
