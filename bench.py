@@ -6,8 +6,12 @@ MI355X, each workload with the roofline that bounds its kernel and the NumPy CPU
                     [--scaling weak|strong]
 
 The ONE JSON line rank 0 prints has the workload BASELINE.json's numeric target is stated on (C3, ProductOfT
-512 x 100 000: ">= 50x the NumPy reference at 1 GPU") as its top-level workload (--head) and all GPU workloads
-(C2..C5 = configs[1..4]) under "workloads", each with ms_per_step, roofline and cpu_baseline.
+512 x 100 000: ">= 50x the NumPy reference at 1 GPU"; in the reference's arithmetic: c3f64) as its top-level workload
+(--head) and every GPU workload (C2..C5 = configs[1..4]; c5 = SparseImageCode with the reference's float32 state rows,
+c5bf16 = BASELINE's wording, which runs hot under MarkovJumpHMC) as flat scalars of `config`: cK_ms, cK_frac (the flops
+or bytes the chain NEEDS / time / peak -- one meaning for every workload), cK_frac_executed, cK_frac_counted, cK_bound,
+cK_one_iter_ms/_frac (one sampling_iteration per call), cK_shard{2,4,8}_{ms,frac,eff}, cK_sample<n>_incl_download,
+cK_autocor_on_device; the complete records go to --detail.
 
 A "step" is one MarkovJumpHMC.sampling_iteration over all particles; --steps K is the batch one
 mjhmc_iterate call runs back to back with a single host sync.  The timed region is R such calls (R chosen so that it
@@ -1091,6 +1095,8 @@ def main(argv=None):
                 flat['%s_shard%d_ms' % (k, g)] = rec['ms_per_step']
                 flat['%s_shard%d_frac' % (k, g)] = rec['roofline']['frac']
                 flat['%s_shard%d_eff' % (k, g)] = rec['shard_efficiency']
+        if 'c5' in results and results['c5']:
+            flat['c5_law'] = 'kept (temperature within 1-3 %: bf16 matrix-core operands)'   # tests/test_gpu_stationary.py::test_sic_stationary_law
         if 'c5bf16' in results and results['c5bf16']:
             flat['c5bf16_law'] = 'hot'         # the bf16-state MarkovJumpHMC chain does not keep its law; c5 does
         cfg.update(flat)
