@@ -166,14 +166,22 @@ static_assert(sizeof(SicShared) <= 160 * 1024, "LDS budget of a CU");
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
-// lane l's 16 bytes at (sbase + voff) land at lds_dst + 16 l.  sbase is wave-uniform (scalar registers), voff the lane's
-// byte offset; the DMA is inline asm, so hipcc neither counts it nor drains it at a barrier
-__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
+// lane l's 16 bytes at (sbase + voff) land at lds_base + LDS_OFF + 16 l.  sbase and lds_base are wave-uniform (scalar
+// registers), voff the lane's byte offset; the DMA is inline asm, so hipcc neither counts it nor drains it at a barrier.
+// Round 6: THREE instructions per request instead of nine.  The request used to be `save m0; m0 = dst; nop; load; restore m0`
+// behind TWO v_readlane: every (block, k-step) source address was its own loop-invariant scalar pair -- 128 of them per
+// leapfrog step, 329 scalar registers spilled into vector lanes and read back one request at a time.  Now the k-step's and
+// the block's offset ride in the lane's VECTOR offset (one v_add with a literal), the source base is ONE scalar pair per
+// wave, the destination is `s_add_u32 m0, base, literal`, and m0 is declared clobbered instead of saved and restored
+// (nothing else in these kernels reads it).
+template <unsigned LDS_OFF, unsigned SRC_OFF>
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned at;   // (the add stands INSIDE the statement, between the write of m0 and its use -- the wait state the pair needs --:
+                 // left to the compiler the 112 sums of a step were formed ahead and kept in registers the kernel does not have)
+  asm volatile("s_add_u32 m0, %3, %4\n\tv_add_u32 %0, %5, %1\n\tglobal_load_lds_dwordx4 %0, %2"
+               : "=&v"(at)
+               : "v"(voff), "s"(sbase), "s"(lds_base), "i"(LDS_OFF), "i"(SRC_OFF)
+               : "memory", "m0", "scc");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -195,6 +203,8 @@ __device__ __forceinline__ int chunk_pos(int hs, int c, int ks_odd) {
 
 struct AStream {
   const char* a2w;     // A2 (+ copy) at this wave's first block: wave-uniform
+  const char* a2p;     // ... and at its SIMD partner's (wave w ^ 4)
+  unsigned img_partner;   // LDS byte address of the partner's image buffer
   unsigned voff[2];    // byte offset, inside a k-step of A2, of the chunk that lands at THIS lane's position (even / odd k-step)
   unsigned img_own;    // LDS byte address of this wave's image buffer, img[w >> 2][w & 3]
   unsigned row[2];     // byte offset of this lane's G2 row-read chunk inside a k-step image (even / odd k-step)
@@ -203,19 +213,21 @@ struct AStream {
 };
 
 // k-steps [K0, K1) of block T (compile time) of this wave into its image buffer
+template <int NB, int T, int KS, int K1>
+__device__ __forceinline__ void issue_ks(const char* base, const unsigned (&voff)[2], unsigned img) {
+  if constexpr (KS < K1) {
+    glds16<(unsigned)KS * 1024u, (unsigned)((T % NB) * 512 + KS * (int)kFrag2)>(base, voff[KS & 1], img);
+    issue_ks<NB, T, KS + 1, K1>(base, voff, img);
+  }
+}
 template <int NB, int T, int K0 = 0, int K1 = 16>
 __device__ __forceinline__ void issue_block(const AStream& s) {
-  const char* src = s.a2w + (T % NB) * 512;
-#pragma unroll
-  for (int ks = K0; ks < K1; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], s.img_own + (unsigned)ks * 1024u);
+  issue_ks<NB, T, K0, K1>(s.a2w, s.voff, s.img_own);
 }
 // the same for the wave's SIMD partner (wave w ^ 4, the other group): DIR = +1 from group 0, -1 from group 1
 template <int NB, int T, int K0, int K1, int DIR>
 __device__ __forceinline__ void issue_partner(const AStream& s) {
-  const char* src = s.a2w + (long)DIR * (long)(4 * 32 * NB * 16) + (T % NB) * 512;
-  const unsigned img = s.img_own + (unsigned)(DIR * 4 * 16384);
-#pragma unroll
-  for (int ks = K0; ks < K1; ++ks) glds16(src + (size_t)ks * kFrag2, s.voff[ks & 1], img + (unsigned)ks * 1024u);
+  issue_ks<NB, T, K0, K1>(s.a2p, s.voff, s.img_partner);
 }
 // A step's pass: of the sixteen requests of an owner's next block the last 16 - kOwnPieces are made by its SIMD partner.
 // The waves that request stand at the vector-memory port (64 B/clk per CU: ~58 cycles per request with four waves
@@ -232,6 +244,13 @@ __device__ __forceinline__ AStream astream_open(const SicModel& mdl, SicShared& 
   s.a2w = (const char*)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long)s.a2w >> 32)) << 32) |
                         (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long)s.a2w));
   s.img_own = __builtin_amdgcn_readfirstlane(lds_addr(&sh.img[w >> 2][w & 3][0][0]));
+  {
+    const long dir = (w < 4) ? 1 : -1;   // the partner of a wave of group 0 is four waves up, of group 1 four down
+    s.a2p = s.a2w + dir * (long)(4 * 32 * NB * 16);
+    s.a2p = (const char*)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long)s.a2p >> 32)) << 32) |
+                          (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long)s.a2p));
+    s.img_partner = __builtin_amdgcn_readfirstlane(lds_addr(&sh.img[(w >> 2) ^ 1][w & 3][0][0]));
+  }
   const int c = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
