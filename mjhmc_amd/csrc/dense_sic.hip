@@ -373,7 +373,10 @@ __device__ __forceinline__ void round_g2(SicShared& sh, const AStream& as, int l
   // the operands of k-step ks + 1 are read before the MFMA of k-step ks; the fences keep hipcc from hoisting all the
   // reads to the top (registers) or sinking them to their uses (an LDS round trip in front of every MFMA)
   const unsigned base = as.img_own;
-  const unsigned rb0 = lds_addr(&sh.pubR[0][0]) + 16u * (unsigned)lane;
+  // (opaque: as a known constant | lane offset hipcc formed every read's address with a v_or of its own -- the fragment
+  // buffers sit beyond the 64 KB an LDS instruction's offset field reaches from zero; from this register it reaches them)
+  unsigned rb0 = lds_addr(&sh.pubR[0][0]) + 16u * (unsigned)lane;
+  asm volatile("" : "+v"(rb0));
   // kAhead k-steps of operands in flight: during an owner's G2 its SIMD partner has no matrix work, so nothing but the
   // wave's own earlier reads covers the LDS round trip
   constexpr int kAhead = 3;   // (2 and 5 measured: within 2 %)
@@ -409,7 +412,8 @@ __device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int l
   using lds_f32x4 = __attribute__((address_space(3))) const f32x4;
   using lds_i16x4 = __attribute__((address_space(3))) i16x4;
   const unsigned img0 = lds_addr(&sh.img[RD & 1][0][0][0]);
-  const unsigned xb0 = lds_addr(&sh.pubX[0][0][0]) + 16u * (unsigned)lane;
+  unsigned xb0 = lds_addr(&sh.pubX[0][0][0]) + 16u * (unsigned)lane;
+  asm volatile("" : "+v"(xb0));   // (as rb0 in round_g2)
   // MFMA n = 2 i + s: the fragment A[pixel row][8 coefficients of k-step s of owner i's block] is two transposed
   // 4-coefficient pieces; the operands of MFMA n + 1 are read before MFMA n
   auto ops_of = [&](int n, i16x4& lo, i16x4& hi, f32x4& xf) {
@@ -418,22 +422,23 @@ __device__ __forceinline__ void round_g1(SicShared& sh, const AStream& as, int l
     hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(unsigned long)(at + as.tr[1]));
     xf = *(lds_f32x4*)(unsigned long)(xb0 + (unsigned)n * 1024u);
   };
-  i16x4 lo, hi, nlo, nhi;
-  f32x4 xf, nxf;
-  ops_of(0, lo, hi, xf);
+  // kAheadG1 MFMAs' operands in flight, as round_g2 keeps them: written as "read n + 1, then MFMA n" without a fence between
+  // the two, hipcc issued MFMA n FIRST and waited for the reads of n + 1 with lgkmcnt(0) right behind them -- every MFMA
+  // of G1 stood behind a whole LDS round trip (the ISA: read, read, read, s_waitcnt lgkmcnt(0), v_mfma, eight times over)
+  constexpr int kAheadG1 = 2;
+  i16x4 lo[kAheadG1], hi[kAheadG1];
+  f32x4 xf[kAheadG1];
+#pragma unroll
+  for (int k = 0; k < kAheadG1; ++k) ops_of(k, lo[k], hi[k], xf[k]);
 #pragma unroll
   for (int n = 0; n < 2 * kG; ++n) {
+    const i16x4 l = lo[n % kAheadG1], h = hi[n % kAheadG1];
+    const f32x4 x = xf[n % kAheadG1];
     __builtin_amdgcn_sched_barrier(0);
-    nlo = lo;
-    nhi = hi;
-    nxf = xf;
-    if (n + 1 < 2 * kG) ops_of(n + 1, nlo, nhi, nxf);
-    const auto a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    R.b[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, xf), R.b[0], 0, 0, 0);
+    if (n + kAheadG1 < 2 * kG) ops_of(n + kAheadG1, lo[n % kAheadG1], hi[n % kAheadG1], xf[n % kAheadG1]);
+    const auto a8 = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+    R.b[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, x), R.b[0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    lo = nlo;
-    hi = nhi;
-    xf = nxf;
   }
 }
 
