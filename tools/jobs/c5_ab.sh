@@ -1,7 +1,6 @@
-for rep in 1 2; do
-for v in O B C D; do
+for rep in 1 2 3; do
+for v in C E; do
   MJHMC_HIP_LIB=$PWD/mjhmc_amd/lib/libsic_$v.so timeout 600 python bench.py --workload c5 --no-cpu-baseline --shard-of 1 --steps 16 --warmup 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v c5', d['config']['c5_ms'])"
 done
 done
-MJHMC_HIP_LIB=$PWD/mjhmc_amd/lib/libsic_C.so timeout 900 python -m pytest tests/test_gpu_dense_parity.py -x -q -k "sic" 2>&1 | grep -E "passed|failed|Error" | tail -2
-MJHMC_HIP_LIB=$PWD/mjhmc_amd/lib/libsic_D.so timeout 900 python -m pytest tests/test_gpu_dense_parity.py -x -q -k "sic" 2>&1 | grep -E "passed|failed|Error" | tail -2
+MJHMC_HIP_LIB=$PWD/mjhmc_amd/lib/libsic_E.so timeout 900 python -m pytest tests/test_gpu_dense_parity.py -x -q -k "sic" 2>&1 | grep -E "passed|failed|Error" | tail -2
