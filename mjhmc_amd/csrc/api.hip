@@ -28,6 +28,38 @@ int mjhmc_fail(int code, const std::string& msg) {
 }
 static int fail(int code, const std::string& msg) { return mjhmc_fail(code, msg); }
 
+// The call block (handles.hpp): [Control, kCtlBytes][flf_counts, counts_bytes(cap)][stats, cap x 4 x 8 bytes]
+constexpr size_t kCtlBytes = 64;
+static_assert(sizeof(Control) <= kCtlBytes, "the failure flag's slot of the call block");
+static size_t counts_bytes(int cap) { return (((size_t)cap + 1) * sizeof(int) + 63) / 64 * 64; }
+static int ensure_call_block(mjhmc_sampler* s, int rows) {
+  if (s->call_block && s->stats_cap >= rows) return 0;
+  const int cap = std::max(rows, 1024);
+  if (s->call_block) {   // (calls end with a stream sync: nothing in flight reads the old block)
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipFree(s->call_block));
+    s->call_block = nullptr;
+    s->ctl = nullptr;
+    s->flf_counts = nullptr;
+    s->stats = nullptr;
+    s->stats_cap = 0;
+  }
+  const size_t total = kCtlBytes + counts_bytes(cap) + (size_t)cap * 4 * sizeof(long long);
+  HIPCHK(hipMalloc((void**)&s->call_block, total));
+  HIPCHK(hipMemsetAsync(s->call_block, 0, total, s->stream));
+  s->ctl = (Control*)s->call_block;
+  s->flf_counts = (int*)(s->call_block + kCtlBytes);
+  s->stats = (long long*)(s->call_block + kCtlBytes + counts_bytes(cap));
+  s->stats_cap = cap;
+  return 0;
+}
+// the start of a call: failure flag, counters and the first `rows` tallies zeroed by ONE fill
+static int zero_call(mjhmc_sampler* s, int rows) {
+  TRY(ensure_call_block(s, rows));
+  HIPCHK(hipMemsetAsync(s->call_block, 0, kCtlBytes + counts_bytes(s->stats_cap) + (size_t)rows * 4 * sizeof(long long), s->stream));
+  return 0;
+}
+
 static int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -1069,9 +1101,9 @@ int mjhmc_sampler_destroy(mjhmc_sampler* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->ctx->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void* ptrs[] = {s->flf_list, s->flf_counts, s->Hpre, s->Hwork, s->cold_list, s->pot64_scratch, s->Hspec[0], s->Hspec[1], s->Hspec_dump, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
+  void* ptrs[] = {s->flf_list, s->call_block, s->Hpre, s->Hwork, s->cold_list, s->pot64_scratch, s->Hspec[0], s->Hspec[1], s->Hspec_dump, s->Gbuf[0], s->Gbuf[1], s->Xbuf[0], s->Xbuf[1], s->Vbuf[0],  s->Vbuf[1], s->EX[0],     s->EX[1],  s->EV[0],
                   s->EV[1],   s->Hflf[0], s->Hflf[1],  s->dwell,  s->dwell_scratch,  s->trans,
-                  s->ctl,     s->stats,   s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
+                  s->ring,     s->dwell_ring, s->stage,  s->noise,  s->rexp,
                   s->runif,   s->scratch,  s->ck[0],    s->ck[1],    s->ck[2],   s->ck[3],  s->ck[4],
                   s->ck[5],   s->ck[6]};
   for (void* p : ptrs)
@@ -1168,15 +1200,11 @@ int mjhmc_sampler_create(mjhmc_ctx* ctx, mjhmc_energy* e, int64_t nparticles, in
     HIPCHK(hipMalloc((void**)&s->dwell_scratch, s->Npad * sizeof(double)));
     HIPCHK(hipMalloc((void**)&s->trans, s->Npad));
     HIPCHK(hipMemsetAsync(s->trans, 0, s->Npad, s->stream));
-    HIPCHK(hipMalloc((void**)&s->ctl, sizeof(Control)));
-    HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
+    TRY(ensure_call_block(s, 1024));   // everything mjhmc_iterate needs is created here, so a timed call never allocates
     HIPCHK(hipEventCreate(&s->ev_total[0]));
     HIPCHK(hipEventCreate(&s->ev_total[1]));
     // a state matrix big enough for the pipelined host copies: their pinned buffers now, not inside the first read
     if ((size_t)s->D * s->N * sizeof(double) >= 2 * kPipeChunk) TRY(ensure_pipe(s));
-    // everything mjhmc_iterate needs is created here, so a timed call never allocates
-    s->stats_cap = 1024;
-    HIPCHK(hipMalloc((void**)&s->stats, (size_t)s->stats_cap * 4 * sizeof(long long)));
     s->Xcur = s->Xbuf[0];
     TRY(upload_matrix(s, Xinit, s->Xcur));
     if (s->sh.round32) TRY(round_rows32(s, s->Xcur));
@@ -1431,10 +1459,12 @@ static int split_state_copy(mjhmc_sampler* s, bool restore) {
   return 0;
 }
 
-// failure flag + tallies of a call, read back through pinned host memory (a pageable destination makes each of the two
-// small copies a synchronous staged transfer: ~20 us of every mjhmc_iterate call) and handed out after ONE stream sync
-static int read_back_call(mjhmc_sampler* s, const void* stats_dev, size_t stats_bytes, Control* hc, long long* hs) {
-  const size_t need = 64 + stats_bytes;
+// failure flag + cold-list counters + tallies of a call: ONE copy of the head of the call block into pinned host memory
+// (a pageable destination makes a small copy a synchronous staged transfer: ~20 us) and ONE stream sync.  Until round 6
+// the call was three fills, two asynchronous copies and -- for the compacted passes -- a synchronous third.
+static int read_back_call(mjhmc_sampler* s, size_t stats_rows, Control* hc, long long* hs, int* counts = nullptr, int n_counts = 0) {
+  const size_t head = kCtlBytes + counts_bytes(s->stats_cap);
+  const size_t need = head + stats_rows * 4 * sizeof(long long);
   if (s->h_pin_cap < need) {
     if (s->h_pin) HIPCHK(hipHostFree(s->h_pin));
     s->h_pin = nullptr;
@@ -1442,11 +1472,11 @@ static int read_back_call(mjhmc_sampler* s, const void* stats_dev, size_t stats_
     HIPCHK(hipHostMalloc((void**)&s->h_pin, need * 2, hipHostMallocDefault));
     s->h_pin_cap = need * 2;
   }
-  HIPCHK(hipMemcpyAsync(s->h_pin, s->ctl, sizeof(Control), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipMemcpyAsync(s->h_pin + 64, stats_dev, stats_bytes, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(s->h_pin, s->call_block, need, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   std::memcpy(hc, s->h_pin, sizeof(Control));
-  std::memcpy(hs, s->h_pin + 64, stats_bytes);
+  if (counts) std::memcpy(counts, s->h_pin + kCtlBytes, (size_t)n_counts * sizeof(int));
+  std::memcpy(hs, s->h_pin + head, stats_rows * 4 * sizeof(long long));
   return 0;
 }
 
@@ -1454,14 +1484,7 @@ template <typename T>
 static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
   const size_t mb = mat_bytes(s);
   const int need = n_iter + kMaxFuse;  // + scratch tallies for the recovery launch
-  if (s->stats_cap < need) {
-    if (s->stats) HIPCHK(hipFree(s->stats));
-    s->stats = nullptr;
-    HIPCHK(hipMalloc((void**)&s->stats, (size_t)need * 4 * sizeof(long long)));
-    s->stats_cap = need;
-  }
-  HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
-  HIPCHK(hipMemsetAsync(s->stats, 0, (size_t)need * 4 * sizeof(long long), s->stream));
+  TRY(zero_call(s, need));
 
   void* xin = s->Xcur;
   if (ring_slot0 >= 0) {  // the live state sits in a slot about to be overwritten: move it out first
@@ -1615,7 +1638,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
-  TRY(read_back_call(s, s->stats, hs.size() * sizeof(long long), &hc, hs.data()));
+  TRY(read_back_call(s, (size_t)n_iter, &hc, hs.data()));
 
   int done = n_iter, attempts = n_iter, committed = (int)launches.size();
   void* xlive = launches.back().xout;
@@ -1685,20 +1708,14 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   if (n_iter >= 2 && fusable && !replay_normal && !replay_exp && !replay_unif && !test_env("MJHMC_NO_FUSE"))
     return iterate_fused_t<T>(s, n_iter, ring_slot0, per_iter, n_done);
   const size_t mb = mat_bytes(s);
-  if (s->stats_cap < n_iter) {
-    if (s->stats) HIPCHK(hipFree(s->stats));
-    s->stats = nullptr;
-    HIPCHK(hipMalloc((void**)&s->stats, (size_t)n_iter * 4 * sizeof(long long)));
-    s->stats_cap = n_iter;
-  }
+  TRY(ensure_call_block(s, n_iter));
   if (replay_normal && !s->noise) {
     HIPCHK(hipMalloc(&s->noise, mb));
     HIPCHK(hipMemsetAsync(s->noise, 0, mb, s->stream));
   }
   if (replay_exp && !s->rexp) HIPCHK(hipMalloc((void**)&s->rexp, 3 * s->N * sizeof(double)));
   if (replay_unif && !s->runif) HIPCHK(hipMalloc((void**)&s->runif, (2 * s->N + 1) * sizeof(double)));
-  HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(Control), s->stream));
-  HIPCHK(hipMemsetAsync(s->stats, 0, (size_t)n_iter * 4 * sizeof(long long), s->stream));
+  TRY(zero_call(s, n_iter));   // (failure flag, the cold lists' counters, the tallies: one fill)
 
   // Several particles per wave and a big batch: the inverse-L trajectory of the cold-cache particles runs in its
   // the list's own workgroups of mjhmc_traj_kernel instead of in every wave of the jump kernel that holds a cold particle.
@@ -1709,13 +1726,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
       HIPCHK(hipMalloc((void**)&s->flf_list, (size_t)2 * s->Npad * sizeof(int)));   // two lists: iterations alternate
       HIPCHK(hipMalloc(&s->Hpre, (size_t)2 * s->Npad * ssize(s)));
     }
-    if (s->flf_cap < n_iter + 1) {  // a counter per iteration of the call (+ the one the last iteration's movers go to)
-      if (s->flf_counts) HIPCHK(hipFree(s->flf_counts));
-      s->flf_counts = nullptr;
-      HIPCHK(hipMalloc((void**)&s->flf_counts, (size_t)(n_iter + 1) * sizeof(int)));
-      s->flf_cap = n_iter + 1;
-    }
-    HIPCHK(hipMemsetAsync(s->flf_counts, 0, (size_t)(n_iter + 1) * sizeof(int), s->stream));
+    // (flf_counts: a counter per iteration of the call + the one the last iteration's movers go to -- stats_cap + 1 of them
+    // in the call block, zeroed with it)
   }
 
   // dense batches: free-running parts on their own streams (part_args; the story is above iterate_fused_t)
@@ -2115,7 +2127,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
-  TRY(read_back_call(s, s->stats, hs.size() * sizeof(long long), &hc, hs.data()));
+  std::vector<int> hcnt((size_t)n_iter);
+  TRY(read_back_call(s, (size_t)n_iter, &hc, hs.data(), hcnt.data(), n_iter));
 
   if (hc.failed && n_parts > 1 && n_iter > 1) {
     // a non-finite rate somewhere in the free-running parts: back to the state the call started from, and once more
@@ -2130,8 +2143,6 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   const int done = hc.failed ? hc.failed_iter : n_iter;
   const int attempts = hc.failed ? done + 1 : n_iter;
   if (compact) {  // the cold tallies are the list lengths (of every part)
-    std::vector<int> hcnt((size_t)attempts);
-    HIPCHK(hipMemcpy(hcnt.data(), s->flf_counts, hcnt.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < attempts; ++i) hs[4 * (size_t)i + 3] = hcnt[(size_t)i];
   }
   fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);

@@ -110,8 +110,7 @@ struct mjhmc_sampler {
   void* Hspec_dump = nullptr;          // (test build, MJHMC_NO_FSPEC: where the hand-over goes instead, so that nothing is ever handed on)
   // elementwise energies, several particles per wave: inverse-L pass over the compacted cold particles
   int* flf_list = nullptr;     // [Npad]
-  int* flf_counts = nullptr;   // [flf_cap] one counter per attempt of the current mjhmc_iterate call
-  int flf_cap = 0;
+  int* flf_counts = nullptr;   // [stats_cap + 1] one counter per attempt of the current mjhmc_iterate call (inside call_block)
   void* Hpre = nullptr;        // [2][Npad] H_flf with the cold entries filled in (iterations alternate between the halves)
   int vcur = 0, scur = 0;
   void* EX[2] = {nullptr, nullptr};
@@ -126,6 +125,10 @@ struct mjhmc_sampler {
   bool undo_valid = false;
   bool undo_multipass = false;   // the last committed iteration ran on the multi-pass path: its undo is a copy back (host_energy.hip)
   uint8_t* trans = nullptr;
+  // What a call zeroes at its start and reads back at its end lives in ONE device block -- [Control, 64 bytes][flf_counts:
+  // stats_cap + 1 counters, padded to 64 bytes][stats: stats_cap x 4] -- so that a call is one fill and one copy
+  // (api.hip: ensure_call_block, zero_call, read_back_call).  ctl, flf_counts and stats point into it.
+  char* call_block = nullptr;
   Control* ctl = nullptr;
   long long* stats = nullptr;  // [stats_cap][4]
   int stats_cap = 0;
