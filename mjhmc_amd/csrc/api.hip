@@ -67,7 +67,7 @@ static int pow2ceil(int v) {
 }
 
 // The A/B switches of the measurement tools and of the launch-strategy tests (MJHMC_NO_FUSE, MJHMC_NO_COMPACT,
-// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_NO_ROWS, MJHMC_FUSE_BELOW, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
+// MJHMC_NO_SPLIT, MJHMC_SPLIT_PARTS, MJHMC_NO_FSPEC, MJHMC_NO_ROWS, MJHMC_NO_LIST_CARRY, MJHMC_FUSE_BELOW, MJHMC_NO_BLOCK_DECIDE, MJHMC_NO_WPP, MJHMC_NO_QUAD, MJHMC_CHUNKS_PER_LANE,
 // MJHMC_SIC_COPIES) and the failure-placing hook MJHMC_DEBUG_POISON exist only in libmjhmc_hip_test.so (built with
 // -DMJHMC_TEST_HOOKS, `make test_hooks`).  The shipped library consults no environment variable on the sampling path:
 // the only ones it reads at all name libraries to dlopen (MJHMC_RCCL_LIB; hipRTC / hipFFT by their sonames).
@@ -1287,6 +1287,7 @@ int mjhmc_restore(mjhmc_sampler* s) {
                   s->Gbuf[s->vcur]};
   for (int i = 0; i < nck; ++i) HIPCHK(hipMemcpyAsync(dst[i], s->ck[i], sizes[i], hipMemcpyDeviceToDevice, s->stream));
   TRY(drop_spec(s));
+  s->list_valid = false;
   s->tick = s->ck_tick;
   s->undo_valid = false;
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1300,6 +1301,7 @@ int mjhmc_rollback(mjhmc_sampler* s) {
   // (X, V, EX, EV, H_flf and, for ProductOfT, dE/dX); dwell / trans hold the rolled-back attempt's values until
   // the retry overwrites them.  The RNG tick stays consumed, like the reference's already-drawn numbers.
   s->undo_valid = false;
+  s->list_valid = false;   // (the carried list is the rolled-back successor's)
   if (s->undo_multipass) return multipass_rollback(s);   // committed in place: the pre-move state is copied back
   s->Xcur = s->undo_X;
   s->vcur ^= 1;
@@ -1330,6 +1332,7 @@ int mjhmc_reset_flf_cache(mjhmc_sampler* s) {
   if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
   HIPCHK(hipSetDevice(s->ctx->device));
   HIPCHK(hipMemsetAsync(s->Hflf[s->scur], 0xFF, s->Npad * ssize(s), s->stream));
+  s->list_valid = false;
   return drop_spec(s);
 }
 
@@ -1695,6 +1698,8 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
                      bool allow_split = true) {
   // Fused launches: always for the Gaussian forces (one iteration is HBM-bound), for the other elementwise energies
   // while the batch is small (launch-/latency-bound) -- big batches of those take the compacted passes below instead.
+  const bool carried = s->list_valid && !test_env("MJHMC_NO_LIST_CARRY");   // (every path consumes it; only the compacted passes renew it)
+  s->list_valid = false;
   const bool gaussian = s->en->ep.kind == MJHMC_E_ISO_GAUSS || s->en->ep.kind == MJHMC_E_DIAG_GAUSS;
   int64_t fuse_below = kFuseBelow;
   if (const char* fb = test_env("MJHMC_FUSE_BELOW")) fuse_below = std::atoll(fb);
@@ -2040,8 +2045,12 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         ta.EX_out = a.EX_out;
         ta.EV_out = a.EV_out;
         ta.Hwork = (T*)s->Hpre;
-        ta.list = s->flf_list + (size_t)(i & 1) * s->Npad;
-        ta.count = s->flf_counts + i;
+        // the two lists alternate; a call that follows a committed call of this path starts from the list that call's last
+        // jump process left (the host knows its length) instead of scanning H_flf
+        const int par0 = carried ? s->list_par : 0;
+        ta.list = s->flf_list + (size_t)((par0 + i) & 1) * s->Npad;
+        ta.count = (carried && i == 0) ? nullptr : s->flf_counts + i;
+        ta.n_listed = s->list_count;
         ta.ctl = s->ctl;
         ta.N = a.N;
         ta.D = a.D;
@@ -2068,7 +2077,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         da.dwell = a.dwell;
         da.dwell_ring = a.dwell_ring;
         da.trans = a.trans;
-        da.next_list = s->flf_list + (size_t)((i + 1) & 1) * s->Npad;
+        da.next_list = s->flf_list + (size_t)((par0 + i + 1) & 1) * s->Npad;
         da.next_count = s->flf_counts + i + 1;
         da.ctl = s->ctl;
         da.stats = a.stats;
@@ -2083,7 +2092,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
         da.r_mix = a.r_mix;
         da.p_r = a.p_r;
         da.key = a.key;
-        if (i == 0) {
+        if (i == 0 && !carried) {
           const dim3 list_grid((unsigned)((s->N + kColdChunk - 1) / kColdChunk));
           hipLaunchKernelGGL(compact_list_kernel<ColdCache<T>>, list_grid, dim3(1024), 0, s->stream,
                              ColdCache<T>{a.Hflf_in, (T*)s->Hpre + s->Npad}, s->N, s->ctl, s->flf_list, s->flf_counts);
@@ -2127,8 +2136,9 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
-  std::vector<int> hcnt((size_t)n_iter);
-  TRY(read_back_call(s, (size_t)n_iter, &hc, hs.data(), hcnt.data(), n_iter));
+  std::vector<int> hcnt((size_t)n_iter + 1);   // (+ the list the last iteration's movers went to)
+  TRY(read_back_call(s, (size_t)n_iter, &hc, hs.data(), hcnt.data(), n_iter + 1));
+  if (compact && carried) hcnt[0] = s->list_count;
 
   if (hc.failed && n_parts > 1 && n_iter > 1) {
     // a non-finite rate somewhere in the free-running parts: back to the state the call started from, and once more
@@ -2146,6 +2156,11 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     for (int i = 0; i < attempts; ++i) hs[4 * (size_t)i + 3] = hcnt[(size_t)i];
   }
   fill_iter_stats(s, hs, attempts, done, hc.failed != 0, per_iter);
+  if (compact && !hc.failed) {   // the next call's list
+    s->list_par = ((carried ? s->list_par : 0) + n_iter) & 1;
+    s->list_count = hcnt[(size_t)n_iter];
+    s->list_valid = true;
+  }
   // commit the finished iterations
   s->undo_valid = (n_iter == 1 && done == 1);  // the input buffers of a single iteration survive it: see mjhmc_rollback
   s->undo_multipass = false;
@@ -2213,6 +2228,7 @@ int mjhmc_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal, con
   const bool pot64_fused = s->sh.wide && s->en->is_pot() && !s->en->pot_big() && !s->sh.round32 && s->L >= 1 &&
                            !test_env("MJHMC_POT64_MULTIPASS");
   if (s->sh.wide && !pot64_fused) {
+    s->list_valid = false;
     const int rc = multipass_iterate(s, n_iter, replay_normal, replay_exp, replay_unif, ring_slot0, per_iter, n_done);
     if (rc == 0) TRY(drop_spec(s));   // (that path neither reads nor writes the F-movers' hand-over: nothing of it is valid afterwards)
     return rc;
@@ -2370,6 +2386,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
       if (nbytes != mat * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected (D,N) float64");
       void* dst = field == MJHMC_F_X ? s->Xcur : s->Vbuf[s->vcur];
       s->undo_valid = false;
+      s->list_valid = false;
       if (field == MJHMC_F_X) s->host_energy_set = false;  // MJHMC_E_HOST: E and dE/dX of the new X are the caller's to supply
       TRY(upload_matrix(s, (const double*)host_src, dst));
       if (s->sh.round32) TRY(round_rows32(s, dst));
@@ -2382,6 +2399,7 @@ int mjhmc_write(mjhmc_sampler* s, int field, const void* host_src, size_t nbytes
     case MJHMC_F_HFLF: {  // float64 (N); NaN marks a cold cache entry
       if (nbytes != (size_t)s->N * sizeof(double)) return fail(MJHMC_ERR_INVALID, "expected N float64");
       TRY(drop_spec(s));
+      s->list_valid = false;
       if (s->dtype == MJHMC_F64) {
         HIPCHK(hipMemcpyAsync(s->Hflf[s->scur], host_src, nbytes, hipMemcpyHostToDevice, s->stream));
       } else {

@@ -756,11 +756,12 @@ struct TrajArgs {
   T* EV_out;
   T* Hwork;           // [Npad] H() of the inverse-L proposal F L F, written for the listed particles only
   const int* list;    // the particles with a cold cache
-  const int* count;   // how many
+  const int* count;   // how many -- or NULL: n_listed then (a list carried over from the previous call, its length known to the host)
   const Control* ctl;
   int64_t N;
   int D, pitch, CH, logG;
   int L;
+  int n_listed;
   int inv_blocks;     // leading workgroups of the grid that walk the list (the rest: one forward slot each)
   int rows;           // energies with a row form: a lane per particle (mjhmc_traj_rows_kernel); 0 = the group form (A/B)
   T eps, chalf;
@@ -1878,7 +1879,7 @@ __device__ __forceinline__ void traj_block(const TrajArgs<T>& a, const En& en, i
   const int ppb = 256 >> a.logG;  // particles per workgroup
   if (vblock < a.inv_blocks) {
     // inverse-L proposal F L F of the listed particles; only H() of it is ever read (markov_jump_hmc.py:360,367)
-    const int n_cold = *a.count;
+    const int n_cold = a.count ? *a.count : a.n_listed;
     for (int64_t first = (int64_t)vblock * ppb; first < n_cold; first += (int64_t)a.inv_blocks * ppb) {
       const int64_t idx = first + (threadIdx.x >> a.logG);
       const bool live = idx < n_cold;
@@ -2225,7 +2226,7 @@ __global__ __launch_bounds__(64, 2) void mjhmc_traj_rows_kernel(const TrajArgs<T
   T x[G][E], v[G][E];
   if ((int)blockIdx.x < n_walk) {
     // inverse-L proposal F L F of the listed particles; only H() of it is ever read (markov_jump_hmc.py:360,367)
-    const int n_cold = *a.count;
+    const int n_cold = a.count ? *a.count : a.n_listed;
     for (int64_t first = (int64_t)blockIdx.x * 64; first < n_cold; first += (int64_t)n_walk * 64) {
       const int64_t idx = first + lane;
       const bool live = idx < n_cold;

@@ -206,6 +206,76 @@ def test_compacted_inverse_pass_equals_in_kernel(kind, D, N, monkeypatch):
     assert sum(s.n_cold for s in stats_a) > 0 and stats_a[0].n_cold == N        # first iteration: every cache is cold
 
 
+@pytest.mark.parametrize('kind,D,N', [('E_FUNNEL_NEAL', 32, 20000), ('E_FUNNEL_NEAL', 21, 20011), ('E_ROUGH_WELL', 40, 16400)])
+def test_list_carried_between_calls_equals_a_scan_per_call(kind, D, N, monkeypatch):
+    """Round 6: a call of the compacted passes that follows a committed call of the same path starts from the list the
+    previous call's last jump process left (its movers ARE the cold caches) instead of scanning H_flf -- the
+    sampling_iteration() callers' path, one iteration per call.  Invisible: a sampler that scans at every call
+    (MJHMC_NO_LIST_CARRY) sees the same state and counters, across everything that must drop the carried list on the way
+    -- calls of odd and even length (the two lists alternate), a cache write, reset_flf_cache, a rollback, a state write,
+    checkpoint / restore, a fused call in between, new hyper-parameters (which keep it)."""
+    from mjhmc_amd import _lib
+    params = {'E_FUNNEL_NEAL': [3.0], 'E_FUNNEL_REF': [3.0], 'E_ROUGH_WELL': [100.0, 4.0]}.get(kind, [1.0])
+    (a, b), _lib = _pair(kind, D, N, _lib.MODE_MJHMC, params=params, libs='hh')
+    for s in (a, b):
+        s.set_hparams(0.05, 7, 0.1, 1.0, 0.5)
+    stats_a, stats_b = [], []
+
+    def both(op):
+        monkeypatch.setenv('MJHMC_NO_FUSE', '1')
+        monkeypatch.delenv('MJHMC_NO_LIST_CARRY', raising=False)
+        ra = op(a)
+        monkeypatch.setenv('MJHMC_NO_LIST_CARRY', '1')
+        rb = op(b)
+        monkeypatch.delenv('MJHMC_NO_LIST_CARRY', raising=False)
+        return ra, rb
+
+    def run(n):
+        (sa, da), (sb, db) = both(lambda s: s.iterate(n))
+        assert da == db == n
+        stats_a.extend(sa)
+        stats_b.extend(sb)
+        _same_state(a, b, _lib)
+
+    for n in (1, 1, 1, 2, 1, 3, 1):            # odd / even call lengths: the carried list changes sides
+        run(n)
+    h = a.read(_lib.F_HFLF)
+    h[::3] = np.nan                             # a cache write from the host: a third of the caches cold again
+    both(lambda s: s.write(_lib.F_HFLF, h))
+    run(1)
+    assert stats_a[-1].n_cold >= (N + 2) // 3
+    run(1)
+    both(lambda s: s.reset_flf_cache())
+    run(1)
+    assert stats_a[-1].n_cold == N
+    run(1)
+    both(lambda s: s.rollback())                # back to the state before that iteration: ITS list, not the successor's
+    run(1)
+    run(2)
+    both(lambda s: s.checkpoint())
+    run(1)
+    run(1)
+    both(lambda s: s.restore())
+    run(1)
+    X = a.read(_lib.F_X)
+    both(lambda s: s.write(_lib.F_X, X * 1.01))   # a state write clears every cache
+    run(1)
+    assert stats_a[-1].n_cold == N
+    run(1)
+    for s in (a, b):                               # new hyper-parameters leave the caches -- and the list -- as they are
+        s.set_hparams(0.04, 5, 0.1, 1.0, 0.5)
+    run(1)
+    run(1)
+    monkeypatch.delenv('MJHMC_NO_FUSE', raising=False)    # a fused call in between (the product fuses below 160 000 particles)
+    (sa, da), (sb, db) = a.iterate(4), b.iterate(4)
+    assert da == db == 4
+    _same_state(a, b, _lib)
+    run(1)
+    run(1)
+    assert [_stats_tuple(s) for s in stats_a] == [_stats_tuple(s) for s in stats_b]
+    assert 0 < stats_a[1].n_cold < N // 2
+
+
 def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
     """A non-finite rate in iteration i > 0 of a multi-iteration call through the compacted passes: the call stops
     there and the state is the one iteration i-1 handed on -- INCLUDING the momentum refresh of its R-movers, which
