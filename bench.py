@@ -10,7 +10,7 @@ The ONE JSON line rank 0 prints has the workload BASELINE.json's numeric target 
 (--head) and every GPU workload (C2..C5 = configs[1..4]; c5 = SparseImageCode with the reference's float32 state rows,
 c5bf16 = BASELINE's wording, which runs hot under MarkovJumpHMC) as flat scalars of `config`: cK_ms, cK_frac (the flops
 or bytes the chain NEEDS / time / peak -- one meaning for every workload), cK_frac_executed, cK_frac_counted, cK_bound,
-cK_one_iter_ms/_frac (one sampling_iteration per call), cK_shard{2,4,8}_{ms,frac,eff}, cK_sample<n>_incl_download,
+cK_one_iter_ms/_frac/_call_ms (one sampling_iteration per call: launches by HIP events; the whole call by the wall clock), cK_shard{2,4,8}_{ms,frac,eff}, cK_sample<n>_incl_download,
 cK_autocor_on_device; the complete records go to --detail.
 
 A "step" is one MarkovJumpHMC.sampling_iteration over all particles; --steps K is the batch one
@@ -442,11 +442,16 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
     fused = (w['kind'] == 'iso' or (w['kind'] == 'funnel' and w['dtype'] == 'float64' and 9 <= w['D'] <= 32)) and steps >= 2
     # the same workload with one sampling iteration per launch (the HBM-bound form of the kernel: what every
     # sampling_iteration() caller gets -- a call of ONE iteration is never fused), after the timed region
-    unfused_ms = None
+    unfused_ms = unfused_call_ms = None
     if fused and shard_of == 1:
         for _ in range(8):
             smp.iterate(1)
         t_sum = 0.0
+        smp.sync()
+        t_b = time.perf_counter()
+        for _ in range(32):
+            smp.iterate(1)                              # (returns after its read-back: a call is synchronous)
+        unfused_call_ms = (time.perf_counter() - t_b) / 32 * 1e3   # what a sampling_iteration() caller waits, host side included
         for _ in range(32):
             smp.iterate(1)
             t_sum += smp.last_timing()['jump_kernel_ms']
@@ -624,7 +629,8 @@ def run_workload(rig, key, steps, warmup, cpu_seconds, scaling='weak', shard_of=
                 roof['one_iteration_per_launch'] = {
                     'bound': 'hbm', 'avg_launch_ms': unfused_ms, 'achieved': abytes / (unfused_ms * 1e-3) / 1e9,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': abytes / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    'traffic': measured_traffic(key + '_one_iteration_per_launch', 1)}
+                    'traffic': measured_traffic(key + '_one_iteration_per_launch', 1),
+                    'call_ms': unfused_call_ms}   # wall clock of a whole call (launches + read-back + host)
         else:
             roof = {'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': hbm['achieved'] / HBM_PEAK_GBS, 'traffic': traffic,
@@ -1084,6 +1090,7 @@ def main(argv=None):
             if 'one_iteration_per_launch' in r:               # the sampling_iteration() path: one iteration per call (HBM-bound)
                 flat['%s_one_iter_ms' % k] = r['one_iteration_per_launch']['avg_launch_ms']
                 flat['%s_one_iter_frac' % k] = r['one_iteration_per_launch']['frac']
+                flat['%s_one_iter_call_ms' % k] = r['one_iteration_per_launch'].get('call_ms')
             flat['%s_lfr' % k] = '%.3f/%.3f/%.3f' % (c['L_move_fraction'], c['F_move_fraction'], c['R_move_fraction'])
             if c.get('gpu_over_cpu'):
                 flat['%s_gpu_over_cpu' % k] = c['gpu_over_cpu']
