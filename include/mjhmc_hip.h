@@ -364,6 +364,12 @@ int mjhmc_comm_allgather_columns(mjhmc_comm* c, mjhmc_sampler* s, const int64_t*
  * n_jump_launches is the number of sampling_iteration attempts it covers. */
 int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms, int* n_jump_launches);
 
+/* The event pair is two marker packets on the stream (~8 us of a call: 3 % of a one-iteration call at C4's size).
+ * on = 0: calls record nothing and mjhmc_last_timing keeps reporting the last recorded call; on by default.  (The
+ * reference has no counterpart: its callers time `sampling_iteration()` with the wall clock; the drop-in classes of
+ * mjhmc_amd.samplers switch it off.) */
+int mjhmc_set_timing(mjhmc_sampler* s, int on);
+
 /* Stream synchronisation (bench harness). */
 int mjhmc_sync(mjhmc_sampler* s);
 

@@ -103,6 +103,7 @@ PROTOTYPES = {
     'mjhmc_comm_allgather_ring': (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     'mjhmc_comm_allgather_columns': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, _P, _P]),
     'mjhmc_last_timing': (ctypes.c_int, [_P, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
+    'mjhmc_set_timing': (ctypes.c_int, [_P, ctypes.c_int]),
     'mjhmc_sync': (ctypes.c_int, [_P]),
 }
 

@@ -1624,7 +1624,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   }
 #endif  // MJHMC_TEST_HOOKS
   std::vector<Launch> launches;
-  HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
+  if (s->timing_on) HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i0 = 0; i0 < n_iter; i0 += kMaxFuse) {
     const int j = (int)launches.size();
     Launch l;
@@ -1638,7 +1638,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
     launches.push_back(l);
     xin = l.xout;
   }
-  HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  if (s->timing_on) HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
   TRY(read_back_call(s, (size_t)n_iter, &hc, hs.data()));
@@ -1682,7 +1682,7 @@ static int iterate_fused_t(mjhmc_sampler* s, int n_iter, int ring_slot0, mjhmc_i
   s->tick += (uint64_t)attempts;
   if (n_done) *n_done = done;
   s->last_jump_launches = attempts;
-  s->timing_pending = true;
+  s->timing_pending = s->timing_on;
   return 0;
 }
 
@@ -1779,7 +1779,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
 
   std::vector<void*> xout(n_iter);
   void* xin = s->Xcur;
-  HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
+  if (s->timing_on) HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i = 0; i < n_iter; ++i) {
     void* xo;
     double* dring = s->dwell_scratch;
@@ -2133,7 +2133,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
     TRY(dl_done(i, xo));
     xin = xo;
   }
-  HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  if (s->timing_on) HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   Control hc;
   std::vector<long long> hs((size_t)n_iter * 4);
   std::vector<int> hcnt((size_t)n_iter + 1);   // (+ the list the last iteration's movers went to)
@@ -2175,7 +2175,7 @@ static int iterate_t(mjhmc_sampler* s, int n_iter, const double* replay_normal, 
   // kernel, on the sampler's stream).  Per-launch event pairs were measured to cost more than they tell:
   // every marker packet opens a ~5 us bubble between back-to-back kernels.
   s->last_jump_launches = attempts;
-  s->timing_pending = true;
+  s->timing_pending = s->timing_on;
   return 0;
 }
 
@@ -2635,6 +2635,13 @@ int mjhmc_last_timing(mjhmc_sampler* s, double* total_ms, double* jump_kernel_ms
   if (total_ms) *total_ms = s->last_total_ms;
   if (jump_kernel_ms) *jump_kernel_ms = s->last_jump_ms;
   if (n_jump_launches) *n_jump_launches = s->last_jump_launches;
+  return 0;
+}
+
+int mjhmc_set_timing(mjhmc_sampler* s, int on) {
+  if (!s) return fail(MJHMC_ERR_INVALID, "sampler is NULL");
+  s->timing_on = on != 0;
+  if (!s->timing_on) s->timing_pending = false;
   return 0;
 }
 

@@ -157,6 +157,7 @@ struct mjhmc_sampler {
   double last_total_ms = 0, last_jump_ms = 0;
   int last_jump_launches = 0;
   bool timing_pending = false;
+  bool timing_on = true;         // mjhmc_set_timing: the HIP-event pair around a call's launches (two marker packets, ~8 us of a call)
   void* pipe_pin[2] = {nullptr, nullptr};       // pinned double buffer of the pipelined device -> host copies (copy_to_host)
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};
   // mjhmc_iterate_download: the ring slot of an iteration goes to the host while the next iterations run -- its own stream,

@@ -947,7 +947,7 @@ int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal,
                       const double* replay_unif, int ring_slot0, mjhmc_iter_stats* per_iter, int* n_done) {
   const size_t DN = (size_t)s->D * s->N;
   int done = 0;
-  HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
+  if (s->timing_on) HIPCHK(hipEventRecord(s->ev_total[0], s->stream));
   for (int i = 0; i < n_iter; ++i) {
     TRY(traj_begin_impl(s, nullptr));
     HostTraj* t = s->ht;
@@ -971,10 +971,10 @@ int multipass_iterate(mjhmc_sampler* s, int n_iter, const double* replay_normal,
     if (st.nonfinite) break;
     done += 1;
   }
-  HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
+  if (s->timing_on) HIPCHK(hipEventRecord(s->ev_total[1], s->stream));
   s->undo_valid = (n_iter == 1 && done == 1);   // mjhmc_rollback's contract: the last call was ONE committed iteration
   s->last_jump_launches = std::min(done + 1, n_iter);
-  s->timing_pending = true;
+  s->timing_pending = s->timing_on;
   if (n_done) *n_done = done;
   return 0;
 }

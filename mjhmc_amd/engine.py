@@ -332,6 +332,10 @@ class DeviceSampler(object):
         check(self.lib.mjhmc_last_timing(self.handle, ctypes.byref(t), ctypes.byref(k), ctypes.byref(n)), self.lib)
         return dict(total_ms=t.value, jump_kernel_ms=k.value, n_jump_launches=n.value)
 
+    def set_timing(self, on):
+        """the HIP-event pair around a call's launches (last_timing): ~8 us of every call; on by default"""
+        check(self.lib.mjhmc_set_timing(self.handle, 1 if on else 0), self.lib)
+
     def sync(self):
         check(self.lib.mjhmc_sync(self.handle), self.lib)
 

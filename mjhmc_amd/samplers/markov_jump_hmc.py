@@ -81,6 +81,7 @@ class HMCBase(object):
                                         seed=self.seed, first_particle_id=first,
                                         dtype=self._dtype or getattr(distribution, 'state_dtype', 'float64'),
                                         mode=self._mode)
+        self._dev.set_timing(False)     # (nothing here reads the device-side timing: two marker packets less per call)
         # HMCState.__init__ evaluates E and dEdX once on every particle (hmc_state.py:28-39)
         distribution.E_count += self.nbatch
         distribution.dEdX_count += self.nbatch

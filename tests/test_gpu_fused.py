@@ -276,6 +276,29 @@ def test_list_carried_between_calls_equals_a_scan_per_call(kind, D, N, monkeypat
     assert 0 < stats_a[1].n_cold < N // 2
 
 
+def test_timing_switched_off_changes_nothing_but_the_markers():
+    """mjhmc_set_timing(0): calls record no HIP-event pair (the drop-in classes run that way); the chain is the same, and
+    mjhmc_last_timing keeps reporting the last RECORDED call instead of failing on events that were never recorded."""
+    from mjhmc_amd import _lib
+    (a, b), _lib = _pair('E_ISO_GAUSS', 64, 500, _lib.MODE_MJHMC)
+    for s in (a, b):
+        s.set_hparams(0.05, 7, 0.1, 1.0, 0.5)
+    a.iterate(3)
+    b.iterate(3)
+    t_before = b.last_timing()
+    assert t_before['n_jump_launches'] == 3 and t_before['total_ms'] > 0
+    b.set_timing(False)
+    for n in (1, 5, 1):
+        sa, da = a.iterate(n)
+        sb, db = b.iterate(n)
+        assert da == db == n and [_stats_tuple(x) for x in sa] == [_stats_tuple(x) for x in sb]
+    _same_state(a, b, _lib)
+    assert b.last_timing()['total_ms'] == t_before['total_ms']          # nothing recorded since
+    b.set_timing(True)
+    b.iterate(2)
+    assert b.last_timing()['total_ms'] > 0 and b.last_timing()['total_ms'] != t_before['total_ms']
+
+
 def test_compacted_passes_failure_in_the_middle_of_a_batch(monkeypatch):
     """A non-finite rate in iteration i > 0 of a multi-iteration call through the compacted passes: the call stops
     there and the state is the one iteration i-1 handed on -- INCLUDING the momentum refresh of its R-movers, which
