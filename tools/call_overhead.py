@@ -26,7 +26,7 @@ for _ in range(200):
 wall = (time.perf_counter() - t) / 200 * 1e3
 try:
     print('wall per call ms', wall, 'launches (events)', s.last_timing())
-except Exception:          # (test build with MJHMC_NO_EVENTS: nothing was recorded)
+except Exception:          # (nothing recorded)
     print('wall per call ms', wall)
 pr = cProfile.Profile()
 pr.enable()
